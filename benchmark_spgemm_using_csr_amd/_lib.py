@@ -1,0 +1,82 @@
+"""ctypes binding of libbhsparse_hip.so (include/bhsparse_hip.h).
+
+No fallback: if the HIP library is missing or fails to load this raises — the
+product path never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libbhsparse_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "bhsparse_hip.h")
+
+BHS_SUCCESS = 0
+BHS_ERR_INVALID_ARG = -1
+BHS_ERR_NO_DEVICE = -2
+BHS_ERR_ALLOC = -3
+BHS_ERR_LAUNCH = -4
+BHS_ERR_NNZ_OVERFLOW = -5
+BHS_ERR_NOT_READY = -6
+BHS_ERR_INTERNAL = -7
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int), ("ms", C.c_double),
+                ("rows", C.c_int64), ("products", C.c_int64), ("nnz_out", C.c_int64),
+                ("nnzA_rows", C.c_int64)]
+
+
+# every symbol include/bhsparse_hip.h declares: (restype, argtypes)
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+SYMBOLS = {
+    "bhs_create": (_i, [C.POINTER(_vp), _i, C.POINTER(_i)]),
+    "bhs_destroy": (_i, [_vp]),
+    "bhs_set_verbose": (_i, [_vp, _i]),
+    "bhs_set_data": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "bhs_set_data_device": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "bhs_free_data": (_i, [_vp]),
+    "bhs_warmup": (_i, [_vp]),
+    "bhs_spgemm": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(C.c_double)]),
+    "bhs_get_nnzC": (_i, [_vp, C.POINTER(_i)]),
+    "bhs_get_C": (_i, [_vp, _vp, _vp]),
+    "bhs_get_rowptrC": (_i, [_vp, _vp]),
+    "bhs_get_C_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "bhs_get_kernel_stats": (_i, [_vp, C.POINTER(KernelStat), _i]),
+    "bhs_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "bhs_strerror": (C.c_char_p, [_i]),
+    "bhs_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libbhsparse_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("bhsparse_hip.hip", "bhs_kernels.hip.h")] + [HEADER]
+    stale = (not os.path.exists(SO_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                "libbhsparse_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C %s`. There is no CPU fallback." % (SO_PATH, CSRC))
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)      # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return load().bhs_strerror(int(code)).decode()

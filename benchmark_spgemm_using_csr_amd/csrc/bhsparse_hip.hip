@@ -1,0 +1,732 @@
+// bhsparse_hip.hip — pipeline + C-ABI of libbhsparse_hip.so (see include/bhsparse_hip.h).
+//
+// Pipeline of one bhs_spgemm() (replaces bhsparse::spgemm_cuda, bhsparse.h:297-339):
+//   stage 1  k_upper_bound (ub per row, nnzCt, symbolic-bin histogram)          <- compute_nnzCt + statistics()
+//            k_fill_queues  (row ids grouped by symbolic bin, on device)
+//   stage 2  k_row_hash<.., NUM=0> per non-empty bin: exact nnz of every C row  <- replaces upper-bound Ct + copy stage
+//   stage 3  k_scan_* : rowPtrC = exclusive scan, nnz(C), numeric-bin histogram <- create_C
+//            (grow-only pool) make room for C; k_fill_queues by nnz per row
+//   stage 4  k_row_hash<.., NUM=1> per non-empty bin: C written once, sorted    <- ESC_*/EM_* + copyCt2C_*
+// Two host<->device round trips of a few hundred bytes (bin counts, nnzCt, nnzC)
+// instead of the reference's whole-array D2H/H2D of rowPtrCt, the 6*m queue and
+// rowPtrC (bhsparse_cuda.h:280, 289, 2787-2808).
+#include "../../include/bhsparse_hip.h"
+#include "bhs_kernels.hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace bhs;
+
+namespace {
+
+#define BHS_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            if (h && h->verbose)                                                            \
+                fprintf(stderr, "[bhsparse_hip] %s failed: %s (%s:%d)\n", #call,            \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                        \
+            (void)hipGetLastError();                                                        \
+            return e__ == hipErrorOutOfMemory ? (int)BHS_ERR_ALLOC : (int)BHS_ERR_LAUNCH;   \
+        }                                                                                   \
+    } while (0)
+
+#define BHS_TRY(call)                     \
+    do {                                  \
+        const int rc__ = (call);          \
+        if (rc__ != BHS_SUCCESS) return rc__; \
+    } while (0)
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+// ---- bin tables ------------------------------------------------------------
+// Symbolic bins are chosen by the per-row upper bound ub (the table must hold
+// every product's column in the worst case: ub <= 3/4 * TS); numeric bins by the
+// exact per-row nnz found by the symbolic pass (nnz <= 3/4 * TS).
+struct KernelCfg {
+    int log2ts;     // table size
+    int block;      // lanes per row
+    bool win;       // column-window variant
+};
+constexpr int kNumSymBins = 11;     // bin 0 = empty rows (no kernel)
+const KernelCfg kSymCfg[kNumSymBins] = {
+    {0, 0, false},   {6, 64, false},  {7, 64, false},   {8, 64, false},   {9, 64, false},  {10, 64, false},
+    {11, 64, false}, {12, 64, false}, {13, 256, false}, {15, 1024, false}, {15, 1024, true}};
+constexpr int kNumNumBins = 9;
+const KernelCfg kNumCfg[kNumNumBins] = {
+    {0, 0, false},   {6, 64, false},  {7, 64, false},   {8, 64, false},  {9, 64, false},
+    {10, 64, false}, {11, 64, false}, {12, 256, false}, {12, 256, true}};
+
+BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2)
+{
+    BinSpec s;
+    memset(&s, 0, sizeof(s));
+    s.nbins = nbins;
+    s.upper[0] = 0;
+    for (int b = 1; b < nbins; ++b) {
+        int lg = std::min(cfg[b].log2ts, maxLog2);
+        int ts = 1 << lg;
+        s.upper[b] = cfg[b].win ? 0x7fffffff : ts - ts / 4;
+        if (b > 1 && s.upper[b] < s.upper[b - 1]) s.upper[b] = s.upper[b - 1];
+    }
+    s.upper[nbins - 1] = 0x7fffffff;
+    return s;
+}
+
+struct StatRec {
+    const char* name;
+    int launches = 0;
+    double ms = 0;
+    int64_t rows = 0, products = 0, nnz_out = 0, nnzA_rows = 0;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int stat;   // index into stats
+};
+
+}  // namespace
+
+struct bhs_handle {
+    int device = 0;
+    int numCU = 256;
+    int verbose = 0;
+    hipStream_t stream = nullptr;
+    bool hasData = false, ownAB = false, hasC = false;
+    int m = 0, k = 0, n = 0, nnzA = 0, nnzB = 0;
+    const int *dAp = nullptr, *dAj = nullptr, *dBp = nullptr, *dBj = nullptr;
+    const double *dAx = nullptr, *dBx = nullptr;
+    DevBuf ownA[3], ownB[3];
+    int bSorted = 1;
+    int logL = 5, ubG = 8;
+    // C
+    DevBuf Cp, Cj, Cx;
+    long long nnzC = 0;
+    long long nnzCt = 0;
+    // workspace
+    DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
+    int* hostSmall = nullptr;            // pinned mirror of `small`
+    // options
+    int forcePath = 0;
+    int maxTableLog2 = 15;
+    // timing
+    hipEvent_t ev[5] = {};
+    std::vector<EventPair> evPool;
+    size_t evUsed = 0;
+    std::vector<StatRec> stats;
+    double stageMs[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+// layout of the `small` device buffer (ints)
+enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S_NUM_START = 64,
+       S_NUM_CURSOR = 80, S_TOTAL_CT = 96 /* 2 ints = u64 */, S_TOTAL_C = 98 /* 2 ints = i64 */,
+       S_ERR = 100,
+       S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
+       S_NUM_SUMS = 104 + 96,
+       S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
+       S_SORTED = 300, S_SMALL_INTS = 320 };
+
+int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return BHS_SUCCESS;
+    if (b.p) { BHS_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (bytes == 0) bytes = 16;
+    BHS_HIP(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return BHS_SUCCESS;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int stat_index(bhs_handle* h, const char* name)
+{
+    for (size_t i = 0; i < h->stats.size(); ++i)
+        if (h->stats[i].name == name || strcmp(h->stats[i].name, name) == 0) return (int)i;
+    StatRec r;
+    r.name = name;
+    h->stats.push_back(r);
+    return (int)h->stats.size() - 1;
+}
+
+int timed_begin(bhs_handle* h, const char* name, EventPair** out)
+{
+    if (h->evUsed == h->evPool.size()) {
+        EventPair p;
+        BHS_HIP(hipEventCreate(&p.a));
+        BHS_HIP(hipEventCreate(&p.b));
+        p.stat = 0;
+        h->evPool.push_back(p);
+    }
+    EventPair* p = &h->evPool[h->evUsed++];
+    p->stat = stat_index(h, name);
+    BHS_HIP(hipEventRecord(p->a, h->stream));
+    *out = p;
+    return BHS_SUCCESS;
+}
+
+int timed_end(bhs_handle* h, EventPair* p)
+{
+    BHS_HIP(hipEventRecord(p->b, h->stream));
+    return BHS_SUCCESS;
+}
+
+template <int LOG2TS, int BLOCK, bool NUM, bool WIN>
+int launch_row_hash(bhs_handle* h, const int* queue, int qn, int* CpOrCnt)
+{
+    constexpr int TS = 1 << LOG2TS;
+    auto kern = k_row_hash<TS, LOG2TS, BLOCK, NUM, WIN>;
+    const size_t smem = sizeof(RowHashSmem<TS, BLOCK, NUM>);
+    static bool attrDone = false;
+    if (!attrDone) {
+        if (smem > 48 * 1024)
+            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attrDone = true;
+    }
+    // resident groups per CU: bounded by LDS (160 KiB) and by 32 waves / CU
+    int perCU = (int)std::min<size_t>((160 * 1024) / (smem + 256), (size_t)(2048 / BLOCK));
+    if (perCU < 1) perCU = 1;
+    long long grid = std::min<long long>((long long)qn, (long long)h->numCU * perCU * 2);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->stream, queue, qn, h->n, h->logL,
+                       h->bSorted, h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p,
+                       CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p, (int*)h->small.p + S_ERR);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <bool NUM>
+int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int* queue, int qn, int* CpOrCnt)
+{
+    const int lg = std::min(c.log2ts, h->maxTableLog2);
+    const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
+#define BHS_CASE(LG, BL, W) \
+    if (lg == LG && c.block == BL && win == W) return launch_row_hash<LG, BL, NUM, W>(h, queue, qn, CpOrCnt)
+    if (!win) {
+        BHS_CASE(6, 64, false);
+        BHS_CASE(7, 64, false);
+        BHS_CASE(8, 64, false);
+        BHS_CASE(9, 64, false);
+        BHS_CASE(10, 64, false);
+        BHS_CASE(11, 64, false);
+        if constexpr (!NUM) {
+            BHS_CASE(12, 64, false);
+            BHS_CASE(13, 256, false);
+            BHS_CASE(15, 1024, false);
+        } else {
+            BHS_CASE(12, 256, false);
+        }
+    }
+    // window variants: workgroup per row; table chosen by the cap
+    if constexpr (!NUM) {
+        if (lg >= 15) return launch_row_hash<15, 1024, NUM, true>(h, queue, qn, CpOrCnt);
+        if (lg >= 12) return launch_row_hash<12, 256, NUM, true>(h, queue, qn, CpOrCnt);
+        return launch_row_hash<8, 256, NUM, true>(h, queue, qn, CpOrCnt);
+    } else {
+        if (lg >= 12) return launch_row_hash<12, 256, NUM, true>(h, queue, qn, CpOrCnt);
+        return launch_row_hash<8, 256, NUM, true>(h, queue, qn, CpOrCnt);
+    }
+#undef BHS_CASE
+}
+
+const char* kSymNames[kNumSymBins] = {"", "symbolic_wave<64>", "symbolic_wave<128>", "symbolic_wave<256>",
+                                      "symbolic_wave<512>", "symbolic_wave<1024>", "symbolic_wave<2048>",
+                                      "symbolic_wave<4096>", "symbolic_wg<8192>", "symbolic_wg<32768>",
+                                      "symbolic_wg_window<32768>"};
+const char* kNumNames[kNumNumBins] = {"", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
+                                      "numeric_wave<512>", "numeric_wave<1024>", "numeric_wave<2048>",
+                                      "numeric_wg<4096>", "numeric_wg_window<4096>"};
+
+int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
+{
+    const int G = h->ubG;
+    const int rowsPerBlock = 256 / G;
+    long long grid = ((long long)h->m + rowsPerBlock - 1) / rowsPerBlock;
+    grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * 32));
+    int* small = (int*)h->small.p;
+#define BHS_UB(GG)                                                                                   \
+    case GG:                                                                                         \
+        hipLaunchKernelGGL(k_upper_bound<GG>, dim3((unsigned)grid), dim3(256), 0, h->stream, h->m,   \
+                           h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,                     \
+                           (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec);    \
+        break;
+    switch (G) {
+        BHS_UB(1) BHS_UB(2) BHS_UB(4) BHS_UB(8) BHS_UB(16) BHS_UB(32) BHS_UB(64)
+        default: return BHS_ERR_INTERNAL;
+    }
+#undef BHS_UB
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+int pow2_at_least(double x, int lo, int hi)
+{
+    int v = lo;
+    while (v < hi && (double)v < x) v <<= 1;
+    return v;
+}
+
+int run_pipeline(bhs_handle* h)
+{
+    const int m = h->m;
+    h->evUsed = 0;
+    for (auto& s : h->stats) { s.launches = 0; s.ms = 0; s.rows = s.products = s.nnz_out = s.nnzA_rows = 0; }
+    BHS_HIP(hipEventRecord(h->ev[0], h->stream));
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    h->nnzC = 0;
+    h->nnzCt = 0;
+    h->hasC = false;
+
+    BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
+    if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
+        BHS_HIP(hipMemsetAsync(h->Cp.p, 0, sizeof(int) * ((size_t)m + 1), h->stream));
+        for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        h->hasC = true;
+        return BHS_SUCCESS;
+    }
+    BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
+    BHS_TRY(ensure(h, h->queue, sizeof(int) * (size_t)m));
+    const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
+    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
+
+    // ------------------------------------------------------------ stage 1
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2);
+    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12));
+    BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
+    EventPair* ep;
+    BHS_TRY(timed_begin(h, "upper_bound", &ep));
+    BHS_TRY(launch_upper_bound(h, symSpec));
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches++;
+    h->stats[ep->stat].rows += m;
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    int symCount[kMaxBins], symStart[kMaxBins + 1];
+    symStart[0] = 0;
+    for (int b = 0; b < kMaxBins; ++b) {
+        symCount[b] = hs[S_SYM_COUNT + b];
+        symStart[b + 1] = symStart[b] + (b == 0 ? 0 : symCount[b]);
+    }
+    unsigned long long tot;
+    memcpy(&tot, hs + S_TOTAL_CT, 8);
+    h->nnzCt = (long long)tot;
+    BHS_HIP(hipMemcpyAsync(small + S_SYM_START, symStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+    {
+        long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 16);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           (const int*)h->ub.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
+                           small + S_SYM_CURSOR, (int*)h->queue.p, symSpec,
+                           (unsigned long long*)(small + S_SYM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+    }
+    BHS_HIP(hipEventRecord(h->ev[1], h->stream));
+
+    // ------------------------------------------------------------ stage 2: symbolic
+    int symStat[kMaxBins], numStat[kMaxBins];
+    for (int b = 0; b < kMaxBins; ++b) symStat[b] = numStat[b] = -1;
+    for (int b = 1; b < kNumSymBins; ++b) {
+        if (!symCount[b]) continue;
+        BHS_TRY(timed_begin(h, kSymNames[b], &ep));
+        int rc = dispatch_bin<false>(h, kSymCfg[b], (const int*)h->queue.p + symStart[b], symCount[b], (int*)h->Cp.p);
+        if (rc) return rc;
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[b];
+        symStat[b] = ep->stat;
+    }
+    BHS_HIP(hipEventRecord(h->ev[2], h->stream));
+
+    // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
+    BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p,
+                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
+                       (long long*)h->blockSum.p, (long long*)(small + S_TOTAL_C));
+    hipLaunchKernelGGL(k_scan_apply, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (int*)h->Cp.p,
+                       (const long long*)h->blockSum.p);
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += 3;
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    long long nnzC;
+    memcpy(&nnzC, hs + S_TOTAL_C, 8);
+    if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+    if (nnzC > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
+    h->nnzC = nnzC;
+    int numCount[kMaxBins], numStart[kMaxBins + 1];
+    numStart[0] = 0;
+    for (int b = 0; b < kMaxBins; ++b) {
+        numCount[b] = hs[S_NUM_COUNT + b];
+        numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
+    }
+    BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
+    BHS_TRY(ensure(h, h->Cx, sizeof(double) * (size_t)std::max<long long>(nnzC, 1)));
+    BHS_HIP(hipMemcpyAsync(small + S_NUM_START, numStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+    {
+        long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 16);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
+                           small + S_NUM_CURSOR, (int*)h->queue.p, numSpec,
+                           (unsigned long long*)(small + S_NUM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+    }
+    BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+
+    // ------------------------------------------------------------ stage 4: numeric
+    for (int b = 1; b < kNumNumBins; ++b) {
+        if (!numCount[b]) continue;
+        BHS_TRY(timed_begin(h, kNumNames[b], &ep));
+        int rc = dispatch_bin<true>(h, kNumCfg[b], (const int*)h->queue.p + numStart[b], numCount[b], (int*)h->Cp.p);
+        if (rc) return rc;
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += numCount[b];
+        numStat[b] = ep->stat;
+    }
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipEventRecord(h->ev[4], h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+    for (int b = 1; b < kMaxBins; ++b) {
+        unsigned long long v[3];
+        if (symStat[b] >= 0) {
+            memcpy(v, hs + S_SYM_SUMS + 6 * b, sizeof(v));
+            StatRec& r = h->stats[symStat[b]];
+            r.products += (int64_t)v[0]; r.nnzA_rows += (int64_t)v[2];
+        }
+        if (numStat[b] >= 0) {
+            memcpy(v, hs + S_NUM_SUMS + 6 * b, sizeof(v));
+            StatRec& r = h->stats[numStat[b]];
+            r.products += (int64_t)v[0]; r.nnz_out += (int64_t)v[1]; r.nnzA_rows += (int64_t)v[2];
+        }
+    }
+
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0;
+        BHS_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->stageMs[i] = ms;
+    }
+    for (size_t i = 0; i < h->evUsed; ++i) {
+        float ms = 0;
+        BHS_HIP(hipEventElapsedTime(&ms, h->evPool[i].a, h->evPool[i].b));
+        h->stats[h->evPool[i].stat].ms += ms;
+    }
+    h->hasC = true;
+    return BHS_SUCCESS;
+}
+
+int finish_set_data(bhs_handle* h)
+{
+    // derived launch parameters
+    const double avgA = h->m > 0 ? (double)h->nnzA / h->m : 1.0;
+    const double avgB = h->k > 0 ? (double)h->nnzB / h->k : 1.0;
+    h->ubG = pow2_at_least(avgA, 1, 64);
+    int L = pow2_at_least(avgB, 1, 64);
+    int lg = 0;
+    while ((1 << lg) < L) ++lg;
+    h->logL = lg;
+    BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
+    h->bSorted = 1;
+    if (h->nnzB > 1 && h->k > 0) {
+        int* small = (int*)h->small.p;
+        BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
+        long long grid = std::min<long long>(((long long)h->nnzB + 255) / 256, (long long)h->numCU * 16);
+        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj,
+                           small + S_SORTED);
+        BHS_HIP(hipGetLastError());
+        int flag = 0;
+        BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        h->bSorted = flag ? 0 : 1;
+    }
+    h->hasData = true;
+    h->hasC = false;
+    return BHS_SUCCESS;
+}
+
+}  // namespace
+
+// ============================================================== C-ABI
+extern "C" {
+
+int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
+{
+    if (!out || device_count != 1) return BHS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return BHS_ERR_NO_DEVICE; }
+    const int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= ndev) return BHS_ERR_INVALID_ARG;
+    bhs_handle* h = new (std::nothrow) bhs_handle();
+    if (!h) return BHS_ERR_ALLOC;
+    h->device = dev;
+    if (hipSetDevice(dev) != hipSuccess) { delete h; return BHS_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return BHS_ERR_NO_DEVICE; }
+    h->numCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "[bhsparse_hip] device %d is %s; this library carries gfx950 code objects only\n", dev,
+                prop.gcnArchName);
+        delete h;
+        return BHS_ERR_NO_DEVICE;
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    for (int i = 0; i < 5; ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * S_SMALL_INTS, hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        return BHS_ERR_ALLOC;
+    }
+    h->stats.reserve(64);
+    *out = h;
+    return BHS_SUCCESS;
+}
+
+int bhs_set_verbose(bhs_handle* h, int level)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (level && !h->verbose) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess)
+            printf("Device [ %d ] %s (%s) @ %.0f MHz, %d CUs, %.0f GB HBM\n", h->device, prop.name, prop.gcnArchName,
+                   prop.clockRate * 1e-3, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+    }
+    h->verbose = level;
+    return BHS_SUCCESS;
+}
+
+int bhs_free_data(bhs_handle* h)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 3; ++i) { release(h->ownA[i]); release(h->ownB[i]); }
+    release(h->Cj);
+    release(h->Cx);
+    h->dAp = h->dAj = h->dBp = h->dBj = nullptr;
+    h->dAx = h->dBx = nullptr;
+    h->hasData = h->hasC = h->ownAB = false;
+    return BHS_SUCCESS;
+}
+
+int bhs_destroy(bhs_handle* h)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    bhs_free_data(h);
+    release(h->Cp);
+    release(h->ub);
+    release(h->queue);
+    release(h->blockSum);
+    release(h->small);
+    if (h->hostSmall) (void)hipHostFree(h->hostSmall);
+    for (auto& p : h->evPool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (int i = 0; i < 5; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BHS_SUCCESS;
+}
+
+static int check_dims(int m, int k, int n, int nnzA, int nnzB)
+{
+    return (m < 0 || k < 0 || n < 0 || nnzA < 0 || nnzB < 0) ? BHS_ERR_INVALID_ARG : BHS_SUCCESS;
+}
+
+int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const double* csrValA, const int* csrRowPtrA,
+                 const int* csrColIndA, int nnzB, const double* csrValB, const int* csrRowPtrB,
+                 const int* csrColIndB)
+{
+    if (!h || check_dims(m, k, n, nnzA, nnzB)) return BHS_ERR_INVALID_ARG;
+    if (!csrRowPtrA || !csrRowPtrB || (nnzA && (!csrValA || !csrColIndA)) || (nnzB && (!csrValB || !csrColIndB)))
+        return BHS_ERR_INVALID_ARG;
+    BHS_HIP(hipSetDevice(h->device));
+    bhs_free_data(h);
+    h->m = m; h->k = k; h->n = n; h->nnzA = nnzA; h->nnzB = nnzB;
+    BHS_TRY(ensure(h, h->ownA[0], sizeof(int) * ((size_t)m + 1)));
+    BHS_TRY(ensure(h, h->ownA[1], sizeof(int) * (size_t)std::max(nnzA, 1)));
+    BHS_TRY(ensure(h, h->ownA[2], sizeof(double) * (size_t)std::max(nnzA, 1)));
+    BHS_TRY(ensure(h, h->ownB[0], sizeof(int) * ((size_t)k + 1)));
+    BHS_TRY(ensure(h, h->ownB[1], sizeof(int) * (size_t)std::max(nnzB, 1)));
+    BHS_TRY(ensure(h, h->ownB[2], sizeof(double) * (size_t)std::max(nnzB, 1)));
+    BHS_HIP(hipMemcpyAsync(h->ownA[0].p, csrRowPtrA, sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnzA) {
+        BHS_HIP(hipMemcpyAsync(h->ownA[1].p, csrColIndA, sizeof(int) * (size_t)nnzA, hipMemcpyHostToDevice, h->stream));
+        BHS_HIP(hipMemcpyAsync(h->ownA[2].p, csrValA, sizeof(double) * (size_t)nnzA, hipMemcpyHostToDevice, h->stream));
+    }
+    BHS_HIP(hipMemcpyAsync(h->ownB[0].p, csrRowPtrB, sizeof(int) * ((size_t)k + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnzB) {
+        BHS_HIP(hipMemcpyAsync(h->ownB[1].p, csrColIndB, sizeof(int) * (size_t)nnzB, hipMemcpyHostToDevice, h->stream));
+        BHS_HIP(hipMemcpyAsync(h->ownB[2].p, csrValB, sizeof(double) * (size_t)nnzB, hipMemcpyHostToDevice, h->stream));
+    }
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    h->dAp = (const int*)h->ownA[0].p; h->dAj = (const int*)h->ownA[1].p; h->dAx = (const double*)h->ownA[2].p;
+    h->dBp = (const int*)h->ownB[0].p; h->dBj = (const int*)h->ownB[1].p; h->dBx = (const double*)h->ownB[2].p;
+    h->ownAB = true;
+    return finish_set_data(h);
+}
+
+int bhs_set_data_device(bhs_handle* h, int m, int k, int n, int nnzA, const double* d_valA, const int* d_rowPtrA,
+                        const int* d_colIndA, int nnzB, const double* d_valB, const int* d_rowPtrB,
+                        const int* d_colIndB)
+{
+    if (!h || check_dims(m, k, n, nnzA, nnzB)) return BHS_ERR_INVALID_ARG;
+    if (!d_rowPtrA || !d_rowPtrB || (nnzA && (!d_valA || !d_colIndA)) || (nnzB && (!d_valB || !d_colIndB)))
+        return BHS_ERR_INVALID_ARG;
+    BHS_HIP(hipSetDevice(h->device));
+    bhs_free_data(h);
+    h->m = m; h->k = k; h->n = n; h->nnzA = nnzA; h->nnzB = nnzB;
+    h->dAp = d_rowPtrA; h->dAj = d_colIndA; h->dAx = d_valA;
+    h->dBp = d_rowPtrB; h->dBj = d_colIndB; h->dBx = d_valB;
+    h->ownAB = false;
+    return finish_set_data(h);
+}
+
+int bhs_warmup(bhs_handle* h)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->hasData) return BHS_ERR_NOT_READY;
+    BHS_HIP(hipSetDevice(h->device));
+    return run_pipeline(h);
+}
+
+int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_out, double stage_ms_out[4])
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->hasData) return BHS_ERR_NOT_READY;
+    BHS_HIP(hipSetDevice(h->device));
+    const int rc = run_pipeline(h);
+    if (rc) return rc;
+    if (h->verbose) {
+        printf("STAGE 1 time: %g ms.\n", h->stageMs[0]);
+        printf("STAGE 2 time: %g ms.\n", h->stageMs[1]);
+        printf("exact size %lld out of full size %lld\n", h->nnzC, h->nnzCt);
+        printf("STAGE 3 time: %g ms.\n", h->stageMs[2]);
+        printf("STAGE 4 time: %g ms.\n", h->stageMs[3]);
+    }
+    if (rowPtrC_out) {
+        BHS_HIP(hipMemcpyAsync(rowPtrC_out, h->Cp.p, sizeof(int) * ((size_t)h->m + 1), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (nnzCt_out) *nnzCt_out = h->nnzCt;
+    if (nnzC_out) *nnzC_out = (int)h->nnzC;
+    if (stage_ms_out) for (int i = 0; i < 4; ++i) stage_ms_out[i] = h->stageMs[i];
+    return BHS_SUCCESS;
+}
+
+int bhs_get_nnzC(bhs_handle* h, int* nnzC_out)
+{
+    if (!h || !nnzC_out) return BHS_ERR_INVALID_ARG;
+    if (!h->hasC) return BHS_ERR_NOT_READY;
+    *nnzC_out = (int)h->nnzC;
+    return BHS_SUCCESS;
+}
+
+int bhs_get_C(bhs_handle* h, int* csrColIndC, double* csrValC)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->hasC) return BHS_ERR_NOT_READY;
+    if (h->nnzC && (!csrColIndC || !csrValC)) return BHS_ERR_INVALID_ARG;
+    BHS_HIP(hipSetDevice(h->device));
+    if (h->nnzC) {
+        BHS_HIP(hipMemcpyAsync(csrColIndC, h->Cj.p, sizeof(int) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(csrValC, h->Cx.p, sizeof(double) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
+    }
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    return BHS_SUCCESS;
+}
+
+int bhs_get_rowptrC(bhs_handle* h, int* csrRowPtrC)
+{
+    if (!h || !csrRowPtrC) return BHS_ERR_INVALID_ARG;
+    if (!h->hasC) return BHS_ERR_NOT_READY;
+    BHS_HIP(hipSetDevice(h->device));
+    BHS_HIP(hipMemcpyAsync(csrRowPtrC, h->Cp.p, sizeof(int) * ((size_t)h->m + 1), hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    return BHS_SUCCESS;
+}
+
+int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC, const double** d_valC)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->hasC) return BHS_ERR_NOT_READY;
+    if (d_rowPtrC) *d_rowPtrC = (const int*)h->Cp.p;
+    if (d_colIndC) *d_colIndC = (const int*)h->Cj.p;
+    if (d_valC) *d_valC = (const double*)h->Cx.p;
+    return BHS_SUCCESS;
+}
+
+int bhs_get_kernel_stats(bhs_handle* h, bhs_kernel_stat* out, int cap)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    int nrec = 0;
+    for (auto& s : h->stats) {
+        if (!s.launches) continue;
+        if (out && nrec < cap) {
+            out[nrec].name = s.name;
+            out[nrec].launches = s.launches;
+            out[nrec].ms = s.ms;
+            out[nrec].rows = s.rows;
+            out[nrec].products = s.products;
+            out[nrec].nnz_out = s.nnz_out;
+            out[nrec].nnzA_rows = s.nnzA_rows;
+        }
+        ++nrec;
+    }
+    return nrec;
+}
+
+int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
+{
+    if (!h || !key) return BHS_ERR_INVALID_ARG;
+    if (!strcmp(key, "force_path")) { h->forcePath = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "max_table_log2")) {
+        if (value < 6 || value > 15) return BHS_ERR_INVALID_ARG;
+        h->maxTableLog2 = (int)value;
+        return BHS_SUCCESS;
+    }
+    if (!strcmp(key, "verbose")) return bhs_set_verbose(h, (int)value);
+    return BHS_ERR_INVALID_ARG;
+}
+
+const char* bhs_strerror(int status)
+{
+    switch (status) {
+        case BHS_SUCCESS: return "success";
+        case BHS_ERR_INVALID_ARG: return "invalid argument";
+        case BHS_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+        case BHS_ERR_ALLOC: return "device memory allocation failed";
+        case BHS_ERR_LAUNCH: return "HIP runtime / kernel launch error";
+        case BHS_ERR_NNZ_OVERFLOW: return "nnz(C) exceeds int32 index_type";
+        case BHS_ERR_NOT_READY: return "call order violated (no data / no result yet)";
+        case BHS_ERR_INTERNAL: return "accumulator overflow not resolved";
+        default: return "unknown bhsparse_hip status";
+    }
+}
+
+const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""Input generators for the SpGEMM benchmark: Poisson stencil matrices and the
+deterministic value fill.
+
+Replaces the reference's use of cusp::gallery::poisson{5,9,7,27}pt
+(SpGEMM_cuda/main.cu:30-53) and its `rand()%9+1` value overwrite
+(main.cu:79-94; made deterministic here).  Only the *pattern*
+of the gallery matrices matters because the driver overwrites the values.
+
+Grid index = x + nx*(y + ny*z); rows are column-sorted.  Two back-ends with the
+same arithmetic: numpy (host; tests) and torch (device; bench at full size).
+"""
+import numpy as np
+
+SEED = 20140519
+
+STENCILS = {
+    # name: (ndim, offsets predicate)
+    "poisson5pt": 2, "poisson9pt": 2, "poisson7pt": 3, "poisson27pt": 3,
+}
+
+
+def stencil_offsets(name):
+    """Offsets (dx,dy,dz) in ascending linear-index order."""
+    offs = []
+    if name == "poisson5pt":
+        offs = [(0, -1, 0), (-1, 0, 0), (0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    elif name == "poisson9pt":
+        offs = [(dx, dy, 0) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    elif name == "poisson7pt":
+        offs = [(0, 0, -1), (0, -1, 0), (-1, 0, 0), (0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    elif name == "poisson27pt":
+        offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    else:
+        raise ValueError("unknown stencil %r" % (name,))
+    return offs
+
+
+def poisson_closed_form(name, nx, ny, nz=1):
+    """(m, nnzA) without building the matrix."""
+    m = nx * ny * nz
+    if name == "poisson5pt":
+        return m, 5 * m - 2 * nx - 2 * ny
+    if name == "poisson9pt":
+        return m, (3 * nx - 2) * (3 * ny - 2)
+    if name == "poisson7pt":
+        return m, 7 * m - 2 * (nx * ny + ny * nz + nx * nz)
+    if name == "poisson27pt":
+        return m, (3 * nx - 2) * (3 * ny - 2) * (3 * nz - 2)
+    raise ValueError(name)
+
+
+def poisson_csr(name, nx, ny, nz=1, row_begin=0, row_end=None):
+    """numpy CSR pattern (rowptr int32[m_local+1], col int32[nnz]) of rows
+    [row_begin,row_end) of the stencil matrix (values are filled separately)."""
+    offs = stencil_offsets(name)
+    if STENCILS[name] == 2:
+        nz = 1
+    m = nx * ny * nz
+    row_end = m if row_end is None else row_end
+    rows = np.arange(row_begin, row_end, dtype=np.int64)
+    x = rows % nx
+    y = (rows // nx) % ny
+    z = rows // (nx * ny)
+    nloc = rows.size
+    cols = np.empty((nloc, len(offs)), np.int32)
+    mask = np.empty((nloc, len(offs)), bool)
+    for t, (dx, dy, dz) in enumerate(offs):
+        ok = ((x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) &
+              (z + dz >= 0) & (z + dz < nz))
+        mask[:, t] = ok
+        cols[:, t] = (rows + dx + nx * (dy + ny * dz)).astype(np.int32)
+    rowptr = np.zeros(nloc + 1, np.int64)
+    np.cumsum(mask.sum(axis=1), out=rowptr[1:])
+    assert rowptr[-1] < 2 ** 31
+    return rowptr.astype(np.int32), np.ascontiguousarray(cols[mask])
+
+
+def fill_values(nnz, seed=SEED, offset=0):
+    """Integer-valued fp64 entries in 1..9: 1 + (lcg(seed, i) % 9), stateless per
+    index so that any shard can generate its own slice.  Exact in fp64 under any
+    summation order."""
+    i = np.arange(offset, offset + nnz, dtype=np.uint64)
+    x = (i + np.uint64(seed)) * np.uint64(6364136223846793005) + np.uint64(1442695040888963407)
+    return (1 + ((x >> np.uint64(33)) % np.uint64(9))).astype(np.float64)
+
+
+# ---------------------------------------------------------------- torch (device)
+def poisson_csr_torch(name, nx, ny, nz=1, row_begin=0, row_end=None, device="cuda", chunk=1 << 22):
+    """Same pattern as poisson_csr, generated on `device` in row chunks."""
+    import torch
+    offs = stencil_offsets(name)
+    if STENCILS[name] == 2:
+        nz = 1
+    m = nx * ny * nz
+    row_end = m if row_end is None else row_end
+    counts, colparts = [], []
+    for r0 in range(row_begin, row_end, chunk):
+        r1 = min(row_end, r0 + chunk)
+        rows = torch.arange(r0, r1, dtype=torch.int64, device=device)
+        x = rows % nx
+        y = (rows // nx) % ny
+        z = rows // (nx * ny)
+        cols = torch.empty((r1 - r0, len(offs)), dtype=torch.int32, device=device)
+        mask = torch.empty((r1 - r0, len(offs)), dtype=torch.bool, device=device)
+        for t, (dx, dy, dz) in enumerate(offs):
+            mask[:, t] = ((x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) &
+                          (z + dz >= 0) & (z + dz < nz))
+            cols[:, t] = (rows + (dx + nx * (dy + ny * dz))).to(torch.int32)
+        counts.append(mask.sum(dim=1))
+        colparts.append(cols[mask])
+        del rows, x, y, z, cols, mask
+    cnt = torch.cat(counts) if counts else torch.zeros(0, dtype=torch.int64, device=device)
+    rowptr = torch.zeros(row_end - row_begin + 1, dtype=torch.int64, device=device)
+    torch.cumsum(cnt, 0, out=rowptr[1:])
+    col = torch.cat(colparts) if colparts else torch.zeros(0, dtype=torch.int32, device=device)
+    return rowptr.to(torch.int32), col.contiguous()
+
+
+def fill_values_torch(nnz, seed=SEED, offset=0, device="cuda"):
+    """Bit-identical to fill_values (int64 wrap-around == uint64 arithmetic)."""
+    import torch
+    i = torch.arange(offset, offset + nnz, dtype=torch.int64, device=device)
+    a = 6364136223846793005
+    c = 1442695040888963407
+    x = (i + seed) * a + c                      # wraps mod 2^64
+    hi = (x >> 33) & 0x7FFFFFFF                 # logical shift of the uint64 pattern
+    return (1 + hi % 9).to(torch.float64)
+
+
+def powerlaw_csr(m, n, nnz_target, max_row, seed=SEED, alpha=1.8, hubs=4):
+    """Seeded power-law CSR pattern: stand-in for SuiteSparse webbase-1M when the
+    file is absent.  Row lengths ~ Zipf scaled to about
+    nnz_target, `hubs` rows of length ~max_row; columns skewed toward low indices
+    (popular columns => long B rows for A^2); rows sorted and duplicate-free."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.zipf(alpha, m), max_row).astype(np.float64)
+    lens = np.minimum(max_row, np.round(lens * (nnz_target / max(1.0, lens.sum())))).astype(np.int64)
+    if hubs and m:
+        lens[rng.choice(m, size=min(hubs, m), replace=False)] = min(n, max_row)
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    cols = np.minimum(n - 1, (rng.random(rows.size) ** 2 * n).astype(np.int64))
+    key = np.unique(rows * n + cols)                     # sorted, duplicate-free
+    r = key // n
+    rowptr = np.zeros(m + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=m), out=rowptr[1:])
+    return rowptr.astype(np.int32), (key - r * n).astype(np.int32)

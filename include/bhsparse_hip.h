@@ -1,0 +1,151 @@
+/*
+ * bhsparse_hip.h — C-ABI of libbhsparse_hip.so, the MI355X (gfx950) CSR SpGEMM
+ * backend that sits behind the bhSPARSE `bhsparse` class API.
+ *
+ * This is the drop-in boundary: the C++ facade (host/bhsparse.h, same public
+ * signatures as the reference's SpGEMM_cuda/bhsparse.h:17-33) and the Python
+ * mirror (facade.py) call ONLY these entry points.  Plain C types, opaque
+ * handle, caller-owned buffers, every function returns 0 (BHS_SUCCESS ==
+ * BHSPARSE_SUCCESS, SpGEMM_cuda/common.h:26) or a negative bhs_status /
+ * positive hipError_t; nothing throws or aborts.  One handle = one device =
+ * one in-flight multiply; calls on a handle must be externally serialised
+ * (same threading contract as the reference: single host thread, synchronous
+ * calls).
+ *
+ * Types: index_type = int32 (SpGEMM_cuda/common.h:30), value_type = double
+ * (common.h:31).  Intermediate-product counts are int64 (the reference's int
+ * overflows beyond 2^31 products, bhsparse.h:367,431).
+ */
+#ifndef BHSPARSE_HIP_H
+#define BHSPARSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define BHS_API __attribute__((visibility("default")))
+#else
+#define BHS_API
+#endif
+
+typedef struct bhs_handle bhs_handle;
+
+enum bhs_status {
+    BHS_SUCCESS            = 0,
+    BHS_ERR_INVALID_ARG    = -1,   /* NULL / negative size / bad state          */
+    BHS_ERR_NO_DEVICE      = -2,   /* no HIP device, or not a gfx950 code object */
+    BHS_ERR_ALLOC          = -3,   /* hipMalloc failed                           */
+    BHS_ERR_LAUNCH         = -4,   /* kernel launch / runtime error (reference returns -1 here,
+                                      bhsparse_cuda.h:251-253)                   */
+    BHS_ERR_NNZ_OVERFLOW   = -5,   /* nnz(C) does not fit index_type (int32)     */
+    BHS_ERR_NOT_READY      = -6,   /* get_C before spgemm, spgemm before set_data */
+    BHS_ERR_INTERNAL       = -7    /* accumulator overflow that the retry logic could not resolve */
+};
+
+/* ---- lifecycle -----------------------------------------------------------
+ * replaces bhsparse::initPlatform -> bhsparse_cuda::initPlatform
+ *   (SpGEMM_cuda/bhsparse.h:91-125, bhsparse_cuda.h:92-119: picks device 0,
+ *   prints the device banner)   and freePlatform (bhsparse.h:127-149).
+ * device_count must be 1 (one process per GPU; multi-GPU runs shard rows of A
+ * across processes, see bhs_set_data on a row block).  device_ids may be NULL
+ * (=> device 0).  Prints the reference-style device banner when verbose.      */
+BHS_API int bhs_create(bhs_handle **out, int device_count, const int *device_ids);
+BHS_API int bhs_destroy(bhs_handle *h);
+
+/* verbosity: 0 silent, 1 reference-style stage prints (default 0 for the C-ABI;
+ * the C++ facade sets 1 to reproduce bhsparse.h:307-336 stdout).              */
+BHS_API int bhs_set_verbose(bhs_handle *h, int level);
+
+/* ---- data ----------------------------------------------------------------
+ * replaces bhsparse::initData -> bhsparse_cuda::initData
+ *   (bhsparse.h:180-258, bhsparse_cuda.h:151-203: cudaMalloc + H2D of A and B).
+ * Host pointers are read during the call only (copied to HBM); the reference
+ * keeps borrowing them, which stays legal.  A is m x k, B is k x n, 0-based
+ * CSR.  Rows of B should be column-sorted (reference precondition, SURVEY.md
+ * §8b); unsorted B is detected and still multiplied correctly.               */
+BHS_API int bhs_set_data(bhs_handle *h, int m, int k, int n,
+                         int nnzA, const double *csrValA, const int *csrRowPtrA, const int *csrColIndA,
+                         int nnzB, const double *csrValB, const int *csrRowPtrB, const int *csrColIndB);
+
+/* Same, but the six arrays are DEVICE pointers on the handle's device (borrowed
+ * until bhs_free_data; never written).  This is the entry the benchmark uses so
+ * that inputs are HBM-resident when the timed region starts, and the entry a
+ * multi-GPU host uses to hand each rank its row block of A with B replicated. */
+BHS_API int bhs_set_data_device(bhs_handle *h, int m, int k, int n,
+                                int nnzA, const double *d_valA, const int *d_rowPtrA, const int *d_colIndA,
+                                int nnzB, const double *d_valB, const int *d_rowPtrB, const int *d_colIndB);
+
+/* replaces bhsparse::free_mem -> bhsparse_cuda::free_mem (bhsparse.h:151-178,
+ * bhsparse_cuda.h:121-149).  Drops A, B, C; keeps the workspace pool.         */
+BHS_API int bhs_free_data(bhs_handle *h);
+
+/* ---- compute -------------------------------------------------------------
+ * replaces bhsparse::warmup (bhsparse.h:341-363, bhsparse_cuda.h:239-256:
+ * re-runs the nnzCt kernel).  Here: runs the upper-bound kernel and pre-sizes
+ * the workspace pool so the timed spgemm() does no hipMalloc.                 */
+BHS_API int bhs_warmup(bhs_handle *h);
+
+/* replaces bhsparse::spgemm / spgemm_cuda (bhsparse.h:260-339): the whole timed
+ * region — stage 1 upper bound + row binning, stage 2 symbolic (exact nnz per
+ * row), stage 3 scan + allocation of C, stage 4 numeric (C written once, in
+ * place, rows column-sorted, duplicates summed, explicit zeros kept).
+ *   rowPtrC_out : caller buffer of m+1 ints, filled with the exclusive-scan row
+ *                 pointer (as bhsparse_cuda.h:2787-2799 does); may be NULL.
+ *   nnzCt_out   : number of intermediate products (GFLOPs numerator,
+ *                 bhsparse.h:287-289); may be NULL.
+ *   nnzC_out    : nnz(C); may be NULL.
+ *   stage_ms_out: 4 doubles, device time of the 4 stages in ms; may be NULL.
+ * Synchronous: returns after C is complete in HBM.                            */
+BHS_API int bhs_spgemm(bhs_handle *h, int *rowPtrC_out, int64_t *nnzCt_out, int *nnzC_out,
+                       double stage_ms_out[4]);
+
+/* replaces bhsparse::get_nnzC (bhsparse.h: get_nnzC -> bhsparse_cuda::get_nnzC). */
+BHS_API int bhs_get_nnzC(bhs_handle *h, int *nnzC_out);
+
+/* replaces bhsparse::get_C -> bhsparse_cuda::get_C (bhsparse_cuda.h:3006-3020:
+ * D2H of colIndC / valC; the reference also re-copies rowPtrC there — pass
+ * rowPtrC_out to bhs_spgemm or use bhs_get_rowptrC).  Caller buffers hold
+ * nnzC entries.                                                               */
+BHS_API int bhs_get_C(bhs_handle *h, int *csrColIndC, double *csrValC);
+BHS_API int bhs_get_rowptrC(bhs_handle *h, int *csrRowPtrC /* m+1 */);
+
+/* Device-resident result for callers that keep C on the GPU (multi-GPU
+ * all-gatherv of row blocks, chained products).  Pointers stay valid until the
+ * next bhs_spgemm / bhs_free_data / bhs_destroy on this handle.               */
+BHS_API int bhs_get_C_device(bhs_handle *h, const int **d_rowPtrC, const int **d_colIndC,
+                             const double **d_valC);
+
+/* ---- measurement ----------------------------------------------------------
+ * Per-kernel-family device times of the LAST bhs_spgemm, measured with
+ * hipEvents on the stream the kernels were launched on (what bench.py reports
+ * as roofline.achieved; replaces the reference's never-enabled `_profiling`
+ * prints, bhsparse_cuda.h:728-733).  Returns the number of records; fills up to
+ * `cap` of them.  `name` points to a static string.                           */
+typedef struct bhs_kernel_stat {
+    const char *name;      /* e.g. "numeric_wave<256>"                        */
+    int         launches;  /* launches of this family in the last spgemm      */
+    double      ms;        /* summed device time of those launches            */
+    int64_t     rows;      /* rows of C processed by them                     */
+    int64_t     products;  /* intermediate products processed by them         */
+    int64_t     nnz_out;   /* entries of C produced (numeric) / counted (symbolic) */
+    int64_t     nnzA_rows; /* nnz of the A rows processed (for algorithmic bytes) */
+} bhs_kernel_stat;
+BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
+
+/* Tunables (mostly for tests that force a particular accumulator path):
+ *   "force_path"    0 auto | 1 wave-per-row hash | 2 workgroup-per-row hash
+ *   "max_table_log2" cap on the LDS table size => forces the column-window path
+ *   "verbose"       same as bhs_set_verbose
+ * Returns BHS_ERR_INVALID_ARG for unknown keys.                               */
+BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
+
+BHS_API const char *bhs_strerror(int status);
+BHS_API const char *bhs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHSPARSE_HIP_H */

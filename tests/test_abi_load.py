@@ -1,0 +1,60 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/bhsparse_hip.h declares.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from benchmark_spgemm_using_csr_amd import _lib
+
+
+def _declared_symbols():
+    txt = open(_lib.HEADER).read()
+    return sorted(set(re.findall(r"BHS_API\s+[\w\s\*]+?\b(bhs_\w+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    decl = _declared_symbols()
+    assert len(decl) >= 14
+    assert sorted(_lib.SYMBOLS) == decl
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    raw = C.CDLL(_lib.SO_PATH)
+    for name in _declared_symbols():
+        assert getattr(raw, name) is not None
+
+
+def test_code_object_is_gfx950():
+    so = _lib.SO_PATH
+    assert os.path.exists(so)
+    blob = open(so, "rb").read()
+    assert b"gfx950" in blob
+    assert b"k_row_hash" in blob      # the accumulator kernels are in the fat binary
+
+
+def test_strerror_and_version(hiplib):
+    assert hiplib.bhs_strerror(0) == b"success"
+    assert b"int32" in hiplib.bhs_strerror(_lib.BHS_ERR_NNZ_OVERFLOW)
+    assert b"gfx950" in hiplib.bhs_version()
+
+
+def test_null_handle_is_rejected(hiplib):
+    assert hiplib.bhs_spgemm(None, None, None, None, None) == _lib.BHS_ERR_INVALID_ARG
+    assert hiplib.bhs_destroy(None) == _lib.BHS_ERR_INVALID_ARG
+    assert hiplib.bhs_create(None, 1, None) == _lib.BHS_ERR_INVALID_ARG
+
+
+def test_python_facade_has_reference_api():
+    # SpGEMM_cuda/bhsparse.h:20-33
+    from benchmark_spgemm_using_csr_amd import bhsparse
+    for meth in ("initPlatform", "initData", "spgemm", "warmup", "get_nnzC", "get_C", "freePlatform", "free_mem"):
+        assert callable(getattr(bhsparse, meth))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.load()

@@ -1,0 +1,132 @@
+"""CPU tests (-m "not gpu"): pin the oracle against the golden vectors.
+
+The reference holds no expected outputs; the pins are the
+hand-derived answers for its two fixed inputs, scipy-generated fixtures
+(tests/golden/make_golden.py) and the Poisson closed forms.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from benchmark_spgemm_using_csr_amd import gallery
+
+
+def _run(oracle, g, nthreads=0):
+    return oracle.spgemm(int(g["m"]), int(g["k"]), int(g["n"]), g["Ap"], g["Aj"], g["Ax"],
+                         g["Bp"], g["Bj"], g["Bx"], nthreads=nthreads)
+
+
+def test_small_test_known_answer(oracle):
+    # inputs: SpGEMM_cuda/main.cu:153-205; expected: SURVEY.md §4
+    g = load_golden("small_test.npz")
+    Cp, Cj, Cx = _run(oracle, g)
+    assert Cp.tolist() == [0, 1, 4, 4, 6]
+    assert Cj.tolist() == [0, 0, 1, 3, 1, 3]
+    assert Cx.tolist() == [10, 120, 190, 60, 120, 180]
+    assert oracle.nnzCt(g["Ap"], g["Aj"], g["Bp"]) == 7
+
+
+def test_cage4_known_answer(oracle):
+    g = load_golden("cage4_sq.npz")
+    Ap, Aj, Ax = g["Ap"], g["Aj"], g["Ax"]
+    Cp, Cj, Cx = oracle.spgemm(9, 9, 9, Ap, Aj, Ax, Ap, Aj, Ax)
+    assert oracle.nnzCt(Ap, Aj, Ap) == 269 and Cp[-1] == 81
+    assert Cp.tolist() == list(range(0, 82, 9))
+    assert np.array_equal(Cj, g["Cj"]) and np.allclose(Cx, g["Cx"], rtol=1e-13, atol=0)
+    ones = np.ones_like(Ax)
+    _, _, C1 = oracle.spgemm(9, 9, 9, Ap, Aj, ones, Ap, Aj, ones)
+    assert C1[:9].tolist() == [5, 3, 2, 3, 3, 3, 3, 3, 2] and C1.sum() == 269
+    # per-row upper bounds of the survey: {27,27,27,27,33,33,33,33,29}
+    _, ub = oracle.nnzCt(Ap, Aj, Ap, want_ub=True)
+    assert ub.tolist() == [27, 27, 27, 27, 33, 33, 33, 33, 29]
+
+
+@pytest.mark.parametrize("name", ["p5_16.npz", "p27_6.npz", "p9_12.npz", "p7_7.npz", "rect_rand.npz"])
+@pytest.mark.parametrize("nthreads", [1, 4])
+def test_scipy_fixtures(oracle, name, nthreads):
+    g = load_golden(name)
+    Cp, Cj, Cx = _run(oracle, g, nthreads)
+    assert np.array_equal(Cp, g["Cp"]) and np.array_equal(Cj, g["Cj"]) and np.array_equal(Cx, g["Cx"])
+    assert oracle.nnzCt(g["Ap"], g["Aj"], g["Bp"]) == int(g["nnzCt"])
+
+
+@pytest.mark.parametrize("tag", ["p5_256", "p27_51"])
+def test_reference_default_sizes_checksums(oracle, tag):
+    # the reference's default benchmark sizes (main.cu:32-51), digests from scipy
+    ref = json.load(open(os.path.join(GOLDEN, "checksums.json")))[tag]
+    rp, col = gallery.poisson_csr(ref["stencil"], *ref["dims"])
+    val = gallery.fill_values(len(col))
+    m = len(rp) - 1
+    assert m == ref["m"] and len(col) == ref["nnzA"]
+    Cp, Cj, Cx = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    d = oracle.digest(Cp, Cj, Cx)
+    assert d[0] == ref["nnzC"] and d[1] == ref["sum_rowptr"] and d[2] == ref["wsum_col"]
+    assert np.array([d[3]], np.uint64).view(np.float64)[0] == ref["sum_val"]
+    assert oracle.nnzCt(rp, col, rp) == ref["nnzCt"]
+
+
+def test_poisson27_closed_forms(oracle):
+    # nnzA=(3N-2)^3, nnzCt=(9N-10)^3, nnzC=(5N-6)^3
+    for N in (4, 9, 16):
+        rp, col = gallery.poisson_csr("poisson27pt", N, N, N)
+        assert len(col) == (3 * N - 2) ** 3
+        assert oracle.nnzCt(rp, col, rp) == (9 * N - 10) ** 3
+        val = np.ones(len(col))
+        Cp, _, _ = oracle.spgemm(N ** 3, N ** 3, N ** 3, rp, col, val, rp, col, val)
+        assert Cp[-1] == (5 * N - 6) ** 3
+
+
+def test_structural_zero_is_kept(oracle):
+    # [[1,-1],[0,0]] * [[1,0],[1,0]]: the products cancel; the reference keeps the entry
+    Ap = np.array([0, 2, 2], np.int32); Aj = np.array([0, 1], np.int32); Ax = np.array([1.0, -1.0])
+    Bp = np.array([0, 1, 2], np.int32); Bj = np.array([0, 0], np.int32); Bx = np.array([1.0, 1.0])
+    Cp, Cj, Cx = oracle.spgemm(2, 2, 2, Ap, Aj, Ax, Bp, Bj, Bx)
+    assert Cp.tolist() == [0, 1, 1] and Cj.tolist() == [0] and Cx.tolist() == [0.0]
+
+
+def test_csr_sort_indices(oracle):
+    rng = np.random.default_rng(3)
+    rp = np.array([0, 5, 5, 45, 46], np.int32)
+    col = np.concatenate([rng.permutation(50)[:5], rng.permutation(100)[:40], [7]]).astype(np.int32)
+    val = col.astype(np.float64) * 2 + 1
+    oracle.csr_sort_indices(rp, col, val)
+    for i in range(4):
+        seg = col[rp[i]:rp[i + 1]]
+        assert np.all(np.diff(seg) > 0)
+    assert np.array_equal(val, col * 2.0 + 1)
+
+
+def test_compare_reports_like_compData(oracle):
+    g = load_golden("p5_16.npz")
+    ref = (g["Cp"], g["Cj"], g["Cx"])
+    good = (g["Cp"].astype(np.int32), g["Cj"].copy(), g["Cx"].copy())
+    assert oracle.compare(ref, good)["ok"]
+    bad = (good[0], good[1], good[2].copy()); bad[2][5] *= 1 + 1e-4
+    r = oracle.compare(ref, bad)
+    assert not r["ok"] and r["stage"] == 2 and r["val_err"] == 1
+    bad = (good[0], good[1].copy(), good[2]); bad[1][3] += 1
+    assert oracle.compare(ref, bad)["col_err"] == 1
+    badp = good[0].copy(); badp[4] += 1
+    assert oracle.compare(ref, (badp, good[1], good[2]))["stage"] == 1
+
+
+def test_value_fill_is_deterministic_and_shardable():
+    a = gallery.fill_values(1000)
+    assert a.min() >= 1 and a.max() <= 9 and np.all(a == np.round(a))
+    b = np.concatenate([gallery.fill_values(400), gallery.fill_values(600, offset=400)])
+    assert np.array_equal(a, b)
+    assert a[:5].tolist() == [3.0, 9.0, 4.0, 9.0, 6.0]
+
+
+def test_poisson_row_blocks_concatenate():
+    rp, col = gallery.poisson_csr("poisson27pt", 5, 6, 7)
+    m = 5 * 6 * 7
+    parts = [gallery.poisson_csr("poisson27pt", 5, 6, 7, r0, r1) for r0, r1 in ((0, 70), (70, 150), (150, m))]
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), col)
+    assert sum(len(p[0]) - 1 for p in parts) == m
+    for name, dims in (("poisson5pt", (7, 9, 1)), ("poisson9pt", (8, 5, 1)), ("poisson7pt", (4, 5, 6))):
+        rp, col = gallery.poisson_csr(name, *dims)
+        assert (len(rp) - 1, len(col)) == gallery.poisson_closed_form(name, *dims)
