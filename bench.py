@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the SpGEMM hot path (C = A^2, fp64, CSR) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one bhsparse::spgemm() (upper bound + binning -> symbolic -> scan ->
+numeric) over the synthetic matrix, inputs already resident in HBM; at N > 1 each
+rank multiplies its row block of A by the replicated B and the step ends with the
+RCCL all-gatherv that assembles the full CSR of C on every rank.
+
+Workloads (BASELINE.json `configs`; values = gallery.fill_values, seed 20140519):
+  p27_weak (default) poisson27pt, 128^3 rows per GPU: 128^3 at N=1 (configs[2]),
+                     128x128x256 at N=2, 128x256x256 at N=4, 256^3 at N=8 (configs[4])
+  p27_128 / p27_160 / p27_256 / p5_1024   fixed-size variants (strong scaling at N > 1)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload_dims(name, world):
+    if name == "p27_weak":
+        dims = {1: (128, 128, 128), 2: (128, 128, 256), 4: (128, 256, 256), 8: (256, 256, 256)}.get(world)
+        if dims is None:
+            dims = (128, 128, 128 * world)
+        return "poisson27pt", dims, "weak"
+    table = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)),
+             "p27_256": ("poisson27pt", (256, 256, 256)), "p27_51": ("poisson27pt", (51, 51, 51)),
+             "p5_1024": ("poisson5pt", (1024, 1024, 1)), "p5_256": ("poisson5pt", (256, 256, 1))}
+    st, dims = table[name]
+    return st, dims, "strong"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="p27_weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (compute-only)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from benchmark_spgemm_using_csr_amd import gallery, facade, dist as bdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    stencil, dims, scaling = workload_dims(args.workload, world)
+    nx, ny, nz = dims
+    m = nx * ny * nz
+    r0, r1 = bdist.row_block(m, rank, world)
+
+    # ---- synthetic inputs, generated on the device (B = A, separate buffers: main.cpp:225-232)
+    Bp, Bj = gallery.poisson_csr_torch(stencil, nx, ny, nz, device=dev)
+    nnzB = int(Bj.numel())
+    Bx = gallery.fill_values_torch(nnzB, device=dev)
+    if world == 1:
+        Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+    else:
+        # rank-local row block of A: same pattern/values as rows [r0,r1) of B
+        lo, hi = int(Bp[r0].item()), int(Bp[r1].item())
+        Ap = (Bp[r0:r1 + 1] - lo).contiguous()
+        Aj = Bj[lo:hi].clone()
+        Ax = Bx[lo:hi].clone()
+    nnzA = int(Aj.numel())
+    torch.cuda.synchronize()
+
+    plats = [False] * facade.NUM_PLATFORMS
+    plats[facade.BHSPARSE_HIP] = True
+    bh = facade.bhsparse()
+    err = bh.initPlatform(plats, device=local_rank)
+    assert err == 0, facade._lib.strerror(err)
+    err = bh.initData_device(r1 - r0, m, m, nnzA, Ax, Ap, Aj, nnzB, Bx, Bp, Bj)
+    assert err == 0, facade._lib.strerror(err)
+
+    gather_out = [None]
+
+    def step():
+        e = bh.spgemm()
+        if e != 0:
+            raise RuntimeError("spgemm: " + facade._lib.strerror(e))
+        if world > 1 and not args.no_gather:
+            pr, pc, pv = bh.get_C_device()
+            nnz = bh.nnzC
+            lr = bdist.device_view(pr, r1 - r0 + 1, torch.int32, dev)
+            lc = bdist.device_view(pc, nnz, torch.int32, dev)
+            lv = bdist.device_view(pv, nnz, torch.float64, dev)
+            rp, cc, vv, _ = bdist.allgatherv_csr(m, lr, lc, lv, out=gather_out[0])
+            gather_out[0] = (rp, cc, vv) if gather_out[0] is None or gather_out[0][1].numel() < cc.numel() else gather_out[0]
+            return rp, cc, vv
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kstats = {}
+    stage = np.zeros(4)
+    t_compute = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tc = time.perf_counter()
+        full = step()
+        for s in bh.kernel_stats():
+            d = kstats.setdefault(s["name"], {"ms": 0.0, "launches": 0, "rows": 0, "products": 0, "nnz_out": 0,
+                                              "nnzA_rows": 0, "steps": 0})
+            d["ms"] += s["ms"]; d["launches"] += s["launches"]; d["steps"] += 1
+            for kk in ("rows", "products", "nnz_out", "nnzA_rows"):
+                d[kk] = s[kk]
+        stage += np.array(bh.stage_ms)
+        t_compute += bh.time_ms
+        del tc
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cnt = torch.tensor([bh.nnzCt, bh.nnzC], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        nnzCt_total, nnzC_total = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        nnzCt_total, nnzC_total = bh.nnzCt, bh.nnzC
+    ms_per_step = elapsed / args.steps * 1e3
+    gflops = 2.0 * nnzCt_total / (ms_per_step * 1e6)
+
+    # ---- correctness of the assembled result at N > 1 (cheap digest check on rank 0)
+    if full is not None and rank == 0:
+        rp, cc, vv = full
+        assert int(rp[-1].item()) == nnzC_total and int(rp[0].item()) == 0
+        assert bool((rp[1:] >= rp[:-1]).all())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (device time from hipEvents on the library's stream)
+    kname = max(kstats, key=lambda k2: kstats[k2]["ms"]) if kstats else None
+    roof = None
+    if kname:
+        ks = kstats[kname]
+        avg_ms = ks["ms"] / max(1, ks["launches"])
+        rows_k, nnzA_k, out_k = ks["rows"], ks["nnzA_rows"], ks["nnz_out"]
+        if kname.startswith("numeric"):
+            # A rows (col+val) + their rowPtr pairs, B once (col+val+rowPtr), C rows written once + rowPtrC read
+            alg = 12 * nnzA_k + 8 * rows_k + 12 * nnzB + 4 * (m + 1) + 12 * out_k + 4 * rows_k
+        elif kname.startswith("symbolic"):
+            alg = 4 * nnzA_k + 8 * rows_k + 4 * nnzB + 4 * (m + 1) + 4 * rows_k
+        else:
+            alg = 4 * nnzA + 8 * (r1 - r0) + 4 * (m + 1)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.workload if world == 1 else "", {}).get(kname)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "alg_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 5),
+                "launches_timed": ks["launches"]}
+    # whole-pipeline compulsory-bytes model: read A, read B, write C once
+    bytes_alg_total = (4 * (r1 - r0 + 1) + 12 * nnzA) + (4 * (m + 1) + 12 * nnzB) + (4 * (r1 - r0 + 1) + 12 * bh.nnzC)
+    pipeline_frac = bytes_alg_total / (np.sum(stage) / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # ---- CPU baseline: the oracle (kind "port") on a bounded row-block sample, all host cores
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        hBp, hBj, hBx = Bp.cpu().numpy(), Bj.cpu().numpy(), Bx.cpu().numpy()
+        cores = oracle.max_threads()
+
+        def run_block(nrows):
+            bp = hBp[:nrows + 1]
+            nn = int(bp[-1])
+            tA = time.perf_counter()
+            ref = oracle.spgemm(nrows, m, m, bp, hBj[:nn], hBx[:nn], hBp, hBj, hBx)
+            dt = time.perf_counter() - tA
+            return ref, dt, oracle.nnzCt(bp, hBj[:nn], hBp)
+        probe = min(m, 1 << 15)
+        _, dtp, ctp = run_block(probe)           # calibration (also pages the oracle in)
+        rate = ctp / max(dtp, 1e-6)
+        want = int(min(m, max(probe, args.cpu_seconds * rate / max(1.0, ctp / probe))))
+        ref, dts, cts = run_block(want)
+        # parity of the GPU result on the same rows, in the same run
+        got_rp = bh.get_rowptrC()[:want + 1]
+        nn = int(got_rp[-1])
+        pr, pc, pv = bh.get_C_device()
+        gc = bdist.device_view(pc, bh.nnzC, torch.int32, dev)[:nn].cpu().numpy()
+        gv = bdist.device_view(pv, bh.nnzC, torch.float64, dev)[:nn].cpu().numpy()
+        chk = oracle.compare(ref, (got_rp, gc, gv), rel_tol=1e-6)
+        cpu = {"value": round(2.0 * cts / dts / 1e9, 4), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+               "sample": "oracle (Gustavson+sort, OpenMP) on rows [0,%d) of A x full B: %d products in %.2f s"
+                         % (want, cts, dts),
+               "gpu_matches_oracle_on_sample": bool(chk["ok"])}
+        if not chk["ok"]:
+            cpu["mismatch"] = chk
+
+    out = {
+        "metric": "spgemm_gflops (2*nnz_intermediate/t, C=A^2, fp64 CSR)",
+        "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s %s C=A^2 (%s)" % (stencil, "x".join(map(str, dims)), args.workload),
+                   "m": m, "nnzA_total": nnzB, "nnzCt": nnzCt_total, "nnzC": nnzC_total,
+                   "parallelism": "rowblock%d+allgatherv" % world if world > 1 else "single",
+                   "values": "1+lcg%9 seed 20140519", "gather_in_step": bool(world > 1 and not args.no_gather)},
+        "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
+        "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
+        "stage_ms": [round(float(x) / args.steps, 4) for x in stage],
+        "host_ms_per_step_spgemm": round(t_compute / args.steps, 4),
+        "pipeline_compulsory_bytes": int(bytes_alg_total),
+        "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
+        "kernels_ms_per_step": {k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items())},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

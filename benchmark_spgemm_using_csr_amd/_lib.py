@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libbhsparse_hip.so")
+# BHSPARSE_HIP_LIB: alternate build of the same library (measurement variants); never a fallback
+SO_PATH = os.environ.get("BHSPARSE_HIP_LIB") or os.path.join(CSRC, "libbhsparse_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bhsparse_hip.h")
 
 BHS_SUCCESS = 0

@@ -15,7 +15,15 @@
 //   k_scan_*           <- create_C's host exclusive scan      :2783-2811
 #pragma once
 #include <hip/hip_runtime.h>
+#include "bhs_wave.hip.h"
+#ifndef BHS_ABL
+#define BHS_ABL 0
+#endif
+#ifndef BHS_ABL_SYM
+#define BHS_ABL_SYM 0
+#endif
 #include <stdint.h>
+#include <type_traits>
 
 namespace bhs {
 
@@ -40,12 +48,12 @@ __device__ __forceinline__ unsigned hash_col(int col, int log2ts)
     return ((unsigned)col * 2654435761u) >> (32 - log2ts);
 }
 
-__device__ __forceinline__ int wave_sum(int v)
+__device__ __forceinline__ int mbcnt64(unsigned long long m)   // number of set bits of m below this lane
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
+
+__device__ __forceinline__ int wave_sum(int v) { return wave_sum_dpp(v); }
 
 // ---------------------------------------------------------------------------
 // Stage 1a: per-row upper bound ub[i] = sum_{j in A(i,:)} len(B(j,:)), with G
@@ -96,16 +104,22 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
 }
 
 // ---------------------------------------------------------------------------
-// Stage 1b / 3b: scatter row ids into per-bin queues.  key[] is ub (symbolic
-// bins) or the per-row nnz (numeric bins; given as rowPtrC so v = Cp[i+1]-Cp[i]).
-// One global atomic per (block, bin); rows of a block stay together so queue
-// order stays close to row order (L2 locality of the B rows they touch).
+// Stage 1b / 3b: scatter 16-byte row descriptors {row, a0, a1, outBase} into
+// per-bin queues (replaces the reference's 6-int host-built queue tuples,
+// bhsparse.h:365-481).  key[] is ub (symbolic bins) or rowPtrC (numeric bins,
+// v = Cp[i+1]-Cp[i], outBase = Cp[i]).  Counting is wave-aggregated: one LDS
+// atomic per (wave, distinct bin), one global atomic per (block, bin); rows of
+// a block stay together so queue order stays close to row order (L2 locality
+// of the B rows they touch).
 // ---------------------------------------------------------------------------
+constexpr int kFillRounds = 8;                   // rows per thread per reservation
+constexpr int kFillTile = 256 * kFillRounds;     // rows per block per global reservation
+
 template <bool FROM_ROWPTR>
 __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restrict__ key,
                                                      const int* __restrict__ Ap, const int* __restrict__ ub,
                                                      const int* __restrict__ binStart,
-                                                     int* __restrict__ binCursor, int* __restrict__ queue,
+                                                     int* __restrict__ binCursor, int4* __restrict__ queue,
                                                      BinSpec spec, unsigned long long* __restrict__ binSums)
 {
     __shared__ int hist[kMaxBins];
@@ -113,25 +127,59 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
     __shared__ unsigned long long sums[kMaxBins * 3];   // per bin: products, nnz(C rows), nnz(A rows)
     const int tid = threadIdx.x;
     if (tid < kMaxBins * 3) sums[tid] = 0;
-    for (long long r0 = (long long)blockIdx.x * 256; r0 < m; r0 += (long long)gridDim.x * 256) {
+    for (long long r0 = (long long)blockIdx.x * kFillTile; r0 < m; r0 += (long long)gridDim.x * kFillTile) {
         if (tid < kMaxBins) hist[tid] = 0;
         __syncthreads();
-        const int row = (int)r0 + tid;
-        int b = -1, pos = 0;
-        if (row < m) {
-            const int v = FROM_ROWPTR ? key[row + 1] - key[row] : key[row];
-            b = bin_of(spec, v);
-            if (b > 0) {
-                pos = atomicAdd(&hist[b], 1);
-                atomicAdd(&sums[b * 3 + 0], (unsigned long long)(unsigned)ub[row]);
-                if (FROM_ROWPTR) atomicAdd(&sums[b * 3 + 1], (unsigned long long)v);
-                atomicAdd(&sums[b * 3 + 2], (unsigned long long)(Ap[row + 1] - Ap[row]));
-            } else b = -1;                                       // bin 0 (empty rows) has no queue
+        int bb[kFillRounds], pp[kFillRounds];
+        int4 dd[kFillRounds];
+#pragma unroll
+        for (int r = 0; r < kFillRounds; ++r) {
+            const long long row = r0 + (long long)r * 256 + tid;
+            int b = 0, pos = 0, a0 = 0, a1 = 0, outBase = 0, v = 0, ubv = 0;
+            if (row < m) {
+                if (FROM_ROWPTR) { outBase = key[row]; v = key[row + 1] - outBase; } else v = key[row];
+                b = bin_of(spec, v);
+                a0 = Ap[row];
+                a1 = Ap[row + 1];
+                ubv = ub[row];
+            }
+            // all 64 lanes take part (rows past m carry b == 0 and never match a leader's bin)
+            unsigned long long todo = __ballot(b > 0);
+            while (todo) {                                   // one pass per distinct bin in this wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const int lbin = __shfl(b, leader, 64);
+                const bool mine = (b == lbin);
+                const unsigned long long peers = __ballot(mine);
+                unsigned long long s0 = mine ? (unsigned long long)(unsigned)ubv : 0ull;
+                unsigned long long s1 = (mine && FROM_ROWPTR) ? (unsigned long long)v : 0ull;
+                unsigned long long s2 = mine ? (unsigned long long)(a1 - a0) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    s0 += __shfl_xor(s0, o, 64);
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                int wbase = 0;
+                if ((tid & 63) == leader) {
+                    wbase = atomicAdd(&hist[lbin], __popcll(peers));
+                    atomicAdd(&sums[lbin * 3 + 0], s0);
+                    if (FROM_ROWPTR) atomicAdd(&sums[lbin * 3 + 1], s1);
+                    atomicAdd(&sums[lbin * 3 + 2], s2);
+                }
+                wbase = __shfl(wbase, leader, 64);
+                if (mine) pos = wbase + mbcnt64(peers);
+                todo &= ~peers;
+            }
+            bb[r] = b;
+            pp[r] = pos;
+            dd[r] = make_int4((int)row, a0, a1, outBase);
         }
         __syncthreads();
         if (tid < spec.nbins && hist[tid]) base[tid] = binStart[tid] + atomicAdd(&binCursor[tid], hist[tid]);
         __syncthreads();
-        if (b > 0) queue[base[b] + pos] = row;
+#pragma unroll
+        for (int r = 0; r < kFillRounds; ++r)
+            if (bb[r] > 0) queue[base[bb[r]] + pp[r]] = dd[r];   // bin 0 (empty rows): no queue
         __syncthreads();
     }
     if (tid < kMaxBins * 3 && sums[tid]) atomicAdd(&binSums[tid], sums[tid]);
@@ -280,7 +328,7 @@ struct RowHashSmem {
 
 template <int TS, int LOG2TS, int BLOCK, bool NUM, bool WIN>
 __global__ __launch_bounds__(BLOCK) void k_row_hash(
-    const int* __restrict__ queue, int qn, int ncolsB, int logL, int bSorted,
+    const int4* __restrict__ queue, int qn, int ncolsB, int logL, int bSorted,
     const int* __restrict__ Ap, const int* __restrict__ Aj, const double* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
     const int* __restrict__ ubArr,          // symbolic + WIN: per-row upper bound (first window guess)
@@ -298,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_hash(
     const int sub = tid >> logL, t = tid & (L - 1), nsub = BLOCK >> logL;
 
     for (int q = blockIdx.x; q < qn; q += gridDim.x) {
-        const int row = queue[q];
+        const int row = queue[q].x;
         const int a0 = Ap[row], a1 = Ap[row + 1];
         long long outBase = 0;
         if (NUM) outBase = CpOrCnt[row];
@@ -437,6 +485,362 @@ __global__ __launch_bounds__(BLOCK) void k_row_hash(
             if (uniq < CAP / 4 && width < ncolsB) width <<= 1;   // sparse window: grow the next one
         }
         if (!NUM && tid == 0) CpOrCnt[row] = rowTotal;
+    }
+}
+
+// ===========================================================================
+// Wavefront-per-row accumulator (the workhorse; one 64-lane workgroup per row
+// in flight, persistent over an XCD-aware slice of the row queue).
+//
+// Differences from k_row_hash<BLOCK=64> that matter on CDNA4:
+//  * no dependent load chain per A entry: the whole A row (<= 64 entries per
+//    pass) is fetched by one coalesced load, the B row extents by one gather,
+//    and a wave scan turns the B row lengths into a flat product index space;
+//  * flat product mapping: lane l of batch u owns product p = w0 + 64u + l; its
+//    A entry is found with ONE v_mbcnt on a 64-bit mask of "last product of an
+//    entry" marks kept in LDS (ds_or_b32 by the entry lanes), so all 64 lanes
+//    are busy whatever the B row lengths are (27-entry rows: 11.4 passes
+//    instead of 14);
+//  * U = 4 batches of colIndB/valB loads are issued back to back before the
+//    first LDS insert (256 independent loads in flight per wave);
+//  * numeric: occupied slots are compacted to packed (col<<32 | slot) words and
+//    sorted in REGISTERS by a wave-wide bitonic network (cross-lane exchange by
+//    DPP/ds_bpermute, no LDS round trip per stage), then streamed out;
+//  * XCD-aware persistent schedule: workgroup b runs on XCD b%8 (observed
+//    dispatch order), so each XCD walks one contiguous eighth of the queue and
+//    neighbouring rows share B rows through that XCD's private L2.
+// ===========================================================================
+constexpr int kMaxB = 12;    // product batches per window: 12 x 64 = 768 products with their loads in flight
+
+// PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
+// otherwise (col << 32 | slot) in 64 bits.
+template <int TS, bool NUM, bool PACK32>
+struct WaveSmem {
+    using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
+    int keys[TS];
+    double vals[NUM ? TS : 1];
+    packed_t packed[NUM ? TS : 2];
+    double sAv[NUM ? 64 : 1];
+    int sBase[64];
+    unsigned marks[2 * kMaxB];
+};
+
+template <typename T>
+__device__ __forceinline__ T lane_xor_any(T x, int lj, int lane)
+{
+    if constexpr (sizeof(T) == 8) {
+        switch (lj) {
+            case 1: return lane_xor64<1>(x, lane);
+            case 2: return lane_xor64<2>(x, lane);
+            case 4: return lane_xor64<4>(x, lane);
+            case 8: return lane_xor64<8>(x, lane);
+            case 16: return lane_xor64<16>(x, lane);
+            default: return lane_xor64<32>(x, lane);
+        }
+    } else {
+        switch (lj) {
+            case 1: return lane_xor<1>(x, lane);
+            case 2: return lane_xor<2>(x, lane);
+            case 4: return lane_xor<4>(x, lane);
+            case 8: return lane_xor<8>(x, lane);
+            case 16: return lane_xor<16>(x, lane);
+            default: return lane_xor<32>(x, lane);
+        }
+    }
+}
+
+// wave-wide bitonic sort of 64*E keys (u32 or u64), ascending; element index
+// i = lane*E + e, so each lane ends with E consecutive sorted keys.  Cross-lane
+// exchanges are DPP / permlane-swap moves (bhs_wave.hip.h): no LDS round trips.
+template <typename T, int E>
+__device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lj = j / E;
+                const bool lower = (lane & lj) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool up = (((lane * E + e) & k) == 0);
+                    const T y = lane_xor_any<T>(x[e], lj, lane);
+                    const T lo = x[e] < y ? x[e] : y;
+                    const T hi = x[e] < y ? y : x[e];
+                    x[e] = (lower == up) ? lo : hi;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const bool up = (((lane * E + e) & k) == 0);
+                        const T a = x[e], b = x[e | j];
+                        const bool sw = (a > b) == up;
+                        x[e] = sw ? b : a;
+                        x[e | j] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int LOG2TS, bool PACK32, int E, typename T>
+__device__ __forceinline__ void wave_sort_and_store(const T* packed, const double* vals, int uniq, int lane,
+                                                    int* __restrict__ Cj, double* __restrict__ Cx,
+                                                    long long outBase)
+{
+    T x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = lane * E + e;
+        x[e] = i < uniq ? packed[i] : (T)~(T)0;
+    }
+    wave_bitonic_sort<T, E>(x, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int r = lane * E + e;
+        if (r < uniq) {
+            int col;
+            unsigned slot;
+            if constexpr (PACK32) { col = (int)(x[e] >> LOG2TS); slot = x[e] & ((1u << LOG2TS) - 1); }
+            else { col = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
+            Cj[outBase + r] = col;
+            Cx[outBase + r] = vals[slot];
+        }
+    }
+}
+
+template <int TS, int LOG2TS, bool NUM, bool PACK32>
+__global__ __launch_bounds__(64) void k_row_wave(
+    const int4* __restrict__ desc, int qn,
+    const int* __restrict__ Aj, const double* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx)
+{
+    // measurement-only ablation mask, compile time (tools/build_variants.sh builds variants with -DBHS_ABL=..):
+    // 1 no value atomics, 2 no sort, 4 no inserts, 8 no stores, 16 no colIndB load, 32 no valB load, 64 no sAv read
+    constexpr int abl = NUM ? BHS_ABL : BHS_ABL_SYM;
+    using Smem = WaveSmem<TS, NUM, PACK32>;
+    using packed_t = typename Smem::packed_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+    const int lane = threadIdx.x;
+    constexpr int MAXB = kMaxB;
+    constexpr int GRP = 4;                   // probes in flight per insert group
+
+    // XCD-aware persistent schedule (gridDim.x is a multiple of 8)
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, perX = gridDim.x >> 3;
+    const int region = (qn + 7) >> 3;
+    const int qBeg = xcd * region;
+    const int qEnd = qBeg + region < qn ? qBeg + region : qn;
+    const int qs = qBeg + lb;
+    const int nIt = qs < qEnd ? (qEnd - qs + perX - 1) / perX : 0;
+    const int4 kNoRow = make_int4(-1, 0, 0, 0);
+
+    // ---- software pipeline over rows: descriptor (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
+    int4 dC = nIt > 0 ? desc[qs] : kNoRow;
+    int4 d1 = nIt > 1 ? desc[qs + perX] : kNoRow;
+    int4 d2 = nIt > 2 ? desc[qs + 2 * perX] : kNoRow;
+    int cC = 0, c1 = 0;
+    double avC = 0.0, av1 = 0.0;
+    if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
+    if (lane < d1.z - d1.y) { c1 = Aj[d1.y + lane]; if (NUM) av1 = Ax[d1.y + lane]; }
+    int b0C = 0, lenC = 0;
+    if (lane < dC.z - dC.y) { b0C = Bp[cC]; lenC = Bp[cC + 1] - b0C; }
+
+    for (int it = 0; it < nIt; ++it) {
+        // ---- prefetch for the rows behind this one
+        const int4 d3 = (it + 3 < nIt) ? desc[qs + (it + 3) * perX] : kNoRow;
+        int c2 = 0;
+        double av2 = 0.0;
+        if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
+        int b01 = 0, len1 = 0;
+        if (lane < d1.z - d1.y) { b01 = Bp[c1]; len1 = Bp[c1 + 1] - b01; }
+
+        const int row = dC.x, a0 = dC.y, a1 = dC.z;
+        // ---- clear the table
+#pragma unroll
+        for (int s = lane * 4; s < TS; s += 256) {
+            *reinterpret_cast<int4*>(&sm.keys[s]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
+            if (NUM) {
+                *reinterpret_cast<double2*>(&sm.vals[s]) = make_double2(0.0, 0.0);
+                *reinterpret_cast<double2*>(&sm.vals[s + 2]) = make_double2(0.0, 0.0);
+            }
+        }
+        int myNew = 0;
+        for (int ca = a0; ca < a1; ca += 64) {
+            // ---- one A entry per lane: B row extent, flat product offsets
+            int b0 = b0C, len = lenC;
+            double av = avC;
+            if (ca != a0) {                                   // rows with > 64 entries: later chunks, unpipelined
+                const int ea = ca + lane;
+                b0 = 0; len = 0; av = 0.0;
+                if (ea < a1) {
+                    const int c = Aj[ea];
+                    if (NUM) av = Ax[ea];
+                    b0 = Bp[c];
+                    len = Bp[c + 1] - b0;
+                }
+            }
+            const int incl = wave_incl_scan_dpp(len);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int last = incl - 1;                      // flat index of this entry's last product
+            const unsigned long long nz = __ballot(len > 0);
+            const int jc = mbcnt64(nz);                      // compacted index among non-empty entries
+            __syncthreads();                                 // previous chunk's readers are done
+            if (len > 0) {
+                sm.sBase[jc] = b0 - (incl - len);
+                if (NUM) sm.sAv[jc] = av;
+            }
+            int done = 0;                                    // entries completed before the window
+            for (int w0 = 0; w0 < total; w0 += 64 * MAXB) {
+                const int nb = (total - w0 + 63) >> 6;       // batches in this window (wave-uniform)
+                if (lane < 2 * MAXB) sm.marks[lane] = 0;
+                __syncthreads();
+                const int rel = last - w0;
+                if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
+                __syncthreads();
+                int col[MAXB];
+                double pv[MAXB];
+                int cum = done;
+                // ---- all loads of the window first
+#pragma unroll
+                for (int u = 0; u < MAXB; ++u) {
+                    col[u] = kEmpty;
+                    pv[u] = 0.0;
+                    if (u < nb) {
+                        const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
+                        const int p = w0 + u * 64 + lane;
+                        const int j = cum + mbcnt64(mk);
+                        cum += __popcll(mk);
+                        if (p < total) {
+                            const long long idx = (long long)sm.sBase[j] + p;
+                            if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
+                            else col[u] = Bj[idx];
+                            if (NUM) {
+                                const double avj = (abl & 64) ? 1.0 : sm.sAv[j];
+                                pv[u] = (abl & 32) ? avj : avj * Bx[idx];
+                            }
+                        }
+                    }
+                }
+                done = cum;
+                if (abl & 4) {
+#pragma unroll
+                    for (int u = 0; u < MAXB; ++u) { asm volatile("" ::"v"(col[u])); if (NUM) asm volatile("" ::"v"(pv[u])); }
+                }
+                // ---- inserts, GRP batches at a time: first probes of a group are read back to back
+#pragma unroll
+                for (int g = 0; g < MAXB; g += GRP) {
+                    if (g < nb && !(abl & 4)) {
+                        unsigned hh[GRP];
+                        int cur[GRP];
+#pragma unroll
+                        for (int v = 0; v < GRP; ++v) {
+                            hh[v] = hash_col(col[g + v], LOG2TS);
+                            cur[v] = kEmpty;
+                            if (col[g + v] != kEmpty) cur[v] = __atomic_load_n(&sm.keys[hh[v]], __ATOMIC_RELAXED);
+                        }
+#pragma unroll
+                        for (int v = 0; v < GRP; ++v) {
+                            const int cv = col[g + v];
+                            if (cv != kEmpty) {
+                                bool ok = cur[v] == cv;
+                                if (cur[v] == kEmpty) {
+                                    const int old = atomicCAS(&sm.keys[hh[v]], kEmpty, cv);
+                                    if (old == kEmpty) { ++myNew; ok = true; }
+                                    else if (old == cv) ok = true;
+                                }
+                                if (!ok) {                           // collision: linear probing
+                                    unsigned h = hh[v];
+                                    for (;;) {
+                                        h = (h + 1) & (TS - 1);
+                                        int c2 = __atomic_load_n(&sm.keys[h], __ATOMIC_RELAXED);
+                                        if (c2 == kEmpty) {
+                                            c2 = atomicCAS(&sm.keys[h], kEmpty, cv);
+                                            if (c2 == kEmpty) { ++myNew; break; }
+                                        }
+                                        if (c2 == cv) break;
+                                    }
+                                    hh[v] = h;
+                                }
+                                if (NUM && !(abl & 1)) unsafeAtomicAdd(&sm.vals[hh[v]], pv[g + v]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!NUM) {
+            myNew = wave_sum_dpp(myNew);
+            if (lane == 0) cntOut[row] = myNew;
+        } else {
+            const long long outBase = dC.w;
+            // ---- compact occupied slots -> packed sort keys
+            int run = 0;
+#pragma unroll
+            for (int s0 = 0; s0 < TS; s0 += 64) {
+                const int s = s0 + lane;
+                const int key = sm.keys[s];
+                const bool valid = key != kEmpty;
+                const unsigned long long bal = __ballot(valid);
+                if (valid) {
+                    packed_t pk;
+                    if constexpr (PACK32) pk = ((unsigned)key << LOG2TS) | (unsigned)s;
+                    else pk = ((unsigned long long)(unsigned)key << 32) | (unsigned)s;
+                    sm.packed[run + mbcnt64(bal)] = pk;
+                }
+                run += __popcll(bal);
+            }
+            const int uniq = run;
+            __syncthreads();
+            if (abl & 2) {
+                if (!(abl & 8))
+                    for (int r = lane; r < uniq; r += 64) {
+                        const packed_t e = sm.packed[r];
+                        Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
+                        Cx[outBase + r] = sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
+                    }
+            } else if (uniq <= 64)
+                wave_sort_and_store<LOG2TS, PACK32, 1>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+            else if (TS >= 128 && uniq <= 128)
+                wave_sort_and_store<LOG2TS, PACK32, 2>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+            else if (TS >= 256 && uniq <= 256)
+                wave_sort_and_store<LOG2TS, PACK32, 4>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+            else if (TS >= 512) {
+                // large tables: bitonic network in LDS (rare bins)
+                int P = 512;
+                while (P < uniq) P <<= 1;
+                for (int s = uniq + lane; s < P; s += 64) sm.packed[s] = (packed_t)~(packed_t)0;
+                __syncthreads();
+                for (int kk = 2; kk <= P; kk <<= 1) {
+                    for (int j = kk >> 1; j > 0; j >>= 1) {
+                        for (int i = lane; i < (P >> 1); i += 64) {
+                            const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                            const int b = a | j;
+                            const bool up = (a & kk) == 0;
+                            const packed_t x = sm.packed[a], y = sm.packed[b];
+                            if ((x > y) == up) { sm.packed[a] = y; sm.packed[b] = x; }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (int r = lane; r < uniq; r += 64) {
+                    const packed_t e = sm.packed[r];
+                    Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
+                    Cx[outBase + r] = sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- rotate the pipeline
+        dC = d1; d1 = d2; d2 = d3;
+        avC = av1; av1 = av2;
+        c1 = c2;
+        b0C = b01; lenC = len1;
     }
 }
 

@@ -117,6 +117,7 @@ struct bhs_handle {
     int* hostSmall = nullptr;            // pinned mirror of `small`
     // options
     int forcePath = 0;
+    int noPack32 = 0;                    // test hook: force 64-bit sort keys
     int maxTableLog2 = 15;
     // timing
     hipEvent_t ev[5] = {};
@@ -187,7 +188,7 @@ int timed_end(bhs_handle* h, EventPair* p)
 }
 
 template <int LOG2TS, int BLOCK, bool NUM, bool WIN>
-int launch_row_hash(bhs_handle* h, const int* queue, int qn, int* CpOrCnt)
+int launch_row_hash(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     constexpr int TS = 1 << LOG2TS;
     auto kern = k_row_hash<TS, LOG2TS, BLOCK, NUM, WIN>;
@@ -211,13 +212,54 @@ int launch_row_hash(bhs_handle* h, const int* queue, int qn, int* CpOrCnt)
     return BHS_SUCCESS;
 }
 
+template <int LOG2TS, bool NUM, bool PACK32>
+int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    constexpr int TS = 1 << LOG2TS;
+    auto kern = k_row_wave<TS, LOG2TS, NUM, PACK32>;
+    const size_t smem = sizeof(WaveSmem<TS, NUM, PACK32>);
+    static int perCU = 0;
+    if (!perCU) {
+        if (smem > 48 * 1024)
+            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nb = 0;   // resident 64-lane workgroups per CU: registers, LDS and the 32-wave cap all count
+        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, smem));
+        perCU = std::max(1, std::min(nb, 32));
+    }
+    long long grid = std::min<long long>((long long)qn, (long long)h->numCU * perCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);       // XCD-aware schedule needs a multiple of 8
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->stream, queue, qn, h->dAj, h->dAx,
+                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <int LOG2TS, bool NUM>
+int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    if constexpr (NUM) {
+        // 32-bit sort keys when every column index fits beside the slot index
+        if ((long long)h->n <= (1LL << (32 - LOG2TS)) && !h->noPack32)
+            return launch_row_wave_impl<LOG2TS, true, true>(h, queue, qn, CpOrCnt);
+        return launch_row_wave_impl<LOG2TS, true, false>(h, queue, qn, CpOrCnt);
+    } else {
+        return launch_row_wave_impl<LOG2TS, false, false>(h, queue, qn, CpOrCnt);
+    }
+}
+
 template <bool NUM>
-int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int* queue, int qn, int* CpOrCnt)
+int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
 {
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_CASE(LG, BL, W) \
     if (lg == LG && c.block == BL && win == W) return launch_row_hash<LG, BL, NUM, W>(h, queue, qn, CpOrCnt)
+#define BHS_WAVE(LG) \
+    if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
+    BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);
+    if constexpr (!NUM) { BHS_WAVE(12); }
+#undef BHS_WAVE
     if (!win) {
         BHS_CASE(6, 64, false);
         BHS_CASE(7, 64, false);
@@ -303,7 +345,7 @@ int run_pipeline(bhs_handle* h)
         return BHS_SUCCESS;
     }
     BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
-    BHS_TRY(ensure(h, h->queue, sizeof(int) * (size_t)m));
+    BHS_TRY(ensure(h, h->queue, sizeof(int4) * (size_t)m));
     const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
     BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
 
@@ -330,11 +372,11 @@ int run_pipeline(bhs_handle* h)
     h->nnzCt = (long long)tot;
     BHS_HIP(hipMemcpyAsync(small + S_SYM_START, symStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
-        long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 16);
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
         BHS_TRY(timed_begin(h, "fill_queues", &ep));
         hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
                            (const int*)h->ub.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
-                           small + S_SYM_CURSOR, (int*)h->queue.p, symSpec,
+                           small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
                            (unsigned long long*)(small + S_SYM_SUMS));
         BHS_HIP(hipGetLastError());
         BHS_TRY(timed_end(h, ep));
@@ -348,7 +390,7 @@ int run_pipeline(bhs_handle* h)
     for (int b = 1; b < kNumSymBins; ++b) {
         if (!symCount[b]) continue;
         BHS_TRY(timed_begin(h, kSymNames[b], &ep));
-        int rc = dispatch_bin<false>(h, kSymCfg[b], (const int*)h->queue.p + symStart[b], symCount[b], (int*)h->Cp.p);
+        int rc = dispatch_bin<false>(h, kSymCfg[b], (const int4*)h->queue.p + symStart[b], symCount[b], (int*)h->Cp.p);
         if (rc) return rc;
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
@@ -385,11 +427,11 @@ int run_pipeline(bhs_handle* h)
     BHS_TRY(ensure(h, h->Cx, sizeof(double) * (size_t)std::max<long long>(nnzC, 1)));
     BHS_HIP(hipMemcpyAsync(small + S_NUM_START, numStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
-        long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 16);
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
         BHS_TRY(timed_begin(h, "fill_queues", &ep));
         hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
                            (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
-                           small + S_NUM_CURSOR, (int*)h->queue.p, numSpec,
+                           small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
                            (unsigned long long*)(small + S_NUM_SUMS));
         BHS_HIP(hipGetLastError());
         BHS_TRY(timed_end(h, ep));
@@ -401,7 +443,7 @@ int run_pipeline(bhs_handle* h)
     for (int b = 1; b < kNumNumBins; ++b) {
         if (!numCount[b]) continue;
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
-        int rc = dispatch_bin<true>(h, kNumCfg[b], (const int*)h->queue.p + numStart[b], numCount[b], (int*)h->Cp.p);
+        int rc = dispatch_bin<true>(h, kNumCfg[b], (const int4*)h->queue.p + numStart[b], numCount[b], (int*)h->Cp.p);
         if (rc) return rc;
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
@@ -708,6 +750,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
         h->maxTableLog2 = (int)value;
         return BHS_SUCCESS;
     }
+    if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "verbose")) return bhs_set_verbose(h, (int)value);
     return BHS_ERR_INVALID_ARG;
 }

@@ -1,0 +1,103 @@
+"""Multi-GPU layer: rows of A (and therefore of C) shard across the GPUs of one
+node, B is replicated, every rank runs the single-GPU pipeline on its row
+block, and one all-gatherv over RCCL/xGMI assembles the full CSR of C on every
+rank (north_star; the reference is single-device: device 0 is hard-coded at
+bhsparse_cuda.h:100-101).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm; "gloo"
+on CPU tensors for the world_size-2 tests).  The only data-path collective is
+the all-gatherv: message sizes differ per rank (nnz of each row block), so it
+is issued as one uneven all_gather (RCCL lowers it to a group of per-root
+broadcasts, which on the fully connected xGMI topology run on all 7 links at
+once) after a tiny all_gather of the per-rank sizes.
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_block(m, rank, world):
+    """Contiguous row range [r0, r1) of rank `rank`: equal row counts (for the
+    stencil matrices equal rows == equal work)."""
+    base, rem = divmod(m, world)
+    r0 = rank * base + min(rank, rem)
+    return r0, r0 + base + (1 if rank < rem else 0)
+
+
+def _uneven_all_gather(full, local, sizes, offsets, group):
+    """full[offsets[r]:offsets[r]+sizes[r]] <- rank r's `local` on every rank."""
+    world = len(sizes)
+    outs = [full[offsets[r]:offsets[r] + sizes[r]] for r in range(world)]
+    if dist.get_backend(group) == "gloo" or any(s == 0 for s in sizes):
+        # gloo has no uneven all_gather; zero-size messages are skipped: per-root broadcasts
+        works = []
+        for r in range(world):
+            if sizes[r] == 0:
+                continue
+            if r == dist.get_rank(group):
+                outs[r].copy_(local)
+            works.append(dist.broadcast(outs[r], src=dist.get_global_rank(group, r) if group else r,
+                                        group=group, async_op=True))
+        for w in works:
+            w.wait()
+    else:
+        dist.all_gather(outs, local, group=group)
+
+
+def allgatherv_csr(m_total, local_rowptr, local_col, local_val, group=None, out=None):
+    """Assemble the global CSR of C from per-rank row blocks.
+
+    local_rowptr: int32[m_local+1] starting at 0; local_col int32[nnz_local];
+    local_val float64[nnz_local] (device tensors for RCCL, CPU tensors for gloo).
+    Returns (rowptr int32[m_total+1], col, val, sizes) identical on every rank.
+    `out` may carry preallocated (rowptr, col, val) buffers to reuse across steps.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_col.device
+    m_local = local_rowptr.numel() - 1
+    nnz_local = int(local_col.numel())
+    # 1. sizes: (rows, nnz) of every rank — int64, offsets stay 64-bit until the final fix-up
+    mine = torch.tensor([m_local, nnz_local], dtype=torch.int64, device=dev)
+    allsz = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allsz, mine, group=group)
+    allsz = allsz.view(world, 2).cpu()
+    rows = [int(x) for x in allsz[:, 0]]
+    nnzs = [int(x) for x in allsz[:, 1]]
+    assert sum(rows) == m_total, (rows, m_total)
+    nnz_total = sum(nnzs)
+    if nnz_total >= 2 ** 31:
+        raise OverflowError("nnz(C) = %d does not fit the int32 index_type of the bhsparse API" % nnz_total)
+    row_off = [0] * world
+    nnz_off = [0] * world
+    for r in range(1, world):
+        row_off[r] = row_off[r - 1] + rows[r - 1]
+        nnz_off[r] = nnz_off[r - 1] + nnzs[r - 1]
+    if out is not None and out[1].numel() >= nnz_total and out[0].numel() == m_total + 1:
+        rowptr, col, val = out[0], out[1][:nnz_total], out[2][:nnz_total]
+    else:
+        rowptr = torch.empty(m_total + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(nnz_total, dtype=torch.int32, device=dev)
+        val = torch.empty(nnz_total, dtype=torch.float64, device=dev)
+    # 2. the all-gatherv proper (values, columns), plus row pointers rebased by the rank's nnz offset
+    _uneven_all_gather(val, local_val[:nnz_local], nnzs, nnz_off, group)
+    _uneven_all_gather(col, local_col[:nnz_local], nnzs, nnz_off, group)
+    rebased = (local_rowptr[:m_local] + nnz_off[rank]).to(torch.int32)
+    _uneven_all_gather(rowptr, rebased, rows, row_off, group)
+    rowptr[m_total] = nnz_total
+    return rowptr, col, val, {"rows": rows, "nnz": nnzs}
+
+
+class _DevArray(object):
+    """Zero-copy view of library-owned device memory for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_view(ptr, n, dtype, device):
+    """torch tensor aliasing `n` elements of `dtype` at device address `ptr`."""
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=dtype, device=device)
+    typestr = {torch.int32: "<i4", torch.float64: "<f8", torch.int64: "<i8"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
