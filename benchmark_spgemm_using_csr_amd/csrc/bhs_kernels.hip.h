@@ -510,7 +510,30 @@ __global__ __launch_bounds__(BLOCK) void k_row_hash(
 //    dispatch order), so each XCD walks one contiguous eighth of the queue and
 //    neighbouring rows share B rows through that XCD's private L2.
 // ===========================================================================
-constexpr int kMaxB = 12;    // product batches per window: 12 x 64 = 768 products with their loads in flight
+#ifndef BHS_WPB
+#define BHS_WPB 1
+#endif
+constexpr int kWavesPerBlock = BHS_WPB;   // independent row-waves per workgroup (co-located on one CU)
+
+// Orders LDS traffic between the lanes of ONE wave: the LDS pipe executes a wave's DS
+// instructions in order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// product batches per window (MAXB x 64 products with their loads in flight): deeper for the symbolic pass
+// (one register per product), shallower for the numeric pass (three) so that it keeps 8 waves per SIMD
+#ifndef BHS_MAXB_SYM
+#define BHS_MAXB_SYM 12
+#endif
+#ifndef BHS_MAXB_NUM
+#define BHS_MAXB_NUM 6
+#endif
+constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM;
+constexpr int kMaxB = kMaxBSym > kMaxBNum ? kMaxBSym : kMaxBNum;   // sizes the LDS mark words
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
 // otherwise (col << 32 | slot) in 64 bits.
@@ -613,7 +636,7 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const doubl
 }
 
 template <int TS, int LOG2TS, bool NUM, bool PACK32>
-__global__ __launch_bounds__(64) void k_row_wave(
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_row_wave(
     const int4* __restrict__ desc, int qn,
     const int* __restrict__ Aj, const double* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
@@ -625,13 +648,16 @@ __global__ __launch_bounds__(64) void k_row_wave(
     using Smem = WaveSmem<TS, NUM, PACK32>;
     using packed_t = typename Smem::packed_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
-    const int lane = threadIdx.x;
-    constexpr int MAXB = kMaxB;
-    constexpr int GRP = 4;                   // probes in flight per insert group
+    constexpr int WPB = kWavesPerBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Smem& sm = reinterpret_cast<Smem*>(smem_raw)[wave];
+    constexpr int MAXB = NUM ? kMaxBNum : kMaxBSym;
+    constexpr int GRP = (MAXB % 4 == 0) ? 4 : (MAXB % 3 == 0 ? 3 : 2);                   // probes in flight per insert group
 
     // XCD-aware persistent schedule (gridDim.x is a multiple of 8)
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, perX = gridDim.x >> 3;
+    // the WPB waves of a workgroup take consecutive queue entries, so that rows which share B rows
+    // run on the same CU at the same time and meet in its L1
+    const int xcd = blockIdx.x & 7, lb = (blockIdx.x >> 3) * WPB + wave, perX = (gridDim.x >> 3) * WPB;
     const int region = (qn + 7) >> 3;
     const int qBeg = xcd * region;
     const int qEnd = qBeg + region < qn ? qBeg + region : qn;
@@ -689,7 +715,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
             const int last = incl - 1;                      // flat index of this entry's last product
             const unsigned long long nz = __ballot(len > 0);
             const int jc = mbcnt64(nz);                      // compacted index among non-empty entries
-            __syncthreads();                                 // previous chunk's readers are done
+            wave_sync();                                 // previous chunk's readers are done
             if (len > 0) {
                 sm.sBase[jc] = b0 - (incl - len);
                 if (NUM) sm.sAv[jc] = av;
@@ -698,10 +724,10 @@ __global__ __launch_bounds__(64) void k_row_wave(
             for (int w0 = 0; w0 < total; w0 += 64 * MAXB) {
                 const int nb = (total - w0 + 63) >> 6;       // batches in this window (wave-uniform)
                 if (lane < 2 * MAXB) sm.marks[lane] = 0;
-                __syncthreads();
+                wave_sync();
                 const int rel = last - w0;
                 if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
-                __syncthreads();
+                wave_sync();
                 int col[MAXB];
                 double pv[MAXB];
                 int cum = done;
@@ -773,7 +799,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (!NUM) {
             myNew = wave_sum_dpp(myNew);
             if (lane == 0) cntOut[row] = myNew;
@@ -796,7 +822,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
                 run += __popcll(bal);
             }
             const int uniq = run;
-            __syncthreads();
+            wave_sync();
             if (abl & 2) {
                 if (!(abl & 8))
                     for (int r = lane; r < uniq; r += 64) {
@@ -815,7 +841,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
                 int P = 512;
                 while (P < uniq) P <<= 1;
                 for (int s = uniq + lane; s < P; s += 64) sm.packed[s] = (packed_t)~(packed_t)0;
-                __syncthreads();
+                wave_sync();
                 for (int kk = 2; kk <= P; kk <<= 1) {
                     for (int j = kk >> 1; j > 0; j >>= 1) {
                         for (int i = lane; i < (P >> 1); i += 64) {
@@ -825,7 +851,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
                             const packed_t x = sm.packed[a], y = sm.packed[b];
                             if ((x > y) == up) { sm.packed[a] = y; sm.packed[b] = x; }
                         }
-                        __syncthreads();
+                        wave_sync();
                     }
                 }
                 for (int r = lane; r < uniq; r += 64) {
@@ -835,7 +861,7 @@ __global__ __launch_bounds__(64) void k_row_wave(
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- rotate the pipeline
         dC = d1; d1 = d2; d2 = d3;
         avC = av1; av1 = av2;

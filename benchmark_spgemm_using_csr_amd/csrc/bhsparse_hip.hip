@@ -66,7 +66,7 @@ const KernelCfg kNumCfg[kNumNumBins] = {
     {0, 0, false},   {6, 64, false},  {7, 64, false},   {8, 64, false},  {9, 64, false},
     {10, 64, false}, {11, 64, false}, {12, 256, false}, {12, 256, true}};
 
-BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2)
+BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct)
 {
     BinSpec s;
     memset(&s, 0, sizeof(s));
@@ -75,7 +75,7 @@ BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2)
     for (int b = 1; b < nbins; ++b) {
         int lg = std::min(cfg[b].log2ts, maxLog2);
         int ts = 1 << lg;
-        s.upper[b] = cfg[b].win ? 0x7fffffff : ts - ts / 4;
+        s.upper[b] = cfg[b].win ? 0x7fffffff : (int)((long long)ts * loadPct / 100);
         if (b > 1 && s.upper[b] < s.upper[b - 1]) s.upper[b] = s.upper[b - 1];
     }
     s.upper[nbins - 1] = 0x7fffffff;
@@ -118,6 +118,7 @@ struct bhs_handle {
     // options
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
+    int symLoadPct = 75, numLoadPct = 75; // max table load factor (percent) that decides a row's bin
     int maxTableLog2 = 15;
     // timing
     hipEvent_t ev[5] = {};
@@ -217,19 +218,20 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     constexpr int TS = 1 << LOG2TS;
     auto kern = k_row_wave<TS, LOG2TS, NUM, PACK32>;
-    const size_t smem = sizeof(WaveSmem<TS, NUM, PACK32>);
+    constexpr int WPB = kWavesPerBlock;
+    const size_t smem = sizeof(WaveSmem<TS, NUM, PACK32>) * WPB;
     static int perCU = 0;
     if (!perCU) {
         if (smem > 48 * 1024)
             BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int nb = 0;   // resident 64-lane workgroups per CU: registers, LDS and the 32-wave cap all count
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, smem));
-        perCU = std::max(1, std::min(nb, 32));
+        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WPB, smem));
+        perCU = std::max(1, std::min(nb, 32 / WPB));
     }
-    long long grid = std::min<long long>((long long)qn, (long long)h->numCU * perCU);
+    long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * perCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);       // XCD-aware schedule needs a multiple of 8
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->stream, queue, qn, h->dAj, h->dAx,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, h->dAj, h->dAx,
                        h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -350,8 +352,8 @@ int run_pipeline(bhs_handle* h)
     BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
 
     // ------------------------------------------------------------ stage 1
-    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2);
-    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12));
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct);
+    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12), h->numLoadPct);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
@@ -751,6 +753,11 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
         return BHS_SUCCESS;
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
+        if (value < 5 || value > 75) return BHS_ERR_INVALID_ARG;
+        (key[0] == 's' ? h->symLoadPct : h->numLoadPct) = (int)value;
+        return BHS_SUCCESS;
+    }
     if (!strcmp(key, "verbose")) return bhs_set_verbose(h, (int)value);
     return BHS_ERR_INVALID_ARG;
 }

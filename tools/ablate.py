@@ -15,9 +15,11 @@ m = Bp.numel() - 1
 plats = [False] * 9; plats[3] = True
 bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
+for kv in os.environ.get('BHS_OPTS','').split(','):
+    if kv: k_, v_ = kv.split('='); assert bh.set_option(k_, int(v_)) == 0
 for _ in range(2): assert bh.spgemm() == 0
 acc = {}
 for _ in range(3):
     assert bh.spgemm() == 0
     for s in bh.kernel_stats(): acc[s["name"]] = acc.get(s["name"], 0) + s["ms"] / 3
-print(os.path.basename(tag), {k: round(v, 3) for k, v in acc.items() if v > 0.05})
+print(os.path.basename(tag), os.environ.get('BHS_OPTS',''), {k: round(v, 3) for k, v in acc.items() if v > 0.05})
