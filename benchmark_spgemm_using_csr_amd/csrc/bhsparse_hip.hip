@@ -100,6 +100,7 @@ struct bhs_handle {
     int device = 0;
     int numCU = 256;
     int verbose = 0;
+    bool bannerDone = false;
     hipStream_t stream = nullptr;
     bool hasData = false, ownAB = false, hasC = false;
     int m = 0, k = 0, n = 0, nnzA = 0, nnzB = 0;
@@ -115,6 +116,11 @@ struct bhs_handle {
     // workspace
     DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
     int* hostSmall = nullptr;            // pinned mirror of `small`
+    int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
+    size_t hostRowPtrCap = 0;
+    hipStream_t copyStream = nullptr;    // D2H of rowPtrC overlaps the numeric stage
+    hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
+    bool wantHostRowPtr = false, rowPtrStaged = false;
     // options
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
@@ -146,6 +152,17 @@ int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
     if (bytes == 0) bytes = 16;
     BHS_HIP(hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    return BHS_SUCCESS;
+}
+
+int ensure_host_rowptr(bhs_handle* h, size_t bytes)
+{
+    if (h->hostRowPtrCap >= bytes) return BHS_SUCCESS;
+    if (h->hostRowPtr) BHS_HIP(hipHostFree(h->hostRowPtr));
+    h->hostRowPtr = nullptr;
+    h->hostRowPtrCap = 0;
+    BHS_HIP(hipHostMalloc((void**)&h->hostRowPtr, bytes, hipHostMallocDefault));
+    h->hostRowPtrCap = bytes;
     return BHS_SUCCESS;
 }
 
@@ -440,6 +457,18 @@ int run_pipeline(bhs_handle* h)
         h->stats[ep->stat].launches++;
     }
     BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+    h->rowPtrStaged = false;
+    if (h->wantHostRowPtr) {
+        // rowPtrC is final after the scan: ship it to pinned host memory on a second stream while the
+        // numeric kernels run (the reference does this D2H inside its timed region too, bhsparse_cuda.h:2787)
+        const size_t bytes = sizeof(int) * ((size_t)m + 1);
+        BHS_TRY(ensure_host_rowptr(h, bytes));
+        BHS_HIP(hipEventRecord(h->evScanDone, h->stream));
+        BHS_HIP(hipStreamWaitEvent(h->copyStream, h->evScanDone, 0));
+        BHS_HIP(hipMemcpyAsync(h->hostRowPtr, h->Cp.p, bytes, hipMemcpyDeviceToHost, h->copyStream));
+        BHS_HIP(hipEventRecord(h->evCopyDone, h->copyStream));
+        h->rowPtrStaged = true;
+    }
 
     // ------------------------------------------------------------ stage 4: numeric
     for (int b = 1; b < kNumNumBins; ++b) {
@@ -542,6 +571,9 @@ int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
     for (int i = 0; i < 5; ++i)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evScanDone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evCopyDone, hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
     if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * S_SMALL_INTS, hipHostMallocDefault) != hipSuccess) {
         delete h;
         return BHS_ERR_ALLOC;
@@ -554,11 +586,13 @@ int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
 int bhs_set_verbose(bhs_handle* h, int level)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
-    if (level && !h->verbose) {
+    if (level && !h->bannerDone) {
+        h->bannerDone = true;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess)
-            printf("Device [ %d ] %s (%s) @ %.0f MHz, %d CUs, %.0f GB HBM\n", h->device, prop.name, prop.gcnArchName,
-                   prop.clockRate * 1e-3, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+            printf("Device [ %d ] %s (%s) @ %.0f MHz, %d CUs, %.0f GB HBM\n", h->device,
+                   prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.clockRate * 1e-3,
+                   prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
     }
     h->verbose = level;
     return BHS_SUCCESS;
@@ -588,6 +622,10 @@ int bhs_destroy(bhs_handle* h)
     release(h->blockSum);
     release(h->small);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
+    if (h->hostRowPtr) (void)hipHostFree(h->hostRowPtr);
+    if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+    if (h->evScanDone) (void)hipEventDestroy(h->evScanDone);
+    if (h->evCopyDone) (void)hipEventDestroy(h->evCopyDone);
     for (auto& p : h->evPool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (int i = 0; i < 5; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -630,6 +668,7 @@ int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const double* csr
     h->dAp = (const int*)h->ownA[0].p; h->dAj = (const int*)h->ownA[1].p; h->dAx = (const double*)h->ownA[2].p;
     h->dBp = (const int*)h->ownB[0].p; h->dBj = (const int*)h->ownB[1].p; h->dBx = (const double*)h->ownB[2].p;
     h->ownAB = true;
+    BHS_TRY(ensure_host_rowptr(h, sizeof(int) * ((size_t)m + 1)));   // pinned staging, outside the timed region
     return finish_set_data(h);
 }
 
@@ -654,7 +693,11 @@ int bhs_warmup(bhs_handle* h)
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasData) return BHS_ERR_NOT_READY;
     BHS_HIP(hipSetDevice(h->device));
-    return run_pipeline(h);
+    h->wantHostRowPtr = h->ownAB;      // host-pointer callers get rowPtrC back: warm that path up too
+    const int rc = run_pipeline(h);
+    h->wantHostRowPtr = false;
+    if (rc == BHS_SUCCESS && h->rowPtrStaged) BHS_HIP(hipEventSynchronize(h->evCopyDone));
+    return rc;
 }
 
 int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_out, double stage_ms_out[4])
@@ -662,7 +705,9 @@ int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_ou
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasData) return BHS_ERR_NOT_READY;
     BHS_HIP(hipSetDevice(h->device));
+    h->wantHostRowPtr = rowPtrC_out != nullptr;
     const int rc = run_pipeline(h);
+    h->wantHostRowPtr = false;
     if (rc) return rc;
     if (h->verbose) {
         printf("STAGE 1 time: %g ms.\n", h->stageMs[0]);
@@ -672,8 +717,13 @@ int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_ou
         printf("STAGE 4 time: %g ms.\n", h->stageMs[3]);
     }
     if (rowPtrC_out) {
-        BHS_HIP(hipMemcpyAsync(rowPtrC_out, h->Cp.p, sizeof(int) * ((size_t)h->m + 1), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
+        if (h->rowPtrStaged) {
+            BHS_HIP(hipEventSynchronize(h->evCopyDone));
+            memcpy(rowPtrC_out, h->hostRowPtr, sizeof(int) * ((size_t)h->m + 1));
+        } else {
+            BHS_HIP(hipMemcpyAsync(rowPtrC_out, h->Cp.p, sizeof(int) * ((size_t)h->m + 1), hipMemcpyDeviceToHost, h->stream));
+            BHS_HIP(hipStreamSynchronize(h->stream));
+        }
     }
     if (nnzCt_out) *nnzCt_out = h->nnzCt;
     if (nnzC_out) *nnzC_out = (int)h->nnzC;

@@ -1,0 +1,25 @@
+// common.h — host-side constants and types of the bhSPARSE facade.
+// Mirrors SpGEMM_cuda/common.h:26-37 (BHSPARSE_SUCCESS, index_type, value_type,
+// NUM_PLATFORMS and the platform slots) with a new BHSPARSE_HIP slot; no CUDA /
+// OpenCL / HIP headers are needed by host code (the device side is reached only
+// through the C-ABI of include/bhsparse_hip.h).
+#ifndef BHSPARSE_AMD_COMMON_H
+#define BHSPARSE_AMD_COMMON_H
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#define BHSPARSE_SUCCESS 0
+
+typedef int    index_type;
+typedef double value_type;
+
+#define NUM_PLATFORMS   9
+#define NAIVE           0
+#define BHSPARSE_CUDA   1   // accepted as an alias of the HIP backend (published command lines keep working)
+#define BHSPARSE_OPENCL 2   // alias
+#define BHSPARSE_HIP    3   // new slot (3..8 are unused in the reference)
+
+#endif

@@ -1,0 +1,183 @@
+// spgemm_main.cpp — the reference's benchmark/test driver restated for the HIP backend
+// (SpGEMM_cuda/main.cu:23-314: benchmark_spgemm, test_small_spgemm, main).
+//
+// Lives under tests/ because, like the reference's driver, it CHECKS the result after the
+// multiply (ref_spgemm::compData, ref_spgemm.h:65-127) — here against the CPU oracle
+// (oracle/), which only test code may link.  The product is libbhsparse_hip.so + the
+// facade header host/bhsparse.h; this file shows that the reference's own call sequence
+// runs unchanged on them.
+//
+//   ./spgemm -hip|-cuda|-opencl -spgemm <0|1|2|3|4|A.mtx> [B.mtx] [-seed S] [-grid NX NY [NZ]]
+//            [-keepvalues] [-nocheck] [-cpu]
+// datasets (main.cu:30-53): 0 built-in 4x6*6x4 test, 1 poisson5pt 256^2, 2 poisson9pt 256^2,
+// 3 poisson7pt 51^3, 4 poisson27pt 51^3, else Matrix Market file(s).
+#include <chrono>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../benchmark_spgemm_using_csr_amd/host/bhsparse.h"
+#include "../../benchmark_spgemm_using_csr_amd/host/mtx_reader.h"
+#include "../../oracle/ref_spgemm_oracle.h"
+
+using namespace std;
+
+struct Options {
+    uint64_t seed = 20140519ull;
+    int gx = 0, gy = 0, gz = 0;
+    bool keepvalues = false, check = true, cpu_time = false;
+};
+
+// ref_spgemm::compData (ref_spgemm.h:65-127) with the CPU oracle in place of cusp::multiply and
+// the north_star tolerance (1e-6 relative) in place of the reference's 10 %.  Same prints.
+static bool compData(const CsrHost &A, const CsrHost &B, int m, int nnzC, index_type *csrRowPtrC,
+                     index_type *csrColIndC, value_type *csrValC, bool time_cpu, long long nnzCt)
+{
+    cout << endl << "Checking correctness ..." << endl;
+    vector<int64_t> Cp(m + 1);
+    const auto t0 = chrono::steady_clock::now();
+    const int64_t refnnz = oracle_spgemm_symbolic(m, A.num_cols, B.num_cols, A.row_offsets.data(), A.column_indices.data(),
+                                                  B.row_offsets.data(), B.column_indices.data(), Cp.data(), 0);
+    vector<int32_t> Cj((size_t)max<int64_t>(refnnz, 1));
+    vector<double> Cx((size_t)max<int64_t>(refnnz, 1));
+    oracle_spgemm_numeric(m, A.num_cols, B.num_cols, A.row_offsets.data(), A.column_indices.data(), A.values.data(),
+                          B.row_offsets.data(), B.column_indices.data(), B.values.data(), Cp.data(), Cj.data(), Cx.data(), 0);
+    const double cpu_ms = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
+    if (time_cpu)
+        cout << "[ CPU oracle, " << oracle_max_threads() << " threads ] SpGEMM time: " << cpu_ms << " ms. Gflops = "
+             << 2.0 * (double)nnzCt / (cpu_ms * 1.0e+6) << endl;
+    int64_t out[4];
+    oracle_compare(m, refnnz, Cp.data(), Cj.data(), Cx.data(), nnzC, csrRowPtrC, csrColIndC, csrValC, 1e-6, out);
+    if (out[0] == 0) { cout << "nnzC = " << nnzC << ", oracle's nnzC = " << refnnz << ". NO PASS!" << endl; return false; }
+    cout << "nnzC = " << nnzC << ". PASS!" << endl;
+    if (out[0] == 1) { cout << "RowPtrC NO PASS!" << endl; return false; }
+    cout << "RowPtrC PASS!" << endl;
+    if (out[0] == 2) { cout << "ColIndC/csrValC NO PASS! #err = " << out[2] + out[3] << endl; return false; }
+    cout << "ColIndC/csrValC PASS!" << endl;
+    return true;
+}
+
+static int run(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const Options &opt)
+{
+    int m = A.num_rows, k = A.num_cols, n = B.num_cols;
+    int nnzA = A.num_entries, nnzB = B.num_entries;
+    cout << " A: ( " << m << " by " << k << ", nnz = " << nnzA << " ) " << endl;
+    cout << " B: ( " << k << " by " << n << ", nnz = " << nnzB << " ) " << endl;
+    index_type *csrRowPtrC = (index_type *)malloc((m + 1) * sizeof(index_type));
+
+    int err = 0;
+    bhsparse *bh_sparse = new bhsparse();
+    err = bh_sparse->initPlatform(platforms);
+    if (err != BHSPARSE_SUCCESS) return err;
+    err = bh_sparse->initData(m, k, n, nnzA, A.values.data(), A.row_offsets.data(), A.column_indices.data(),
+                              nnzB, B.values.data(), B.row_offsets.data(), B.column_indices.data(), csrRowPtrC);
+    if (err != BHSPARSE_SUCCESS) return err;
+    for (int i = 0; i < warmups; i++) {
+        err = bh_sparse->warmup();
+        if (err != BHSPARSE_SUCCESS) return err;
+    }
+    err = bh_sparse->spgemm();
+    if (err != BHSPARSE_SUCCESS) return err;
+
+    int nnzC = bh_sparse->get_nnzC();
+    index_type *csrColIndC = (index_type *)malloc(max(nnzC, 1) * sizeof(index_type));
+    value_type *csrValC = (value_type *)malloc(max(nnzC, 1) * sizeof(value_type));
+    err = bh_sparse->get_C(csrColIndC, csrValC);
+    if (err != BHSPARSE_SUCCESS) return err;
+    const long long nnzCt = bh_sparse->get_nnzCt();
+    err = bh_sparse->free_mem();
+    if (err != BHSPARSE_SUCCESS) return err;
+    err = bh_sparse->freePlatform();
+    if (err != BHSPARSE_SUCCESS) return err;
+
+    bool ok = true;
+    if (opt.check) ok = compData(A, B, m, nnzC, csrRowPtrC, csrColIndC, csrValC, opt.cpu_time, nnzCt);
+    cout << "{\"nnzCt\": " << nnzCt << ", \"nnzC\": " << nnzC << ", \"pass\": " << (ok ? "true" : "false") << "}" << endl;
+    free(csrColIndC); free(csrValC); free(csrRowPtrC);
+    delete bh_sparse;
+    return ok ? BHSPARSE_SUCCESS : -100;
+}
+
+static int benchmark_spgemm(const char *dataset_name1, const char *dataset_name2, bool *platforms, const Options &opt)
+{
+    CsrHost A, B;
+    auto gal = [&](const char *st, int nx, int ny, int nz, const char *label) {
+        if (opt.gx) { nx = opt.gx; ny = opt.gy; nz = opt.gz ? opt.gz : 1; }
+        gallery_poisson(st, nx, ny, nz, A);
+        B = A;
+        cout << label;
+    };
+    if (strcmp(dataset_name1, "1") == 0) gal("poisson5pt", 256, 256, 1, "2D FD, 5-point. ");
+    else if (strcmp(dataset_name1, "2") == 0) gal("poisson9pt", 256, 256, 1, "2D FE, 9-point. ");
+    else if (strcmp(dataset_name1, "3") == 0) gal("poisson7pt", 51, 51, 51, "3D FD, 7-point. ");
+    else if (strcmp(dataset_name1, "4") == 0) gal("poisson27pt", 51, 51, 51, "3D FE, 27-point. ");
+    else {
+        string msg;
+        cout << " A: " << dataset_name1 << endl;
+        if (read_matrix_market(dataset_name1, A, &msg)) { cout << msg << endl; return -10; }
+        cout << " B: " << dataset_name2 << endl;
+        if (read_matrix_market(dataset_name2, B, &msg)) { cout << msg << endl; return -10; }
+        if (A.num_cols != B.num_rows) { cout << "dimension mismatch" << endl; return -11; }
+    }
+    if (!opt.keepvalues) {            // main.cu:79-94, with a fixed seed instead of time(NULL)
+        fill_values(A.values, opt.seed, 0);
+        fill_values(B.values, opt.seed, (uint64_t)A.num_entries);
+    }
+    return run(A, B, platforms, 3, opt);
+}
+
+static int test_small_spgemm(bool *platforms, const Options &opt)
+{
+    // main.cu:153-205
+    CsrHost A, B;
+    A.num_rows = 4; A.num_cols = 6; A.num_entries = 6;
+    A.row_offsets = {0, 1, 4, 5, 6};
+    A.column_indices = {0, 1, 2, 3, 3, 1};
+    for (int i = 0; i < 6; i++) A.values.push_back((value_type)((i + 1) * 10));
+    B.num_rows = 6; B.num_cols = 4; B.num_entries = 7;
+    B.row_offsets = {0, 1, 3, 5, 5, 5, 7};
+    B.column_indices = {0, 1, 3, 0, 1, 1, 3};
+    for (int i = 0; i < 7; i++) B.values.push_back((value_type)(i + 1));
+    return run(A, B, platforms, 0, opt);
+}
+
+int main(int argc, char **argv)
+{
+    bool *platforms = (bool *)malloc(sizeof(bool) * NUM_PLATFORMS);
+    memset(platforms, 0, sizeof(bool) * NUM_PLATFORMS);
+    int argi = 1;
+    const char *dataset_name1 = "0", *dataset_name2 = "0";
+    Options opt;
+    if (argc > argi) {
+        const char *option = argv[argi++];
+        if (strcmp(option, "-hip") == 0) platforms[BHSPARSE_HIP] = true;
+        else if (strcmp(option, "-cuda") == 0) platforms[BHSPARSE_CUDA] = true;        // aliases: same backend
+        else if (strcmp(option, "-opencl") == 0 || strcmp(option, "-opencl-hcmp") == 0) platforms[BHSPARSE_OPENCL] = true;
+    }
+    if (argc > argi && strcmp(argv[argi], "-spgemm") == 0) {
+        argi++;
+        if (argc > argi) { dataset_name1 = argv[argi++]; dataset_name2 = dataset_name1; }
+        if (argc > argi && argv[argi][0] != '-') dataset_name2 = argv[argi++];
+    }
+    while (argc > argi) {
+        string o = argv[argi++];
+        if (o == "-seed" && argc > argi) opt.seed = strtoull(argv[argi++], 0, 10);
+        else if (o == "-grid" && argc > argi + 1) {
+            opt.gx = atoi(argv[argi++]); opt.gy = atoi(argv[argi++]);
+            if (argc > argi && argv[argi][0] != '-') opt.gz = atoi(argv[argi++]);
+        } else if (o == "-keepvalues") opt.keepvalues = true;
+        else if (o == "-nocheck") opt.check = false;
+        else if (o == "-cpu") opt.cpu_time = true;
+    }
+    cout << "------------------------" << endl;
+    int err = 0;
+    if (strcmp(dataset_name1, "0") == 0) err = test_small_spgemm(platforms, opt);
+    else err = benchmark_spgemm(dataset_name1, dataset_name2, platforms, opt);
+    if (err != BHSPARSE_SUCCESS) cout << "Found an err, code = " << err << endl;
+    cout << "------------------------" << endl;
+    free(platforms);
+    return err == BHSPARSE_SUCCESS ? 0 : 1;   // the reference always returns 0 (main.cu:313); a test driver should not
+}

@@ -1,0 +1,81 @@
+"""The reference-style C++ driver (tests/driver/spgemm_main.cpp) over the C++ facade
+(host/bhsparse.h, same public signatures as SpGEMM_cuda/bhsparse.h:17-33)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+DRV_DIR = os.path.join(ROOT, "tests", "driver")
+DRV = os.path.join(DRV_DIR, "spgemm")
+
+
+@pytest.fixture(scope="module")
+def driver(hiplib, oracle):
+    subprocess.check_call(["make", "-C", DRV_DIR, "-s"])
+    return DRV
+
+
+def test_facade_keeps_reference_signatures():
+    src = open(os.path.join(ROOT, "benchmark_spgemm_using_csr_amd", "host", "bhsparse.h")).read()
+    flat = re.sub(r"\s+", " ", src)
+    for sig in ("int initPlatform(bool *spgemm_platform);",
+                "int initData(int m, int k, int n, int nnzA, value_type *csrValA, index_type *csrRowPtrA, "
+                "index_type *csrColIndA, int nnzB, value_type *csrValB, index_type *csrRowPtrB, "
+                "index_type *csrColIndB, index_type *csrRowPtrC",
+                "int spgemm();", "int warmup();", "int get_nnzC();",
+                "int get_C(index_type *csrColIndC, value_type *csrValC);", "int freePlatform();", "int free_mem();"):
+        assert sig in flat, sig
+    assert "hip_runtime" not in src          # host code carries no HIP headers
+
+
+def test_driver_builds_and_fails_cleanly_without_gpu(driver):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    p = subprocess.run([driver, "-hip", "-spgemm", "0"], capture_output=True, text=True, timeout=60)
+    assert "Found an err, code = -2" in p.stdout      # BHS_ERR_NO_DEVICE, printed like main.cu:308-313
+    assert p.returncode == 1
+
+
+def _run(driver, *args):
+    p = subprocess.run([driver] + list(args), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", ["-hip", "-cuda", "-opencl"])
+def test_driver_small_test(driver, flag):
+    out = _run(driver, flag, "-spgemm", "0")
+    assert "nnzC = 6. PASS!" in out and "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out
+    assert "[ HIP ] SpGEMM time:" in out and "STAGE 4 time:" in out
+    assert '"nnzCt": 7' in out
+
+
+@pytest.mark.gpu
+def test_driver_cage4(driver):
+    mtx = os.path.join(GOLDEN, "cage4.mtx")
+    out = _run(driver, "-hip", "-spgemm", mtx, "-keepvalues")
+    assert "nnzC = 81. PASS!" in out and "ColIndC/csrValC PASS!" in out and '"nnzCt": 269' in out
+    out = _run(driver, "-hip", "-spgemm", mtx, mtx)        # two-file form, random 1..9 values
+    assert "ColIndC/csrValC PASS!" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ds,nnzct", [("1", None), ("2", None), ("3", None), ("4", (9 * 51 - 10) ** 3)])
+def test_driver_gallery_datasets(driver, ds, nnzct):
+    out = _run(driver, "-hip", "-spgemm", ds, "-cpu")
+    assert "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out and "CPU oracle" in out
+    if ds == "4":
+        assert '"nnzCt": %d' % nnzct in out and '"nnzC": %d' % ((5 * 51 - 6) ** 3) in out
+
+
+@pytest.mark.gpu
+def test_driver_symmetric_and_pattern_mtx(driver, tmp_path):
+    p = tmp_path / "sym.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n% c\n5 5 6\n1 1\n2 1\n3 2\n5 1\n4 4\n5 5\n")
+    out = _run(driver, "-hip", "-spgemm", str(p))
+    assert "A: ( 5 by 5, nnz = 9 )" in out and "ColIndC/csrValC PASS!" in out
