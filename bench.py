@@ -208,11 +208,19 @@ def main():
             ref = oracle.spgemm(nrows, m, m, bp, hBj[:nn], hBx[:nn], hBp, hBj, hBx)
             dt = time.perf_counter() - tA
             return ref, dt, oracle.nnzCt(bp, hBj[:nn], hBp)
-        probe = min(m, 1 << 15)
-        _, dtp, ctp = run_block(probe)           # calibration (also pages the oracle in)
-        rate = ctp / max(dtp, 1e-6)
+        probe = min(m, 1 << 16)
+        _, dtp, ctp = run_block(probe)           # calibration (also pages the oracle + OpenMP team in)
+        _, dtp, ctp = run_block(probe)
+        rate = ctp / max(dtp, 1e-6)              # products / s with all cores on a small block
         want = int(min(m, max(probe, args.cpu_seconds * rate / max(1.0, ctp / probe))))
         ref, dts, cts = run_block(want)
+        # single-thread figure on a bounded block (about cpu_seconds/5 of work)
+        one = int(min(want, max(1024, args.cpu_seconds / 5 * (rate / cores) / max(1.0, ctp / probe))))
+        bp1 = hBp[:one + 1]
+        t1 = time.perf_counter()
+        oracle.spgemm(one, m, m, bp1, hBj[:int(bp1[-1])], hBx[:int(bp1[-1])], hBp, hBj, hBx, nthreads=1)
+        dt1 = time.perf_counter() - t1
+        ct1 = oracle.nnzCt(bp1, hBj[:int(bp1[-1])], hBp)
         # parity of the GPU result on the same rows, in the same run
         got_rp = bh.get_rowptrC()[:want + 1]
         nn = int(got_rp[-1])
@@ -223,7 +231,9 @@ def main():
         cpu = {"value": round(2.0 * cts / dts / 1e9, 4), "unit": "GFLOP/s", "cores": cores, "kind": "port",
                "sample": "oracle (Gustavson+sort, OpenMP) on rows [0,%d) of A x full B: %d products in %.2f s"
                          % (want, cts, dts),
-               "gpu_matches_oracle_on_sample": bool(chk["ok"])}
+               "gpu_matches_oracle_on_sample": bool(chk["ok"]),
+               "value_1thread": round(2.0 * ct1 / dt1 / 1e9, 4),
+               "sample_1thread": "rows [0,%d): %d products in %.2f s" % (one, ct1, dt1)}
         if not chk["ok"]:
             cpu["mismatch"] = chk
 
