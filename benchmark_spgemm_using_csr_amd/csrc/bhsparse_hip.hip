@@ -124,6 +124,7 @@ struct bhs_handle {
     // options
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
+    int wgPerCU = 0;                     // tuning hook: persistent workgroups per CU (0 = occupancy API)
     int symLoadPct = 75, numLoadPct = 75; // max table load factor (percent) that decides a row's bin
     int maxTableLog2 = 15;
     // timing
@@ -246,7 +247,9 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
         BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WPB, smem));
         perCU = std::max(1, std::min(nb, 32 / WPB));
     }
-    long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * perCU);
+    if (h->verbose > 1) printf("  [%s TS=%d] occupancy API: %d workgroups/CU, smem %zu B\n", NUM ? "numeric" : "symbolic", TS, perCU, smem);
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);       // XCD-aware schedule needs a multiple of 8
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, h->dAj, h->dAx,
                        h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
@@ -803,6 +806,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
         return BHS_SUCCESS;
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
         if (value < 5 || value > 75) return BHS_ERR_INVALID_ARG;
         (key[0] == 's' ? h->symLoadPct : h->numLoadPct) = (int)value;
