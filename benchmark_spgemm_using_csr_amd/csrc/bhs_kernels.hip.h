@@ -30,17 +30,20 @@ namespace bhs {
 constexpr int kEmpty = -1;          // empty hash slot (column indices are >= 0)
 constexpr int kMaxBins = 16;
 
-struct BinSpec {                    // bin b holds rows with upper[b-1] < v <= upper[b]; bin 0: v == 0
-    int nbins;
-    int upper[kMaxBins];
+struct BinSpec {                    // bin b >= 2 holds rows with upper[b-1] < v <= upper[b]; bin 0: v == 0;
+    int nbins;                      // bin 1 ("quad" bin): 0 < v <= quadMax and at most kQuadMaxA entries in the A row
+    int quadMax;                    // 0 disables the quad bin
+    int upper[kMaxBins];            // upper[1] is 0: the size ladder starts at bin 2
 };
+constexpr int kQuadMaxA = 16;       // a 16-lane quarter wave holds one A entry per lane
 
-__device__ __forceinline__ int bin_of(const BinSpec& s, int v)
+__device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA)
 {
+    if (v > 0 && v <= s.quadMax && nA <= kQuadMaxA) return 1;
     int b = 0;
 #pragma unroll
     for (int i = 0; i < kMaxBins; ++i) b += (i < s.nbins - 1 && v > s.upper[i]) ? 1 : 0;
-    return b;
+    return (b == 1) ? 2 : b;        // 0 < v <= upper[2] that did not qualify for the quad bin
 }
 
 __device__ __forceinline__ unsigned hash_col(int col, int log2ts)
@@ -81,9 +84,11 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
          rbase += (long long)gridDim.x * rows_per_block) {
         const int row = (int)rbase + tid / G;
         long long s = 0;
+        int nA = 0;
         if (row < m) {
-            const int a1 = Ap[row + 1];
-            for (int j = Ap[row] + g; j < a1; j += G) {
+            const int a0 = Ap[row], a1 = Ap[row + 1];
+            nA = a1 - a0;
+            for (int j = a0 + g; j < a1; j += G) {
                 const int c = Aj[j];
                 int2 be;                                     // rowPtrB[c], rowPtrB[c+1] in one 8-byte gather
                 __builtin_memcpy(&be, Bp + c, sizeof(be));
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
             const int v = s > 0x7fffffffLL ? 0x7fffffff : (int)s;
             ub[row] = v;
             if (v == 0) cnt[row] = 0;          // ESC_0 (bhsparse_cuda.h:1582-1595): nothing else to do
-            atomicAdd(&hist[bin_of(spec, v)], 1);
+            atomicAdd(&hist[bin_of(spec, v, nA)], 1);
             atomicAdd(&bsum, (unsigned long long)s);
         }
     }
@@ -140,9 +145,9 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
             int b = 0, pos = 0, a0 = 0, a1 = 0, outBase = 0, v = 0, ubv = 0;
             if (row < m) {
                 if (FROM_ROWPTR) { outBase = key[row]; v = key[row + 1] - outBase; } else v = key[row];
-                b = bin_of(spec, v);
                 a0 = Ap[row];
                 a1 = Ap[row + 1];
+                b = bin_of(spec, v, a1 - a0);
                 ubv = ub[row];
             }
             // all 64 lanes take part (rows past m carry b == 0 and never match a leader's bin)
@@ -196,6 +201,7 @@ constexpr int kScanItems = 16;                  // per thread
 constexpr int kScanTile = 256 * kScanItems;     // per block
 
 __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restrict__ cnt,
+                                                     const int* __restrict__ Ap,
                                                      long long* __restrict__ blockSum,
                                                      int* __restrict__ binCount, BinSpec spec)
 {
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restric
         if (idx < m) {
             const int v = cnt[idx];
             s += v;
-            const int b = bin_of(spec, v);
+            const int b = bin_of(spec, v, Ap[idx + 1] - Ap[idx]);
             if (b > 0) atomicAdd(&hist[b], 1);
         }
     }
@@ -585,11 +591,13 @@ __device__ __forceinline__ T lane_xor_any(T x, int lj, int lane)
 // wave-wide bitonic sort of 64*E keys (u32 or u64), ascending; element index
 // i = lane*E + e, so each lane ends with E consecutive sorted keys.  Cross-lane
 // exchanges are DPP / permlane-swap moves (bhs_wave.hip.h): no LDS round trips.
-template <typename T, int E>
+template <typename T, int E, int GW = 64>
 __device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
 {
+    // GW = lanes per independent sort (64: whole wave; 16: four quarter-wave sorts side by side, DPP only)
+    lane &= GW - 1;
 #pragma unroll
-    for (int k = 2; k <= 64 * E; k <<= 1) {
+    for (int k = 2; k <= GW * E; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j >= E) {
@@ -882,6 +890,199 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         avC = av1; av1 = av2;
         c1 = c2;
         b0C = b01; lenC = len1;
+    }
+}
+
+// ===========================================================================
+// Quarter-wave accumulator for tiny rows (the reference's ESC_2heap territory,
+// bhsparse_cuda.h:653-722: poisson5pt rows have 25 products -> 13 entries).
+// FOUR rows per wavefront, 16 lanes each: a DPP "row" is 16 lanes, so the
+// segmented scan of the B row lengths, the count reduction and the bitonic sort
+// (64 keys per row = 4 per lane, strides <= 8 lanes) never leave the VALU.
+// Each quarter owns a 64-slot LDS table; product -> A entry mapping is a 64-bit
+// mark word per quarter.  Rows qualify with <= 16 A entries and <= 48 products
+// (symbolic) / <= 48 entries (numeric); products beyond 64 are walked in windows.
+// ===========================================================================
+template <bool NUM, bool PACK32>
+struct QuadSmem {
+    using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
+    int keys[4][64];
+    double vals[NUM ? 4 : 1][NUM ? 64 : 1];
+    packed_t packed[NUM ? 4 : 1][NUM ? 64 : 2];
+    double sAv[NUM ? 4 : 1][NUM ? 16 : 1];
+    int sBase[4][16];
+    unsigned long long marks[4];
+};
+
+template <bool NUM, bool PACK32>
+__global__ __launch_bounds__(64) void k_row_quad(
+    const int4* __restrict__ desc, int qn,
+    const int* __restrict__ Aj, const double* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx)
+{
+    using Smem = QuadSmem<NUM, PACK32>;
+    using packed_t = typename Smem::packed_t;
+    __shared__ Smem sm;
+    constexpr int LOG2TS = 6, TS = 64;
+    const int lane = threadIdx.x, g = lane >> 4, l16 = lane & 15;
+
+    // XCD-aware persistent schedule over groups of 4 queue entries
+    const int nGroups = (qn + 3) >> 2;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, perX = gridDim.x >> 3;
+    const int region = (nGroups + 7) >> 3;
+    const int gBeg = xcd * region;
+    const int gEnd = gBeg + region < nGroups ? gBeg + region : nGroups;
+
+    int4 dNext = make_int4(-1, 0, 0, 0);
+    if (gBeg + lb < gEnd && (gBeg + lb) * 4 + g < qn) dNext = desc[(gBeg + lb) * 4 + g];
+    for (int grp = gBeg + lb; grp < gEnd; grp += perX) {
+        const int4 d = dNext;                                  // this quarter's row (row < 0: idle quarter)
+        dNext = make_int4(-1, 0, 0, 0);
+        if (grp + perX < gEnd && (grp + perX) * 4 + g < qn) dNext = desc[(grp + perX) * 4 + g];
+        const int nA = d.x >= 0 ? d.z - d.y : 0;
+        // ---- one A entry per lane of the quarter
+        int b0 = 0, len = 0;
+        double av = 0.0;
+        if (l16 < nA) {
+            const int c = Aj[d.y + l16];
+            if (NUM) av = Ax[d.y + l16];
+            int2 be;
+            __builtin_memcpy(&be, Bp + c, sizeof(be));
+            b0 = be.x;
+            len = be.y - be.x;
+        }
+        // ---- clear the four tables (64 lanes x 4 slots = 256 slots)
+        *reinterpret_cast<int4*>(&sm.keys[0][lane * 4]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
+        if (NUM) {
+            *reinterpret_cast<double2*>(&sm.vals[0][lane * 4]) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2*>(&sm.vals[0][lane * 4 + 2]) = make_double2(0.0, 0.0);
+        }
+        // segmented inclusive scan inside each 16-lane DPP row
+        unsigned sc = (unsigned)len;
+        sc += dpp_u32<0x111, 0xf, 0xf, true>(0, sc);
+        sc += dpp_u32<0x112, 0xf, 0xf, true>(0, sc);
+        sc += dpp_u32<0x114, 0xf, 0xf, true>(0, sc);
+        sc += dpp_u32<0x118, 0xf, 0xf, true>(0, sc);
+        const int incl = (int)sc;
+        const int total = __shfl(incl, (lane & 48) | 15, 64);   // products of this quarter's row
+        int maxTotal = __builtin_amdgcn_readlane(incl, 15);
+        maxTotal = max(maxTotal, __builtin_amdgcn_readlane(incl, 31));
+        maxTotal = max(maxTotal, __builtin_amdgcn_readlane(incl, 47));
+        maxTotal = max(maxTotal, __builtin_amdgcn_readlane(incl, 63));
+        const int last = incl - 1;
+        const unsigned long long nz = __ballot(len > 0);
+        const unsigned gmaskNz = (unsigned)(nz >> (g * 16)) & 0xffffu;
+        const int jc = __popc(gmaskNz & ((1u << l16) - 1u));     // compacted index among the quarter's non-empty entries
+        wave_sync();
+        if (len > 0) {
+            sm.sBase[g][jc] = b0 - (incl - len);
+            if (NUM) sm.sAv[g][jc] = av;
+        }
+        int myNew = 0;
+        int done = 0;
+        for (int w0 = 0; w0 < maxTotal; w0 += 64) {
+            if (l16 == 0) sm.marks[g] = 0ull;
+            wave_sync();
+            const int rel = last - w0;
+            if (len > 0 && rel >= 0 && rel < 64) atomicOr(&sm.marks[g], 1ull << rel);
+            wave_sync();
+            const unsigned long long mk = sm.marks[g];
+            int col[4];
+            double pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                col[u] = kEmpty;
+                pv[u] = 0.0;
+                const int pr = u * 16 + l16;                        // product index inside the window
+                const int p = w0 + pr;
+                if (p < total) {
+                    const int j = done + __popcll(mk & ((1ull << pr) - 1ull));
+                    const long long idx = (long long)sm.sBase[g][j] + p;
+                    col[u] = Bj[idx];
+                    if (NUM) pv[u] = sm.sAv[g][j] * Bx[idx];
+                }
+            }
+            done += __popcll(mk);
+            unsigned hh[4];
+            int cur[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                hh[u] = hash_col(col[u], LOG2TS);
+                cur[u] = kEmpty;
+                if (col[u] != kEmpty) cur[u] = atomicCAS(&sm.keys[g][hh[u]], kEmpty, col[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cv = col[u];
+                if (cv != kEmpty) {
+                    bool ok = cur[u] == cv;
+                    if (cur[u] == kEmpty) { ++myNew; ok = true; }
+                    if (!ok) {
+                        unsigned h = hh[u];
+                        for (;;) {
+                            h = (h + 1) & (TS - 1);
+                            const int c2 = atomicCAS(&sm.keys[g][h], kEmpty, cv);
+                            if (c2 == kEmpty) { ++myNew; break; }
+                            if (c2 == cv) break;
+                        }
+                        hh[u] = h;
+                    }
+                    if (NUM) unsafeAtomicAdd(&sm.vals[g][hh[u]], pv[u]);
+                }
+            }
+        }
+        wave_sync();
+        if (!NUM) {
+            // per-quarter sum of myNew: DPP row reduction, lane 15 of the row holds it
+            unsigned r = (unsigned)myNew;
+            r += dpp_u32<0x111, 0xf, 0xf, true>(0, r);
+            r += dpp_u32<0x112, 0xf, 0xf, true>(0, r);
+            r += dpp_u32<0x114, 0xf, 0xf, true>(0, r);
+            r += dpp_u32<0x118, 0xf, 0xf, true>(0, r);
+            if (l16 == 15 && d.x >= 0) cntOut[d.x] = (int)r;
+        } else {
+            // ---- compact each quarter's 64 slots, 16 at a time
+            int run = 0;
+#pragma unroll
+            for (int s0 = 0; s0 < 64; s0 += 16) {
+                const int s = s0 + l16;
+                const int key = sm.keys[g][s];
+                const bool valid = key != kEmpty;
+                const unsigned long long bal = __ballot(valid);
+                const unsigned gm = (unsigned)(bal >> (g * 16)) & 0xffffu;
+                if (valid) {
+                    packed_t pk;
+                    if constexpr (PACK32) pk = ((unsigned)key << LOG2TS) | (unsigned)s;
+                    else pk = ((unsigned long long)(unsigned)key << 32) | (unsigned)s;
+                    sm.packed[g][run + __popc(gm & ((1u << l16) - 1u))] = pk;
+                }
+                run += __popc(gm);
+            }
+            const int uniq = run;
+            wave_sync();
+            packed_t x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = l16 * 4 + e;
+                x[e] = i < uniq ? sm.packed[g][i] : (packed_t)~(packed_t)0;
+            }
+            wave_bitonic_sort<packed_t, 4, 16>(x, lane);
+            const long long outBase = d.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = l16 * 4 + e;
+                if (r < uniq) {
+                    int c;
+                    unsigned slot;
+                    if constexpr (PACK32) { c = (int)(x[e] >> LOG2TS); slot = x[e] & 63u; }
+                    else { c = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
+                    Cj[outBase + r] = c;
+                    Cx[outBase + r] = sm.vals[g][slot];
+                }
+            }
+        }
+        wave_sync();
     }
 }
 

@@ -57,26 +57,30 @@ struct KernelCfg {
     int block;      // lanes per row
     bool win;       // column-window variant
 };
-constexpr int kNumSymBins = 11;     // bin 0 = empty rows (no kernel)
+// bin 0 = empty rows (no kernel); bin 1 = quad bin (block 16: four rows per wavefront, k_row_quad)
+constexpr int kNumSymBins = 12;
 const KernelCfg kSymCfg[kNumSymBins] = {
-    {0, 0, false},   {6, 64, false},  {7, 64, false},   {8, 64, false},   {9, 64, false},  {10, 64, false},
-    {11, 64, false}, {12, 64, false}, {13, 256, false}, {15, 1024, false}, {15, 1024, true}};
-constexpr int kNumNumBins = 9;
+    {0, 0, false},   {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},   {9, 64, false},
+    {10, 64, false}, {11, 64, false}, {12, 64, false}, {13, 256, false}, {15, 1024, false}, {15, 1024, true}};
+constexpr int kNumNumBins = 10;
 const KernelCfg kNumCfg[kNumNumBins] = {
-    {0, 0, false},   {6, 64, false},  {7, 64, false},   {8, 64, false},  {9, 64, false},
-    {10, 64, false}, {11, 64, false}, {12, 256, false}, {12, 256, true}};
+    {0, 0, false},  {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},
+    {9, 64, false}, {10, 64, false}, {11, 64, false}, {12, 256, false}, {12, 256, true}};
+constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a 64-slot quarter table admits
 
-BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct)
+BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad)
 {
     BinSpec s;
     memset(&s, 0, sizeof(s));
     s.nbins = nbins;
+    s.quadMax = (quad && maxLog2 >= 6) ? kQuadMax : 0;
     s.upper[0] = 0;
-    for (int b = 1; b < nbins; ++b) {
+    s.upper[1] = 0;
+    for (int b = 2; b < nbins; ++b) {
         int lg = std::min(cfg[b].log2ts, maxLog2);
         int ts = 1 << lg;
         s.upper[b] = cfg[b].win ? 0x7fffffff : (int)((long long)ts * loadPct / 100);
-        if (b > 1 && s.upper[b] < s.upper[b - 1]) s.upper[b] = s.upper[b - 1];
+        if (b > 2 && s.upper[b] < s.upper[b - 1]) s.upper[b] = s.upper[b - 1];
     }
     s.upper[nbins - 1] = 0x7fffffff;
     return s;
@@ -270,9 +274,40 @@ int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     }
 }
 
+template <bool NUM, bool PACK32>
+int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    auto kern = k_row_quad<NUM, PACK32>;
+    static int perCU = 0;
+    if (!perCU) {
+        int nb = 0;
+        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, 0));
+        perCU = std::max(1, std::min(nb, 32));
+    }
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->stream, queue, qn, h->dAj, h->dAx, h->dBp, h->dBj,
+                       h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <bool NUM>
+int launch_row_quad(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    if constexpr (NUM) {
+        if ((long long)h->n <= (1LL << 26) && !h->noPack32) return launch_row_quad_impl<true, true>(h, queue, qn, CpOrCnt);
+        return launch_row_quad_impl<true, false>(h, queue, qn, CpOrCnt);
+    } else {
+        return launch_row_quad_impl<false, false>(h, queue, qn, CpOrCnt);
+    }
+}
+
 template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
 {
+    if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_CASE(LG, BL, W) \
@@ -309,11 +344,11 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
 #undef BHS_CASE
 }
 
-const char* kSymNames[kNumSymBins] = {"", "symbolic_wave<64>", "symbolic_wave<128>", "symbolic_wave<256>",
+const char* kSymNames[kNumSymBins] = {"", "symbolic_quad<64>", "symbolic_wave<64>", "symbolic_wave<128>", "symbolic_wave<256>",
                                       "symbolic_wave<512>", "symbolic_wave<1024>", "symbolic_wave<2048>",
                                       "symbolic_wave<4096>", "symbolic_wg<8192>", "symbolic_wg<32768>",
                                       "symbolic_wg_window<32768>"};
-const char* kNumNames[kNumNumBins] = {"", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
+const char* kNumNames[kNumNumBins] = {"", "numeric_quad<64>", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
                                       "numeric_wave<512>", "numeric_wave<1024>", "numeric_wave<2048>",
                                       "numeric_wg<4096>", "numeric_wg_window<4096>"};
 
@@ -372,8 +407,8 @@ int run_pipeline(bhs_handle* h)
     BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
 
     // ------------------------------------------------------------ stage 1
-    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct);
-    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12), h->numLoadPct);
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0);
+    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12), h->numLoadPct, h->forcePath == 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
@@ -423,7 +458,7 @@ int run_pipeline(bhs_handle* h)
 
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p,
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
                        (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
                        (long long*)h->blockSum.p, (long long*)(small + S_TOTAL_C));

@@ -42,12 +42,12 @@ void run(const char* d, size_t window, const char* name, int contiguous) {
   constexpr int ELEM = (BYTES == 4) ? 4 : 8; constexpr int EPL = BYTES / ELEM; constexpr int LPR = (RUN + EPL - 1) / EPL; constexpr int RPI = 64 / LPR;
   double bytes = (double)grid * iters * 8 * RPI * RUN * ELEM;
   double instr = (double)grid * iters * 8;
-  printf("%-44s window %5zu MB: %8.1f GB/s useful, %6.1f cycles/instr/CU (2.1GHz), %.2f ms\n", name, window >> 20, bytes / ms / 1e6,
+  printf("%-44s window %8zu KB: %8.1f GB/s useful, %6.1f cycles/instr/CU (2.1GHz), %.2f ms\n", name, window >> 10, bytes / ms / 1e6,
          ms * 1e-3 * 2.1e9 / (instr / 256), ms);
 }
 int main() {
   size_t big = 1ull << 30; char* d; hipMalloc(&d, big); hipMemset(d, 0, big);
-  for (size_t w : {(size_t)16 << 20, (size_t)1 << 30}) {
+  for (size_t w : {(size_t)16 << 10, (size_t)16 << 20, (size_t)1 << 30}) {
     run<8, 27>(d, w, "8B/lane, runs of 27 doubles (current vals)", 0);
     run<16, 27>(d, w, "16B/lane, runs of 27 doubles", 0);
     run<4, 27>(d, w, "4B/lane, runs of 27 ints (current cols)", 0);
