@@ -140,6 +140,44 @@ def test_bin_edges(oracle, ub):
     _check(oracle, 4, k, n, (Ap, Aj, Ax), (Bp.astype(np.int32), Bj, Bx))
 
 
+@pytest.mark.parametrize("nA,lenB,dup", [(1, 1, 0), (5, 5, 1), (16, 3, 1), (17, 2, 1), (16, 4, 0), (12, 4, 0), (13, 4, 0),
+                                         (3, 40, 1), (2, 33, 0), (16, 9, 1)])
+def test_quarter_wave_rows(oracle, nA, lenB, dup):
+    """Rows around the limits of the four-rows-per-wavefront kernel (<= 16 A entries, <= 48 products
+    symbolic / <= 48 entries numeric, windows of 64 products): many such rows so that full and
+    partially filled quartets both occur."""
+    rng = np.random.default_rng(nA * 100 + lenB)
+    k, n, m = 400, 5000, 203
+    Bp = np.arange(k + 1, dtype=np.int64) * lenB
+    Bj = np.empty(k * lenB, np.int32)
+    for j in range(k):
+        lo = (j // 2 if dup else j) * 3 % (n - 4 * lenB)         # dup: neighbouring B rows overlap
+        Bj[j * lenB:(j + 1) * lenB] = lo + np.sort(rng.choice(2 * lenB, lenB, replace=False))
+    Bx = rng.integers(1, 10, k * lenB).astype(np.float64)
+    lens = np.full(m, nA)
+    lens[::7] = 0                                                # empty rows in between
+    lens[3::11] = max(1, nA - 1)
+    Ap = np.zeros(m + 1, np.int64)
+    np.cumsum(lens, out=Ap[1:])
+    Aj = np.concatenate([np.sort(rng.choice(k, L, replace=False)) for L in lens] + [np.empty(0, np.int64)]).astype(np.int32)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    _check(oracle, m, k, n, (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx))
+    _check(oracle, m, k, n, (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx), options={"no_pack32": 1})
+
+
+def test_sort_key_width_paths(oracle):
+    """32-bit packed sort keys vs the 64-bit fallback must agree (wave and quarter-wave kernels)."""
+    m, rp, col, val = poisson_case("poisson27pt", 14, 14, 14)
+    A = (rp, col, val)
+    a = _check(oracle, m, m, m, A, A)
+    b = _check(oracle, m, m, m, A, A, options={"no_pack32": 1})
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    m, rp, col, val = poisson_case("poisson5pt", 40, 40)
+    A = (rp, col, val)
+    _check(oracle, m, m, m, A, A, options={"no_pack32": 1})
+    _check(oracle, m, m, m, A, A, options={"force_path": 1})     # quad bin off: same rows through the wave kernel
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_random_rectangular(oracle, seed):
     rng = np.random.default_rng(100 + seed)
