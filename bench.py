@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (compute-only)")
+    ap.add_argument("--no-extra", action="store_true", help="N=1: skip the short runs of the other BASELINE configs")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,7 +66,9 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_GATHER=1: run the RCCL all-gatherv path even with one rank (self-test of the N > 1 code)
+    force_gather = os.environ.get("BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -103,7 +106,7 @@ def main():
         e = bh.spgemm()
         if e != 0:
             raise RuntimeError("spgemm: " + facade._lib.strerror(e))
-        if world > 1 and not args.no_gather:
+        if (world > 1 or force_gather) and not args.no_gather:
             pr, pc, pv = bh.get_C_device()
             nnz = bh.nnzC
             lr = bdist.device_view(pr, r1 - r0 + 1, torch.int32, dev)
@@ -115,7 +118,7 @@ def main():
         return None
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,6 +160,11 @@ def main():
         rp, cc, vv = full
         assert int(rp[-1].item()) == nnzC_total and int(rp[0].item()) == 0
         assert bool((rp[1:] >= rp[:-1]).all())
+        if world == 1:      # forced self-test: the gathered copy must equal the local result bit for bit
+            pr, pc, pv = bh.get_C_device()
+            assert torch.equal(rp, bdist.device_view(pr, m + 1, torch.int32, dev))
+            assert torch.equal(cc, bdist.device_view(pc, bh.nnzC, torch.int32, dev))
+            assert torch.equal(vv, bdist.device_view(pv, bh.nnzC, torch.float64, dev))
 
     if rank != 0:
         if world > 1:
@@ -237,6 +245,35 @@ def main():
         if not chk["ok"]:
             cpu["mismatch"] = chk
 
+    # ---- the other single-GPU configurations of BASELINE.json, short runs, reported beside the headline
+    extra = None
+    if world == 1 and not args.no_extra and args.workload == "p27_weak":
+        extra = {}
+        bh.free_mem()
+        del Ap, Aj, Ax, Bp, Bj, Bx
+        torch.cuda.empty_cache()
+        for wname in ("p5_1024", "p27_160"):
+            st2, d2, _ = workload_dims(wname, 1)
+            bp2, bj2 = gallery.poisson_csr_torch(st2, *d2, device=dev)
+            bx2 = gallery.fill_values_torch(int(bj2.numel()), device=dev)
+            ap2, aj2, ax2 = bp2.clone(), bj2.clone(), bx2.clone()
+            m2 = int(bp2.numel()) - 1
+            assert bh.initData_device(m2, m2, m2, int(aj2.numel()), ax2, ap2, aj2, int(bj2.numel()), bx2, bp2, bj2) == 0
+            for _ in range(3):
+                assert bh.spgemm() == 0
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(10):
+                assert bh.spgemm() == 0
+            msq = (time.perf_counter() - tq) / 10 * 1e3
+            balg = 2 * (4 * (m2 + 1) + 12 * int(bj2.numel())) + 4 * (m2 + 1) + 12 * bh.nnzC
+            extra[wname] = {"workload": "%s %s C=A^2" % (st2, "x".join(map(str, d2))), "ms_per_step": round(msq, 4),
+                            "gflops": round(2.0 * bh.nnzCt / (msq * 1e6), 2), "nnzCt": bh.nnzCt, "nnzC": bh.nnzC,
+                            "pipeline_frac_of_hbm_peak": round(balg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            bh.free_mem()
+            del bp2, bj2, bx2, ap2, aj2, ax2
+            torch.cuda.empty_cache()
+
     out = {
         "metric": "spgemm_gflops (2*nnz_intermediate/t, C=A^2, fp64 CSR)",
         "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -245,7 +282,7 @@ def main():
         "config": {"workload": "%s %s C=A^2 (%s)" % (stencil, "x".join(map(str, dims)), args.workload),
                    "m": m, "nnzA_total": nnzB, "nnzCt": nnzCt_total, "nnzC": nnzC_total,
                    "parallelism": "rowblock%d+allgatherv" % world if world > 1 else "single",
-                   "values": "1+lcg%9 seed 20140519", "gather_in_step": bool(world > 1 and not args.no_gather)},
+                   "values": "1+lcg%9 seed 20140519", "gather_in_step": bool((world > 1 or force_gather) and not args.no_gather)},
         "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
         "stage_ms": [round(float(x) / args.steps, 4) for x in stage],
@@ -253,10 +290,10 @@ def main():
         "pipeline_compulsory_bytes": int(bytes_alg_total),
         "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
         "kernels_ms_per_step": {k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items())},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "additional_configs": extra,
     }
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

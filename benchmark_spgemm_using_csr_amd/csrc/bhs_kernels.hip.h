@@ -6,10 +6,10 @@
 // Reference functions these kernels replace (SpGEMM_cuda/bhsparse_cuda.h):
 //   k_upper_bound      <- compute_nnzCt_cudakernel            :210-237
 //   k_fill_queues      <- bhsparse::statistics (host)         bhsparse.h:365-481
-//   k_row_hash<..,0>   <- (symbolic) no counterpart: the reference sizes Ct by
+//   k_row_*<..,NUM=0>  <- (symbolic) no counterpart: the reference sizes Ct by
 //                         upper bound and compacts later (create_Ct :285-301,
 //                         copyCt2C_* :2813-2911); here an exact count replaces both
-//   k_row_hash<..,1>   <- ESC_0/ESC_1 :1582-1640, ESC_2heap_noncoalesced :653-722,
+//   k_row_*<..,NUM=1>  <- ESC_0/ESC_1 :1582-1640, ESC_2heap_noncoalesced :653-722,
 //                         ESC_bitonic_scan :1400-1518, EM_mergepath :1902-2157,
 //                         EM_mergepath_global :2270-2525 (all numeric families)
 //   k_scan_*           <- create_C's host exclusive scan      :2783-2811
@@ -300,197 +300,212 @@ __global__ __launch_bounds__(256) void k_check_sorted(int k, const int* __restri
 }
 
 // ---------------------------------------------------------------------------
-// The accumulator kernel.  One thread group of BLOCK lanes per row of C
-// (BLOCK = 64: one wavefront per row, the workhorse; BLOCK >= 256: one
-// workgroup per long row).  Per row:
-//   1. clear an LDS open-addressing table of TS slots (keys int32 [+ fp64 vals])
-//   2. expand the products: sub-groups of L = 2^logL lanes walk one B row each
-//      (coalesced colIndB/valB segments), insert by multiplicative hash +
-//      linear probing; a plain ds_read first (duplicates dominate: 83% of the
-//      products on poisson27pt), ds_cmpst only on an empty slot, ds_add_f64 to
-//      accumulate
-//   3a. SYMBOLIC (NUM=0): wave-reduce the number of successful inserts -> cnt[row]
-//   3b. NUMERIC (NUM=1): compact the occupied slots as packed (col<<32 | slot)
-//      into LDS, bitonic-sort them there, and stream the row out once, in final
-//      CSR position, ascending by column
-// WIN=1 (only with BLOCK >= 256) adds the column-window loop for rows whose
-// accumulator does not fit the table: the row is produced in successive column
-// ranges [lo,hi), each range small enough for the table; an overflowing range
-// is halved and retried (replaces the reference's progressive re-allocation
-// rounds, bhsparse_cuda.h:2527-2780).  Windows come out in ascending column
-// order, so the concatenation is sorted.
+// Workgroup-per-row accumulator for long rows (the reference's EM_mergepath /
+// EM_mergepath_global territory, bhsparse_cuda.h:1902-2525, and its progressive
+// re-allocation rounds :2527-2780).  One workgroup of BLOCK lanes per row:
+//   * A entries are taken BLOCK at a time, one per lane; a block-wide scan of
+//     the B row lengths gives a flat product index space, and every lane finds
+//     the A entry of its product by binary search in the LDS prefix array
+//     (U products per lane in flight);
+//   * LDS open-addressing table of TS slots, first probe = ds_cmpst_rtn;
+//     new keys are counted per wave (ballot) so the fill level is known after
+//     every batch;
+//   * COLUMN WINDOWS: a row whose accumulator does not fit the table is produced
+//     in successive column ranges [lo,hi).  With column-sorted B rows each lane
+//     restricts its B row to the range by two binary searches; an overflowing
+//     range is halved and retried, a sparse one doubles the next.  Ranges come
+//     out in ascending column order, so the concatenation is the sorted row;
+//   * numeric: the table is sorted IN PLACE (keys with their values, empty
+//     slots = 0xffffffff sort last) by a bitonic network in LDS and the first
+//     `uniq` slots are streamed to C — no second copy of the table, which lets
+//     an 8192-slot fp64 table fit the 160 KiB LDS.
 // ---------------------------------------------------------------------------
-template <int BLOCK>
-__device__ __forceinline__ void group_sync()
-{
-    __syncthreads();   // BLOCK == 64: one wave per workgroup, lowers to a waitcnt (no s_barrier)
-}
-
 template <int TS, int BLOCK, bool NUM>
-struct RowHashSmem {
+struct BlockSmem {
     int keys[TS];
     double vals[NUM ? TS : 1];
-    unsigned long long sorted[NUM ? TS : 1];
-    int counter[4];      // [0] unique count, [1] overflow flag, [2] compaction cursor
+    double sAv[NUM ? BLOCK : 1];
+    int sIncl[BLOCK];
+    int sBase[BLOCK];
+    int wtot[BLOCK / 64];
+    int counter[4];      // [0] unique keys in the table, [1] overflow flag
 };
 
-template <int TS, int LOG2TS, int BLOCK, bool NUM, bool WIN>
-__global__ __launch_bounds__(BLOCK) void k_row_hash(
-    const int4* __restrict__ queue, int qn, int ncolsB, int logL, int bSorted,
-    const int* __restrict__ Ap, const int* __restrict__ Aj, const double* __restrict__ Ax,
+template <int TS, int LOG2TS, int BLOCK, bool NUM>
+__global__ __launch_bounds__(BLOCK) void k_row_block(
+    const int4* __restrict__ desc, int qn, int ncolsB, int bSorted,
+    const int* __restrict__ Aj, const double* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
-    const int* __restrict__ ubArr,          // symbolic + WIN: per-row upper bound (first window guess)
+    const int* __restrict__ ubArr,          // symbolic: per-row upper bound (first window guess)
     int* __restrict__ CpOrCnt, int* __restrict__ Cj, double* __restrict__ Cx,
-    int* __restrict__ errFlag)
+    int* __restrict__ errFlag, int* __restrict__ ticket)
 {
     static_assert((1 << LOG2TS) == TS, "table size must be 2^LOG2TS");
-    static_assert(!WIN || BLOCK > 64, "column windows are a workgroup-per-row feature");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    RowHashSmem<TS, BLOCK, NUM>& sm = *reinterpret_cast<RowHashSmem<TS, BLOCK, NUM>*>(smem_raw);
+    using Smem = BlockSmem<TS, BLOCK, NUM>;
+    Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
     constexpr int CAP = TS - TS / 4;      // max unique keys admitted per table fill
+    constexpr int U = 4;                  // products per lane per batch
+    constexpr int NW = BLOCK / 64;
 
-    const int tid = threadIdx.x;
-    const int L = 1 << logL;
-    const int sub = tid >> logL, t = tid & (L - 1), nsub = BLOCK >> logL;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    for (int q = blockIdx.x; q < qn; q += gridDim.x) {
-        const int row = queue[q].x;
-        const int a0 = Ap[row], a1 = Ap[row + 1];
-        long long outBase = 0;
-        if (NUM) outBase = CpOrCnt[row];
+    // rows differ in cost by orders of magnitude: workgroups pull the next row from a device ticket
+    for (;;) {
+        if (tid == 0) sm.counter[2] = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int q = sm.counter[2];
+        __syncthreads();
+        if (q >= qn) break;
+        const int4 d = desc[q];
+        const int row = d.x, a0 = d.y, a1 = d.z;
+        long long outBase = d.w;
         int rowTotal = 0;                 // symbolic: unique count over all windows
-
-        // column window [lo, hi); without WIN a single window covers everything
-        long long lo = 0, width = 0x7fffffffLL;
-        if (WIN) {
-            // first guess: split the column range uniformly by the expected load
-            const long long need = NUM ? (long long)(CpOrCnt[row + 1] - CpOrCnt[row]) : (long long)ubArr[row];
+        const long long need = NUM ? (long long)(CpOrCnt[row + 1] - CpOrCnt[row]) : (long long)ubArr[row];
+        long long lo = 0, width = ncolsB;
+        if (need > CAP) {                 // first guess: split the column range uniformly by the expected load
             const long long nwin = (need + CAP / 2 - 1) / (CAP / 2);
-            width = ncolsB / (nwin > 0 ? nwin : 1);
+            width = ncolsB / nwin;
             if (width < 1) width = 1;
         }
-        for (;;) {
-            if (WIN && lo >= ncolsB) break;
-            const long long hi = WIN ? (lo + width < ncolsB ? lo + width : (long long)ncolsB) : 0x7fffffffLL;
-            // ---- 1. clear
+        while (lo < ncolsB) {
+            const long long hi = lo + width < ncolsB ? lo + width : (long long)ncolsB;
+            const bool full = (lo == 0 && hi >= ncolsB);
+            // ---- clear
             for (int s = tid; s < TS; s += BLOCK) {
                 sm.keys[s] = kEmpty;
                 if (NUM) sm.vals[s] = 0.0;
             }
-            if (tid < 4) sm.counter[tid] = 0;
-            group_sync<BLOCK>();
+            if (tid < 2) sm.counter[tid] = 0;
+            __syncthreads();
 
-            // ---- 2. expand + insert
-            int myNew = 0;
-            for (int ja = a0 + sub; ja < a1; ja += nsub) {
-                if (WIN && __atomic_load_n(&sm.counter[1], __ATOMIC_RELAXED)) break;
-                const int c = Aj[ja];
-                int b0 = Bp[c];
-                const int b1 = Bp[c + 1];
+            for (int ca = a0; ca < a1; ca += BLOCK) {
+                if (sm.counter[1]) break;                       // uniform: read after a barrier
+                // ---- one A entry per lane, restricted to the column window
+                const int e = ca + tid;
+                int b0 = 0, len = 0;
                 double av = 0.0;
-                if (NUM) av = Ax[ja];
-                if (WIN && bSorted && lo > 0) {              // lower_bound(lo) in the sorted B row
-                    int l = b0, r = b1;
-                    while (l < r) { const int mid = (l + r) >> 1; if (Bj[mid] < (int)lo) l = mid + 1; else r = mid; }
-                    b0 = l;
-                }
-                for (int jb = b0 + t; jb < b1; jb += L) {
-                    const int col = Bj[jb];
-                    if (WIN) {
-                        if (col >= hi) { if (bSorted) break; else continue; }
-                        if (col < lo) continue;
+                if (e < a1) {
+                    const int c = Aj[e];
+                    if (NUM) av = Ax[e];
+                    int2 be;
+                    __builtin_memcpy(&be, Bp + c, sizeof(be));
+                    b0 = be.x;
+                    int b1 = be.y;
+                    if (!full && bSorted) {
+                        int l = b0, r = b1;                      // lower_bound(lo)
+                        while (l < r) { const int mid = (l + r) >> 1; if (Bj[mid] < (int)lo) l = mid + 1; else r = mid; }
+                        b0 = l;
+                        r = b1;                                  // lower_bound(hi)
+                        while (l < r) { const int mid = (l + r) >> 1; if ((long long)Bj[mid] < hi) l = mid + 1; else r = mid; }
+                        b1 = l;
                     }
-                    unsigned h = hash_col(col, LOG2TS);
-                    bool overflow = false;
-                    int probes = 0;
-                    for (;;) {
-                        int cur = __atomic_load_n(&sm.keys[h], __ATOMIC_RELAXED);
-                        if (cur == kEmpty) {
-                            cur = atomicCAS(&sm.keys[h], kEmpty, col);
-                            if (cur == kEmpty) {
-                                ++myNew;
-                                if (WIN) {
-                                    const int u = atomicAdd(&sm.counter[0], 1);
-                                    if (u + 1 > CAP) { atomicOr(&sm.counter[1], 1); overflow = true; }
-                                }
-                                break;
+                    len = b1 - b0;
+                }
+                // ---- block-wide inclusive scan of len
+                int incl = wave_incl_scan_dpp(len);
+                if (lane == 63) sm.wtot[wv] = incl;
+                __syncthreads();
+                int woff = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const int t = sm.wtot[w];
+                    if (w < wv) woff += t;
+                    total += t;
+                }
+                incl += woff;
+                sm.sIncl[tid] = incl;
+                sm.sBase[tid] = b0 - (incl - len);
+                if (NUM) sm.sAv[tid] = av;
+                __syncthreads();
+
+                for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
+                    int col[U];
+                    double pv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int p = p0 + u * BLOCK + tid;
+                        col[u] = kEmpty;
+                        pv[u] = 0.0;
+                        if (p < total) {
+                            int l = 0, r = BLOCK - 1;            // first entry j with sIncl[j] > p
+                            while (l < r) { const int mid = (l + r) >> 1; if (sm.sIncl[mid] > p) r = mid; else l = mid + 1; }
+                            const long long idx = (long long)sm.sBase[l] + p;
+                            const int c = Bj[idx];
+                            if (full || bSorted || ((long long)c >= lo && (long long)c < hi)) {
+                                col[u] = c;
+                                if (NUM) pv[u] = sm.sAv[l] * Bx[idx];
                             }
                         }
-                        if (cur == col) break;
-                        h = (h + 1) & (TS - 1);
-                        if (WIN && ++probes >= TS) { atomicOr(&sm.counter[1], 1); overflow = true; break; }
                     }
-                    if (NUM && !overflow) unsafeAtomicAdd(&sm.vals[h], av * Bx[jb]);
+                    int myNew = 0;
+                    bool ovf = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int cv = col[u];
+                        if (cv != kEmpty) {
+                            unsigned h = hash_col(cv, LOG2TS);
+                            int probes = 0;
+                            for (;;) {
+                                const int c2 = atomicCAS(&sm.keys[h], kEmpty, cv);
+                                if (c2 == kEmpty) { ++myNew; break; }
+                                if (c2 == cv) break;
+                                h = (h + 1) & (TS - 1);
+                                if (++probes >= TS) { ovf = true; break; }
+                            }
+                            if (NUM && !ovf) unsafeAtomicAdd(&sm.vals[h], pv[u]);
+                        }
+                    }
+                    // ---- fill level after this batch (one LDS atomic per wave)
+                    const int wNew = wave_sum_dpp(myNew);
+                    const unsigned long long anyOvf = __ballot(ovf);
+                    if (lane == 0) {
+                        if (wNew) { const int before = atomicAdd(&sm.counter[0], wNew); if (before + wNew > CAP) sm.counter[1] = 1; }
+                        if (anyOvf) sm.counter[1] = 1;
+                    }
+                    __syncthreads();
+                    if (sm.counter[1]) break;                       // uniform
                 }
+                __syncthreads();                                    // sIncl/sBase are rewritten by the next chunk
             }
-            if (!WIN) {
-                myNew = wave_sum(myNew);
-                if (BLOCK == 64) { if (tid == 0) sm.counter[0] = myNew; }
-                else if ((tid & 63) == 0 && myNew) atomicAdd(&sm.counter[0], myNew);
-            }
-            group_sync<BLOCK>();
+            __syncthreads();
             const int uniq = sm.counter[0];
-            const int ovf = WIN ? sm.counter[1] : 0;
-            group_sync<BLOCK>();
-            if (WIN && ovf) {                      // halve the window and retry the same lo
+            const int ovfl = sm.counter[1];
+            __syncthreads();
+            if (ovfl) {                                             // halve the window and retry the same lo
                 if (width <= 1) { if (tid == 0) atomicOr(errFlag, 1); lo = hi; }
                 else width = (width + 1) >> 1;
                 continue;
             }
-
             if (!NUM) {
                 rowTotal += uniq;
             } else if (uniq > 0) {
-                // ---- 3b. compact occupied slots -> packed (col<<32 | slot)
-                int P = 2;
-                while (P < uniq) P <<= 1;
-                int run = 0;                       // BLOCK == 64: running output cursor (wave-uniform)
-                for (int s0 = 0; s0 < TS; s0 += BLOCK) {
-                    const int s = s0 + tid;
-                    const int key = sm.keys[s];
-                    const bool valid = key != kEmpty;
-                    const unsigned long long bal = __ballot(valid);
-                    const int lanePos = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-                    int wbase;
-                    if (BLOCK == 64) {
-                        wbase = run;
-                        run += __popcll(bal);
-                    } else {
-                        wbase = 0;
-                        if ((tid & 63) == 0) wbase = atomicAdd(&sm.counter[2], __popcll(bal));
-                        wbase = __shfl(wbase, 0, 64);
-                    }
-                    if (valid)
-                        sm.sorted[wbase + lanePos] = ((unsigned long long)(unsigned)key << 32) | (unsigned)s;
-                }
-                for (int s = uniq + tid; s < P; s += BLOCK) sm.sorted[s] = ~0ull;
-                group_sync<BLOCK>();
-                // ---- bitonic sort of P packed keys in LDS
-                for (int kk = 2; kk <= P; kk <<= 1) {
+                // ---- in-place bitonic sort of the whole table (keys as unsigned: empty = 0xffffffff last)
+                for (int kk = 2; kk <= TS; kk <<= 1) {
                     for (int j = kk >> 1; j > 0; j >>= 1) {
-                        for (int i = tid; i < (P >> 1); i += BLOCK) {
+                        for (int i = tid; i < (TS >> 1); i += BLOCK) {
                             const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                             const int b = a | j;
                             const bool up = (a & kk) == 0;
-                            const unsigned long long x = sm.sorted[a], y = sm.sorted[b];
-                            if ((x > y) == up) { sm.sorted[a] = y; sm.sorted[b] = x; }
+                            const unsigned x = (unsigned)sm.keys[a], y = (unsigned)sm.keys[b];
+                            if ((x > y) == up && x != y) {
+                                sm.keys[a] = (int)y; sm.keys[b] = (int)x;
+                                const double va = sm.vals[a], vb = sm.vals[b];
+                                sm.vals[a] = vb; sm.vals[b] = va;
+                            }
                         }
-                        group_sync<BLOCK>();
+                        __syncthreads();
                     }
                 }
-                // ---- stream the window out at its final CSR position
                 for (int r = tid; r < uniq; r += BLOCK) {
-                    const unsigned long long e = sm.sorted[r];
-                    Cj[outBase + r] = (int)(e >> 32);
-                    Cx[outBase + r] = sm.vals[(unsigned)e];
+                    Cj[outBase + r] = sm.keys[r];
+                    Cx[outBase + r] = sm.vals[r];
                 }
                 outBase += uniq;
-                group_sync<BLOCK>();
+                __syncthreads();
             }
-            if (!WIN) break;
             lo = hi;
-            if (uniq < CAP / 4 && width < ncolsB) width <<= 1;   // sparse window: grow the next one
+            if (uniq < CAP / 4 && width < ncolsB) width <<= 1;      // sparse window: grow the next one
         }
         if (!NUM && tid == 0) CpOrCnt[row] = rowTotal;
     }

@@ -64,8 +64,8 @@ const KernelCfg kSymCfg[kNumSymBins] = {
     {10, 64, false}, {11, 64, false}, {12, 64, false}, {13, 256, false}, {15, 1024, false}, {15, 1024, true}};
 constexpr int kNumNumBins = 10;
 const KernelCfg kNumCfg[kNumNumBins] = {
-    {0, 0, false},  {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},
-    {9, 64, false}, {10, 64, false}, {11, 64, false}, {12, 256, false}, {12, 256, true}};
+    {0, 0, false},  {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},  {9, 64, false},
+    {10, 64, false}, {12, 256, false}, {13, 512, false}, {13, 512, true}};
 constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a 64-slot quarter table admits
 
 BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad)
@@ -144,7 +144,7 @@ namespace {
 // layout of the `small` device buffer (ints)
 enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S_NUM_START = 64,
        S_NUM_CURSOR = 80, S_TOTAL_CT = 96 /* 2 ints = u64 */, S_TOTAL_C = 98 /* 2 ints = i64 */,
-       S_ERR = 100,
+       S_ERR = 100, S_TICKET = 101 /* dynamic row scheduler of the workgroup-per-row kernels */,
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
        S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
@@ -210,27 +210,26 @@ int timed_end(bhs_handle* h, EventPair* p)
     return BHS_SUCCESS;
 }
 
-template <int LOG2TS, int BLOCK, bool NUM, bool WIN>
-int launch_row_hash(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+template <int LOG2TS, int BLOCK, bool NUM>
+int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     constexpr int TS = 1 << LOG2TS;
-    auto kern = k_row_hash<TS, LOG2TS, BLOCK, NUM, WIN>;
-    const size_t smem = sizeof(RowHashSmem<TS, BLOCK, NUM>);
-    static bool attrDone = false;
-    if (!attrDone) {
+    auto kern = k_row_block<TS, LOG2TS, BLOCK, NUM>;
+    const size_t smem = sizeof(BlockSmem<TS, BLOCK, NUM>);
+    static int perCU = 0;
+    if (!perCU) {
         if (smem > 48 * 1024)
             BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attrDone = true;
+        int nb = 0;
+        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, smem));
+        perCU = std::max(1, nb);
     }
-    // resident groups per CU: bounded by LDS (160 KiB) and by 32 waves / CU
-    int perCU = (int)std::min<size_t>((160 * 1024) / (smem + 256), (size_t)(2048 / BLOCK));
-    if (perCU < 1) perCU = 1;
-    long long grid = std::min<long long>((long long)qn, (long long)h->numCU * perCU * 2);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->stream, queue, qn, h->n, h->logL,
-                       h->bSorted, h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p,
-                       CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p, (int*)h->small.p + S_ERR);
+    long long grid = std::max<long long>(1, std::min<long long>((long long)qn, (long long)h->numCU * perCU));
+    BHS_HIP(hipMemsetAsync((int*)h->small.p + S_TICKET, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->stream, queue, qn, h->n, h->bSorted, h->dAj,
+                       h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p,
+                       (int*)h->small.p + S_ERR, (int*)h->small.p + S_TICKET);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -310,36 +309,22 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
-#define BHS_CASE(LG, BL, W) \
-    if (lg == LG && c.block == BL && win == W) return launch_row_hash<LG, BL, NUM, W>(h, queue, qn, CpOrCnt)
+#define BHS_CASE(LG, BL, W)
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
     BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);
     if constexpr (!NUM) { BHS_WAVE(12); }
 #undef BHS_WAVE
-    if (!win) {
-        BHS_CASE(6, 64, false);
-        BHS_CASE(7, 64, false);
-        BHS_CASE(8, 64, false);
-        BHS_CASE(9, 64, false);
-        BHS_CASE(10, 64, false);
-        BHS_CASE(11, 64, false);
-        if constexpr (!NUM) {
-            BHS_CASE(12, 64, false);
-            BHS_CASE(13, 256, false);
-            BHS_CASE(15, 1024, false);
-        } else {
-            BHS_CASE(12, 256, false);
-        }
-    }
-    // window variants: workgroup per row; table chosen by the cap
+    // long rows: workgroup per row (every instantiation carries the column-window loop)
+    (void)win;
     if constexpr (!NUM) {
-        if (lg >= 15) return launch_row_hash<15, 1024, NUM, true>(h, queue, qn, CpOrCnt);
-        if (lg >= 12) return launch_row_hash<12, 256, NUM, true>(h, queue, qn, CpOrCnt);
-        return launch_row_hash<8, 256, NUM, true>(h, queue, qn, CpOrCnt);
+        if (lg >= 15) return launch_row_block<15, 1024, false>(h, queue, qn, CpOrCnt);
+        if (lg >= 13) return launch_row_block<13, 256, false>(h, queue, qn, CpOrCnt);
+        return launch_row_block<8, 256, false>(h, queue, qn, CpOrCnt);       // capped tables (tests): many windows
     } else {
-        if (lg >= 12) return launch_row_hash<12, 256, NUM, true>(h, queue, qn, CpOrCnt);
-        return launch_row_hash<8, 256, NUM, true>(h, queue, qn, CpOrCnt);
+        if (lg >= 13) return launch_row_block<13, 512, true>(h, queue, qn, CpOrCnt);
+        if (lg >= 12) return launch_row_block<12, 256, true>(h, queue, qn, CpOrCnt);
+        return launch_row_block<8, 256, true>(h, queue, qn, CpOrCnt);
     }
 #undef BHS_CASE
 }
@@ -349,8 +334,8 @@ const char* kSymNames[kNumSymBins] = {"", "symbolic_quad<64>", "symbolic_wave<64
                                       "symbolic_wave<4096>", "symbolic_wg<8192>", "symbolic_wg<32768>",
                                       "symbolic_wg_window<32768>"};
 const char* kNumNames[kNumNumBins] = {"", "numeric_quad<64>", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
-                                      "numeric_wave<512>", "numeric_wave<1024>", "numeric_wave<2048>",
-                                      "numeric_wg<4096>", "numeric_wg_window<4096>"};
+                                      "numeric_wave<512>", "numeric_wave<1024>",
+                                      "numeric_wg<4096>", "numeric_wg<8192>", "numeric_wg_window<8192>"};
 
 int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
 {
@@ -408,7 +393,7 @@ int run_pipeline(bhs_handle* h)
 
     // ------------------------------------------------------------ stage 1
     const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0);
-    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 12), h->numLoadPct, h->forcePath == 0);
+    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
