@@ -511,6 +511,164 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Dense accumulator (SPA) in HBM for rows whose result does not fit the LDS table
+// of k_row_block (hub rows of power-law matrices: webbase-1M has C rows with
+// ~100 k entries).  Each resident workgroup owns one slot: an n-entry fp64
+// vector (numeric) and an n-bit occupancy bitmap.  Products are added with
+// global_atomic_add_f64 / global_atomic_or (they execute in the XCD's L2; the
+// slot is private to the workgroup, so there is no cross-XCD traffic); the
+// bitmap scan then yields the row in ascending column order — no column
+// windows, no sort — and restores the slot to all-zero on the way out.
+// Replaces, for those rows, the reference's EM_mergepath_global rounds
+// (bhsparse_cuda.h:2270-2525) and their progressive re-allocation (:2527-2780).
+// ---------------------------------------------------------------------------
+template <int BLOCK, bool NUM>
+__global__ __launch_bounds__(BLOCK) void k_row_spa(
+    const int4* __restrict__ desc, int qn, int ncolsB,
+    const int* __restrict__ Aj, const double* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx,
+    int* __restrict__ ticket, double* __restrict__ spaBase, unsigned* __restrict__ bitsBase)
+{
+    __shared__ double sAv[NUM ? BLOCK : 1];
+    __shared__ int sIncl[BLOCK];
+    __shared__ int sBase[BLOCK];
+    __shared__ int wtot[BLOCK / 64];
+    __shared__ int bcast;
+    constexpr int U = 4, NW = BLOCK / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nWords = (ncolsB + 31) >> 5;
+    double* spa = NUM ? spaBase + (size_t)blockIdx.x * (size_t)ncolsB : nullptr;
+    unsigned* bits = bitsBase + (size_t)blockIdx.x * (size_t)nWords;
+
+    for (;;) {
+        if (tid == 0) bcast = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int q = bcast;
+        __syncthreads();
+        if (q >= qn) break;
+        const int4 d = desc[q];
+        const int row = d.x, a0 = d.y, a1 = d.z;
+        // ---- expand: one A entry per lane, flat product space per chunk of BLOCK entries
+        for (int ca = a0; ca < a1; ca += BLOCK) {
+            const int e = ca + tid;
+            int b0 = 0, len = 0;
+            double av = 0.0;
+            if (e < a1) {
+                const int c = Aj[e];
+                if (NUM) av = Ax[e];
+                int2 be;
+                __builtin_memcpy(&be, Bp + c, sizeof(be));
+                b0 = be.x;
+                len = be.y - be.x;
+            }
+            int incl = wave_incl_scan_dpp(len);
+            if (lane == 63) wtot[wv] = incl;
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int t = wtot[w];
+                if (w < wv) woff += t;
+                total += t;
+            }
+            incl += woff;
+            sIncl[tid] = incl;
+            sBase[tid] = b0 - (incl - len);
+            if (NUM) sAv[tid] = av;
+            __syncthreads();
+            for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * BLOCK + tid;
+                    if (p < total) {
+                        int l = 0, r = BLOCK - 1;                // first entry j with sIncl[j] > p
+                        while (l < r) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
+                        const long long idx = (long long)sBase[l] + p;
+                        const int c = Bj[idx];
+                        atomicOr(&bits[c >> 5], 1u << (c & 31));
+                        if (NUM) unsafeAtomicAdd(&spa[c], sAv[l] * Bx[idx]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // The slot is private to this workgroup and every access to it is served by this XCD's L2
+        // (device-scope atomics, sc1 loads, write-through stores), so a workgroup barrier (which drains
+        // each wave's vmcnt) orders them; an agent-scope fence would write back the whole L2 (buffer_wbl2).
+        __syncthreads();
+        // ---- scan the bitmap: thread t owns words [t*per, (t+1)*per); loads go out 8 at a time
+        const int per = (nWords + BLOCK - 1) / BLOCK;
+        const int wBeg = tid * per < nWords ? tid * per : nWords;
+        const int wEnd = wBeg + per < nWords ? wBeg + per : nWords;
+        int mine = 0;
+        for (int w = wBeg; w < wEnd; w += 8) {
+            unsigned m[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                m[t] = (w + t < wEnd) ? __hip_atomic_load(&bits[w + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mine += __popc(m[t]);
+        }
+        int inc2 = wave_incl_scan_dpp(mine);
+        if (lane == 63) wtot[wv] = inc2;
+        __syncthreads();
+        int off = 0, rowCount = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int t = wtot[w];
+            if (w < wv) off += t;
+            rowCount += t;
+        }
+        off += inc2 - mine;                                   // entries of this row before this thread's words
+        if (!NUM) {
+            for (int w = wBeg; w < wEnd; ++w) bits[w] = 0u;     // leave the slot clean
+            if (tid == 0) cntOut[row] = rowCount;
+        } else {
+            // column indices: each thread expands its words (stores only, nothing waits on them)
+            long long out = (long long)d.w + off;
+            for (int w = wBeg; w < wEnd; w += 8) {
+                unsigned m[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    m[t] = (w + t < wEnd) ? __hip_atomic_load(&bits[w + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    unsigned mm = m[t];
+                    if (mm) bits[w + t] = 0u;
+                    while (mm) {
+                        const int b = __ffs((int)mm) - 1;
+                        mm &= mm - 1;
+                        Cj[out++] = ((w + t) << 5) + b;
+                    }
+                }
+            }
+            __syncthreads();
+            // values: all lanes gather spa[col] for the row's sorted columns, coalesced and independent
+            const long long base = d.w;
+            for (int r0 = 0; r0 < rowCount; r0 += BLOCK * U) {
+                int c[U];
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + u * BLOCK + tid;
+                    c[u] = r < rowCount ? __hip_atomic_load(&Cj[base + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = c[u] >= 0 ? __hip_atomic_load(&spa[c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + u * BLOCK + tid;
+                    if (c[u] >= 0) { Cx[base + r] = v[u]; spa[c[u]] = 0.0; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ===========================================================================
 // Wavefront-per-row accumulator (the workhorse; one 64-lane workgroup per row
 // in flight, persistent over an XCD-aware slice of the row queue).
@@ -536,8 +694,10 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 #ifndef BHS_WPB
 #define BHS_WPB 1
 #endif
+// ask the register allocator for >= 6 waves per SIMD: the accumulator is latency-bound (LDS round trips),
+// measured -8 % on the numeric pass versus the 5 waves the unconstrained allocation reaches
 #ifndef BHS_WAVE_ATTR
-#define BHS_WAVE_ATTR
+#define BHS_WAVE_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
 #endif
 // first probe = one ds_cmpst_rtn (claims an empty slot or returns the resident key) instead of
 // ds_read + conditional ds_cmpst: measured -19 % symbolic / -8 % numeric on poisson27pt

@@ -119,6 +119,9 @@ struct bhs_handle {
     long long nnzCt = 0;
     // workspace
     DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
+    DevBuf spaVals, spaBits;             // dense-accumulator slots for rows beyond the LDS tables (kept all-zero)
+    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0;
+    bool spaDirty = false;
     int* hostSmall = nullptr;            // pinned mirror of `small`
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
     size_t hostRowPtrCap = 0;
@@ -234,6 +237,44 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     return BHS_SUCCESS;
 }
 
+// Dense-accumulator slots: one n-entry fp64 vector + n-bit bitmap per resident workgroup, sized against
+// 1/16 of the device memory, allocated once per column count and kept all-zero by the kernel itself.
+int ensure_spa(bhs_handle* h)
+{
+    const size_t n = (size_t)std::max(h->n, 1), nWords = (n + 31) / 32;
+    if (h->spaCols == h->n && h->spaSlots > 0 && !h->spaDirty) return BHS_SUCCESS;
+    size_t freeB = 0, totalB = 0;
+    BHS_HIP(hipMemGetInfo(&freeB, &totalB));
+    const size_t perSlot = n * sizeof(double) + nWords * sizeof(unsigned);
+    long long slots = (long long)(std::min(totalB / 16, freeB / 2) / perSlot);
+    slots = std::min<long long>(slots, h->spaMaxSlots > 0 ? (long long)h->spaMaxSlots : (long long)h->numCU);   // 1 per CU measured best
+    if (slots < 8) { h->spaSlots = 0; return BHS_SUCCESS; }       // too wide: the column-window path stays in charge
+    if (h->spaCols != h->n || h->spaSlots != (int)slots) {
+        BHS_TRY(ensure(h, h->spaVals, (size_t)slots * n * sizeof(double)));
+        BHS_TRY(ensure(h, h->spaBits, (size_t)slots * nWords * sizeof(unsigned)));
+    }
+    BHS_HIP(hipMemsetAsync(h->spaVals.p, 0, (size_t)slots * n * sizeof(double), h->stream));
+    BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->stream));
+    h->spaSlots = (int)slots;
+    h->spaCols = h->n;
+    h->spaDirty = false;
+    return BHS_SUCCESS;
+}
+
+template <bool NUM>
+int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    constexpr int BLOCK = 512;
+    const long long grid = std::max<long long>(1, std::min<long long>(qn, h->spaSlots));
+    int* small = (int*)h->small.p;
+    BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->stream, queue, qn, h->n,
+                       h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p,
+                       small + S_TICKET, (double*)h->spaVals.p, (unsigned*)h->spaBits.p);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
 template <int LOG2TS, bool NUM, bool PACK32>
 int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
@@ -307,6 +348,7 @@ template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
+    if (c.win && h->spaSlots > 0 && h->useSpa && h->maxTableLog2 >= 15) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_CASE(LG, BL, W)
@@ -332,10 +374,10 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
 const char* kSymNames[kNumSymBins] = {"", "symbolic_quad<64>", "symbolic_wave<64>", "symbolic_wave<128>", "symbolic_wave<256>",
                                       "symbolic_wave<512>", "symbolic_wave<1024>", "symbolic_wave<2048>",
                                       "symbolic_wave<4096>", "symbolic_wg<8192>", "symbolic_wg<32768>",
-                                      "symbolic_wg_window<32768>"};
+                                      "symbolic_long_rows"};
 const char* kNumNames[kNumNumBins] = {"", "numeric_quad<64>", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
                                       "numeric_wave<512>", "numeric_wave<1024>",
-                                      "numeric_wg<4096>", "numeric_wg<8192>", "numeric_wg_window<8192>"};
+                                      "numeric_wg<4096>", "numeric_wg<8192>", "numeric_long_rows"};
 
 int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
 {
@@ -560,6 +602,7 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipStreamSynchronize(h->stream));
         h->bSorted = flag ? 0 : 1;
     }
+    if (h->useSpa) BHS_TRY(ensure_spa(h));
     h->hasData = true;
     h->hasC = false;
     return BHS_SUCCESS;
@@ -644,6 +687,8 @@ int bhs_destroy(bhs_handle* h)
     release(h->queue);
     release(h->blockSum);
     release(h->small);
+    release(h->spaVals);
+    release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
     if (h->hostRowPtr) (void)hipHostFree(h->hostRowPtr);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
@@ -729,9 +774,10 @@ int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_ou
     if (!h->hasData) return BHS_ERR_NOT_READY;
     BHS_HIP(hipSetDevice(h->device));
     h->wantHostRowPtr = rowPtrC_out != nullptr;
+    if (h->useSpa && (h->spaDirty || h->spaCols != h->n)) BHS_TRY(ensure_spa(h));
     const int rc = run_pipeline(h);
     h->wantHostRowPtr = false;
-    if (rc) return rc;
+    if (rc) { h->spaDirty = true; return rc; }
     if (h->verbose) {
         printf("STAGE 1 time: %g ms.\n", h->stageMs[0]);
         printf("STAGE 2 time: %g ms.\n", h->stageMs[1]);
@@ -827,6 +873,8 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
         if (value < 5 || value > 75) return BHS_ERR_INVALID_ARG;
         (key[0] == 's' ? h->symLoadPct : h->numLoadPct) = (int)value;

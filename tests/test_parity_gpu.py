@@ -251,7 +251,15 @@ def test_hub_row_power_law(oracle):
     val = gallery.fill_values(len(col))
     A = (rp, col, val)
     Cp, Cj, Cx, info = _check(oracle, m, m, m, A, A)
-    assert np.diff(Cp).max() > 6144      # at least one row needs the window path
+    assert np.diff(Cp).max() > 6144      # at least one row is beyond every LDS table
+    names = [k["name"] for k in info["kernels"]]
+    assert "numeric_long_rows" in names
+    # dense accumulator in HBM (default) vs the column-window fallback: same bits
+    Cp2, Cj2, Cx2, _ = _check(oracle, m, m, m, A, A, options={"spa": 0})
+    assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
+    # float values through the global fp64 atomics stay within tolerance
+    valf = np.random.default_rng(1).standard_normal(len(col))
+    _check(oracle, m, m, m, (rp, col, valf), (rp, col, valf), exact=False)
 
 
 def test_repeated_spgemm_and_data_swap(oracle):

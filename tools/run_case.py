@@ -23,10 +23,13 @@ assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, B
 for kv in os.environ.get('BHS_OPTS','').split(','):
     if kv: k_, v_ = kv.split('='); assert bh.set_option(k_, int(v_)) == 0
 for _ in range(2): assert bh.spgemm() == 0
-acc = {}; st = np.zeros(4); n = 5
+acc = {}; info = {}; st = np.zeros(4); n = 5
 for _ in range(n):
     assert bh.spgemm() == 0
     st += np.array(bh.stage_ms) / n
-    for s in bh.kernel_stats(): acc[s["name"]] = acc.get(s["name"], 0) + s["ms"] / n
+    for s in bh.kernel_stats():
+        acc[s["name"]] = acc.get(s["name"], 0) + s["ms"] / n
+        info[s["name"]] = (s["rows"], s["products"], s["nnz_out"])
 print(name, "m=%d nnzA=%d nnzCt=%d nnzC=%d" % (m, Aj.numel(), bh.nnzCt, bh.nnzC), "stages", np.round(st, 3), "total %.3f ms  %.1f GFLOPs" % (st.sum(), 2 * bh.nnzCt / st.sum() / 1e6))
 print("   ", {k: round(v, 3) for k, v in acc.items() if v > 0.01})
+print("   rows/products/nnz:", {k: v for k, v in info.items() if acc[k] > 0.3})
