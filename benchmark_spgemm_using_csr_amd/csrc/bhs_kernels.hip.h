@@ -72,39 +72,73 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
                                                      unsigned long long* __restrict__ total,
                                                      int* __restrict__ binCount, BinSpec spec)
 {
+    // The per-row work is a chain of three dependent loads (rowPtrA -> colIndA -> rowPtrB) and little
+    // else, so every lane group keeps R rows in flight: all rowPtrA pairs, then all colIndA, then all
+    // rowPtrB gathers are issued before the first sum is needed.
+    constexpr int R = 4;
     __shared__ int hist[kMaxBins];
     __shared__ unsigned long long bsum;
     const int tid = threadIdx.x;
     if (tid < kMaxBins) hist[tid] = 0;
     if (tid == 0) bsum = 0;
     __syncthreads();
-    const int rows_per_block = 256 / G;
+    constexpr int rows_per_block = 256 / G;
     const int g = tid % G;
-    for (long long rbase = (long long)blockIdx.x * rows_per_block; rbase < m;
-         rbase += (long long)gridDim.x * rows_per_block) {
-        const int row = (int)rbase + tid / G;
-        long long s = 0;
-        int nA = 0;
-        if (row < m) {
-            const int a0 = Ap[row], a1 = Ap[row + 1];
-            nA = a1 - a0;
-            for (int j = a0 + g; j < a1; j += G) {
-                const int c = Aj[j];
+    unsigned long long mySum = 0;                       // leaders only
+    for (long long rbase = (long long)blockIdx.x * rows_per_block * R; rbase < m;
+         rbase += (long long)gridDim.x * rows_per_block * R) {
+        int row[R], a0[R], a1[R], c[R];
+        long long s[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            row[k] = (int)rbase + k * rows_per_block + tid / G;
+            a0[k] = a1[k] = 0;
+            if (row[k] < m) { a0[k] = Ap[row[k]]; a1[k] = Ap[row[k] + 1]; }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) { c[k] = -1; if (a0[k] + g < a1[k]) c[k] = Aj[a0[k] + g]; }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            s[k] = 0;
+            if (c[k] >= 0) {
                 int2 be;                                     // rowPtrB[c], rowPtrB[c+1] in one 8-byte gather
-                __builtin_memcpy(&be, Bp + c, sizeof(be));
-                s += be.y - be.x;
+                __builtin_memcpy(&be, Bp + c[k], sizeof(be));
+                s[k] = be.y - be.x;
             }
         }
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (row < m && g == 0) {
-            const int v = s > 0x7fffffffLL ? 0x7fffffff : (int)s;
-            ub[row] = v;
-            if (v == 0) cnt[row] = 0;          // ESC_0 (bhsparse_cuda.h:1582-1595): nothing else to do
-            atomicAdd(&hist[bin_of(spec, v, nA)], 1);
-            atomicAdd(&bsum, (unsigned long long)s);
+        for (int k = 0; k < R; ++k)                          // rows longer than G entries: the rest, plainly
+            for (int j = a0[k] + g + G; j < a1[k]; j += G) {
+                const int cc = Aj[j];
+                int2 be;
+                __builtin_memcpy(&be, Bp + cc, sizeof(be));
+                s[k] += be.y - be.x;
+            }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            // group sum: one DPP wave scan + one cross-lane read while the partial sums are small (the
+            // common case); 64-bit butterfly otherwise.  The LAST lane of a group is its leader.
+            long long tot;
+            if (!__any(s[k] >= (1LL << 24))) {
+                const int incl = wave_incl_scan_dpp((int)s[k]);
+                const int before = __shfl(incl, (int)(threadIdx.x & 63) - G, 64);   // end of the previous group
+                tot = incl - ((threadIdx.x & 63) >= G ? before : 0);
+            } else {
+                long long t = s[k];
+#pragma unroll
+                for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                tot = t;
+            }
+            if (row[k] < m && g == G - 1) {
+                const int v = tot > 0x7fffffffLL ? 0x7fffffff : (int)tot;
+                ub[row[k]] = v;
+                if (v == 0) cnt[row[k]] = 0;   // ESC_0 (bhsparse_cuda.h:1582-1595): nothing else to do
+                atomicAdd(&hist[bin_of(spec, v, a1[k] - a0[k])], 1);
+                mySum += (unsigned long long)tot;
+            }
         }
     }
+    if (mySum) atomicAdd(&bsum, mySum);
     __syncthreads();
     if (tid < spec.nbins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
     if (tid == 0 && bsum) atomicAdd(total, bsum);
@@ -280,6 +314,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(int m, int* __restrict__ cnt
         if (base + i <= m) cnt_to_ptr[base + i] = (int)off;
         off += v[i];
     }
+}
+
+// longest row of a CSR matrix (chooses the lanes-per-row of k_upper_bound for skewed inputs)
+__global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ Ap, int* __restrict__ out)
+{
+    int mx = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256)
+        mx = max(mx, Ap[i + 1] - Ap[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
 }
 
 // B-row sortedness check (reference precondition for EM_mergepath,

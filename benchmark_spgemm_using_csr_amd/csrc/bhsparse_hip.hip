@@ -151,7 +151,7 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
        S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_SMALL_INTS = 320 };
+       S_SORTED = 300, S_MAXROW = 301, S_SMALL_INTS = 320 };
 
 int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
 {
@@ -383,7 +383,7 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
 {
     const int G = h->ubG;
     const int rowsPerBlock = 256 / G;
-    long long grid = ((long long)h->m + rowsPerBlock - 1) / rowsPerBlock;
+    long long grid = ((long long)h->m + rowsPerBlock * 4 - 1) / (rowsPerBlock * 4);   // 4 rows per lane group per pass
     grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * 32));
     int* small = (int*)h->small.p;
 #define BHS_UB(GG)                                                                                   \
@@ -583,7 +583,20 @@ int finish_set_data(bhs_handle* h)
     // derived launch parameters
     const double avgA = h->m > 0 ? (double)h->nnzA / h->m : 1.0;
     const double avgB = h->k > 0 ? (double)h->nnzB / h->k : 1.0;
-    h->ubG = pow2_at_least(avgA, 1, 64);
+    BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
+    int maxRowA = 0;
+    if (h->m > 0) {
+        int* small0 = (int*)h->small.p;
+        BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
+        const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 8);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_MAXROW);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(&maxRowA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+    }
+    // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
+    // that the longest row is walked in <= 32 passes
+    h->ubG = pow2_at_least(std::max(avgA, maxRowA / 32.0), 1, 64);
     int L = pow2_at_least(avgB, 1, 64);
     int lg = 0;
     while ((1 << lg) < L) ++lg;
