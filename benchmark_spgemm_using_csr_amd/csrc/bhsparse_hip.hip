@@ -62,10 +62,10 @@ constexpr int kNumSymBins = 12;
 const KernelCfg kSymCfg[kNumSymBins] = {
     {0, 0, false},   {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},   {9, 64, false},
     {10, 64, false}, {11, 64, false}, {12, 64, false}, {13, 256, false}, {15, 1024, false}, {15, 1024, true}};
-constexpr int kNumNumBins = 10;
+constexpr int kNumNumBins = 11;
 const KernelCfg kNumCfg[kNumNumBins] = {
     {0, 0, false},  {6, 16, false},  {6, 64, false},  {7, 64, false},   {8, 64, false},  {9, 64, false},
-    {10, 64, false}, {12, 256, false}, {13, 512, false}, {13, 512, true}};
+    {10, 64, false}, {11, 256, false}, {12, 256, false}, {13, 512, false}, {13, 512, true}};
 constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a 64-slot quarter table admits
 
 BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad)
@@ -366,6 +366,7 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
     } else {
         if (lg >= 13) return launch_row_block<13, 512, true>(h, queue, qn, CpOrCnt);
         if (lg >= 12) return launch_row_block<12, 256, true>(h, queue, qn, CpOrCnt);
+        if (lg >= 11) return launch_row_block<11, 256, true>(h, queue, qn, CpOrCnt);
         return launch_row_block<8, 256, true>(h, queue, qn, CpOrCnt);
     }
 #undef BHS_CASE
@@ -377,7 +378,7 @@ const char* kSymNames[kNumSymBins] = {"", "symbolic_quad<64>", "symbolic_wave<64
                                       "symbolic_long_rows"};
 const char* kNumNames[kNumNumBins] = {"", "numeric_quad<64>", "numeric_wave<64>", "numeric_wave<128>", "numeric_wave<256>",
                                       "numeric_wave<512>", "numeric_wave<1024>",
-                                      "numeric_wg<4096>", "numeric_wg<8192>", "numeric_long_rows"};
+                                      "numeric_wg<2048>", "numeric_wg<4096>", "numeric_wg<8192>", "numeric_long_rows"};
 
 int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
 {
