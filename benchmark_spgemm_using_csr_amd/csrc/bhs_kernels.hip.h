@@ -22,6 +22,16 @@
 #ifndef BHS_ABL_SYM
 #define BHS_ABL_SYM 0
 #endif
+// measurement only: per-phase shader-clock accounting of the numeric wave kernel (tools/phase_profile.py)
+#ifndef BHS_PHASES
+#define BHS_PHASES 0
+#endif
+#if BHS_PHASES
+__device__ unsigned long long g_phase_cycles[16];
+#define BHS_TICK(i) do { if (NUM) { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPrev; tPrev = t__; } } while (0)
+#else
+#define BHS_TICK(i) do { } while (0)
+#endif
 #include <stdint.h>
 #include <type_traits>
 
@@ -914,6 +924,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     int b0C = 0, lenC = 0;
     if (lane < dC.z - dC.y) { b0C = Bp[cC]; lenC = Bp[cC + 1] - b0C; }
 
+#if BHS_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tPrev = __builtin_readcyclecounter();
+#endif
     for (int it = 0; it < nIt; ++it) {
         // ---- prefetch for the rows behind this one
         const int4 d3 = (it + 3 < nIt) ? desc[qs + (it + 3) * perX] : kNoRow;
@@ -959,6 +973,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 if (NUM) sm.sAv[jc] = av;
             }
             int done = 0;                                    // entries completed before the window
+            BHS_TICK(0);
             for (int w0 = 0; w0 < total; w0 += 64 * MAXB) {
                 const int nb = (total - w0 + 63) >> 6;       // batches in this window (wave-uniform)
                 if (lane < 2 * MAXB) sm.marks[lane] = 0;
@@ -991,6 +1006,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                     }
                 }
                 done = cum;
+                BHS_TICK(1);
+#if BHS_PHASES
+                if (NUM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                BHS_TICK(2);
+#endif
                 if (abl & 4) {
 #pragma unroll
                     for (int u = 0; u < MAXB; ++u) { asm volatile("" ::"v"(col[u])); if (NUM) asm volatile("" ::"v"(pv[u])); }
@@ -1043,6 +1063,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
         }
         wave_sync();
+        BHS_TICK(3);
         if (!NUM) {
             myNew = wave_sum_dpp(myNew);
             if (lane == 0) cntOut[row] = myNew;
@@ -1066,6 +1087,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
             const int uniq = run;
             wave_sync();
+            BHS_TICK(4);
             if (abl & 2) {
                 if (!(abl & 8))
                     for (int r = lane; r < uniq; r += 64) {
@@ -1105,12 +1127,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
         }
         wave_sync();
+        BHS_TICK(5);
         // ---- rotate the pipeline
         dC = d1; d1 = d2; d2 = d3;
         avC = av1; av1 = av2;
         c1 = c2;
         b0C = b01; lenC = len1;
     }
+#if BHS_PHASES
+    if (NUM && lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
+        atomicAdd(&g_phase_cycles[7], (unsigned long long)nIt);
+    }
+#endif
 }
 
 // ===========================================================================

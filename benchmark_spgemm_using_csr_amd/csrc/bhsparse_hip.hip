@@ -915,4 +915,15 @@ const char* bhs_strerror(int status)
 
 const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950)"; }
 
+#if BHS_PHASES
+// measurement-only builds (tools/build_variants.sh -DBHS_PHASES=1): read and reset the phase counters
+__attribute__((visibility("default"))) int bhs_debug_phases(unsigned long long* out)
+{
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 }  // extern "C"

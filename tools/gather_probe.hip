@@ -4,10 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-template <int BYTES, int RUN>   // RUN elements of 8 bytes (vals) or 4 bytes (cols: BYTES==4)
+template <int BYTES, int RUN, int ELEM>   // RUN elements of ELEM bytes per row, BYTES loaded per lane
 __global__ __launch_bounds__(64) void k(const char* __restrict__ base, size_t windowBytes, int iters, double* out, int contiguous) {
   const int lane = threadIdx.x;
-  constexpr int ELEM = (BYTES == 4) ? 4 : 8;
   constexpr int EPL = BYTES / ELEM;                 // elements per lane per load
   constexpr int LPR = (RUN + EPL - 1) / EPL;        // lanes per row
   constexpr int RPI = 64 / LPR;                     // rows per instruction
@@ -24,22 +23,22 @@ __global__ __launch_bounds__(64) void k(const char* __restrict__ base, size_t wi
       const char* p = base + row * (RUN * ELEM) + (size_t)t * BYTES;
       if (r < RPI && t * EPL < RUN) {
         if constexpr (BYTES == 4) { acc += *(const float*)p; }
-        else if constexpr (BYTES == 8) { acc += *(const double*)p; }
-        else { double2 v; __builtin_memcpy(&v, p, 16); acc += v.x + ((t * EPL + 1 < RUN) ? v.y : 0.0); }
+        else if constexpr (BYTES == 8) { float2 v; __builtin_memcpy(&v, p, 8); acc += v.x + v.y; }
+        else { float4 v; __builtin_memcpy(&v, p, 16); acc += v.x + v.y + v.z + v.w; }
       }
     }
   }
   if (acc == 123.456) out[0] = acc;
 }
-template <int BYTES, int RUN>
+template <int BYTES, int RUN, int ELEM>
 void run(const char* d, size_t window, const char* name, int contiguous) {
   double* out; hipMalloc(&out, 8);
   const int grid = 256 * 32, iters = 200;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  hipLaunchKernelGGL((k<BYTES, RUN>), dim3(grid), dim3(64), 0, 0, d, window, 10, out, contiguous);
-  hipEventRecord(a); hipLaunchKernelGGL((k<BYTES, RUN>), dim3(grid), dim3(64), 0, 0, d, window, iters, out, contiguous); hipEventRecord(b);
+  hipLaunchKernelGGL((k<BYTES, RUN, ELEM>), dim3(grid), dim3(64), 0, 0, d, window, 10, out, contiguous);
+  hipEventRecord(a); hipLaunchKernelGGL((k<BYTES, RUN, ELEM>), dim3(grid), dim3(64), 0, 0, d, window, iters, out, contiguous); hipEventRecord(b);
   hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
-  constexpr int ELEM = (BYTES == 4) ? 4 : 8; constexpr int EPL = BYTES / ELEM; constexpr int LPR = (RUN + EPL - 1) / EPL; constexpr int RPI = 64 / LPR;
+  constexpr int EPL = BYTES / ELEM; constexpr int LPR = (RUN + EPL - 1) / EPL; constexpr int RPI = 64 / LPR;
   double bytes = (double)grid * iters * 8 * RPI * RUN * ELEM;
   double instr = (double)grid * iters * 8;
   printf("%-44s window %8zu KB: %8.1f GB/s useful, %6.1f cycles/instr/CU (2.1GHz), %.2f ms\n", name, window >> 10, bytes / ms / 1e6,
@@ -47,13 +46,13 @@ void run(const char* d, size_t window, const char* name, int contiguous) {
 }
 int main() {
   size_t big = 1ull << 30; char* d; hipMalloc(&d, big); hipMemset(d, 0, big);
-  for (size_t w : {(size_t)16 << 10, (size_t)16 << 20, (size_t)1 << 30}) {
-    run<8, 27>(d, w, "8B/lane, runs of 27 doubles (current vals)", 0);
-    run<16, 27>(d, w, "16B/lane, runs of 27 doubles", 0);
-    run<4, 27>(d, w, "4B/lane, runs of 27 ints (current cols)", 0);
-    run<8, 32>(d, w, "8B/lane, runs of 32 doubles (aligned 256B)", 0);
-    run<8, 64>(d, w, "8B/lane, 64 contiguous doubles random start", 0);
-    run<16, 128>(d, w, "16B/lane, 128 contiguous doubles streaming", 1);
+  for (size_t w : {(size_t)16 << 20}) {
+    run<4, 27, 4>(d, w, "cols: 4B/lane, runs of 27 ints", 0);
+    run<8, 27, 4>(d, w, "cols: 8B/lane (2 ints, 4B-aligned), runs of 27", 0);
+    run<16, 27, 4>(d, w, "cols: 16B/lane (4 ints, 4B-aligned), runs of 27", 0);
+    run<8, 27, 8>(d, w, "vals: 8B/lane, runs of 27 doubles", 0);
+    run<16, 27, 8>(d, w, "vals: 16B/lane (2 doubles, 8B-aligned), runs of 27", 0);
+    run<16, 28, 8>(d, w, "vals: 16B/lane, runs of 28 doubles (16B-aligned)", 0);
   }
   return 0;
 }
