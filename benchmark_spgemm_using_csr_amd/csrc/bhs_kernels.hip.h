@@ -940,11 +940,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         const int row = dC.x, a0 = dC.y, a1 = dC.z;
         // ---- clear the table
 #pragma unroll
-        for (int s = lane * 4; s < TS; s += 256) {
-            *reinterpret_cast<int4*>(&sm.keys[s]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
-            if (NUM) {
-                *reinterpret_cast<double2*>(&sm.vals[s]) = make_double2(0.0, 0.0);
-                *reinterpret_cast<double2*>(&sm.vals[s + 2]) = make_double2(0.0, 0.0);
+        for (int k = 0; k < (TS + 255) / 256; ++k) {
+            const int s = k * 256 + lane * 4;
+            if (TS >= 256 || s < TS) {
+                *reinterpret_cast<int4*>(&sm.keys[s]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
+                if (NUM) {
+                    *reinterpret_cast<double2*>(&sm.vals[s]) = make_double2(0.0, 0.0);
+                    *reinterpret_cast<double2*>(&sm.vals[s + 2]) = make_double2(0.0, 0.0);
+                }
             }
         }
         int myNew = 0;
