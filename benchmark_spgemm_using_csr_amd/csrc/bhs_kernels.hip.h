@@ -749,6 +749,9 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
 #ifndef BHS_WPB
 #define BHS_WPB 1
 #endif
+#ifndef BHS_NT_STORES
+#define BHS_NT_STORES 0
+#endif
 // ask the register allocator for >= 6 waves per SIMD: the accumulator is latency-bound (LDS round trips),
 // measured -8 % on the numeric pass versus the 5 waves the unconstrained allocation reaches
 #ifndef BHS_WAVE_ATTR
@@ -877,8 +880,13 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const doubl
             unsigned slot;
             if constexpr (PACK32) { col = (int)(x[e] >> LOG2TS); slot = x[e] & ((1u << LOG2TS) - 1); }
             else { col = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
+#if BHS_NT_STORES
+            __builtin_nontemporal_store(col, &Cj[outBase + r]);
+            __builtin_nontemporal_store(vals[slot], &Cx[outBase + r]);
+#else
             Cj[outBase + r] = col;
             Cx[outBase + r] = vals[slot];
+#endif
         }
     }
 }
