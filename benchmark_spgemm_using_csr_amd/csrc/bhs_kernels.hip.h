@@ -1154,318 +1154,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
 }
 
 // ===========================================================================
-// Row-PAIR accumulator: two adjacent queue entries (usually adjacent rows of C)
-// per wavefront, processed as one "super-row".
-//
-// Why: the B gather is bound by L1 misses (profiles/r01_*_memory_pipe_pmc.txt:
-// texture-data unit 98 % busy, 68 % stalled on L2), and neighbouring rows of
-// FEM / stencil / banded matrices use mostly the SAME B rows (poisson27pt: a row
-// pair touches 36 distinct B rows, not 54).  Here lanes 0-31 hold the A entries
-// of row 0 and lanes 32-63 those of row 1; a 128-slot LDS claim table makes the
-// union of their B rows; every B row of the union is gathered ONCE and each
-// loaded element is inserted under the key (col << 1 | rowbit) into one shared
-// table, once per row that uses it, with that row's A value.  One compaction and
-// one register bitonic sort on (rowbit, col) leave row 0's entries followed by
-// row 1's, each ascending by column.  Everything else (row-pipelined metadata,
-// flat product mapping by end marks, batched loads, CAS-only probes, XCD-aware
-// persistent schedule) is as in k_row_wave.  Rows with more than 32 A entries
-// are walked in chunks of 32 per half.
-// ===========================================================================
-template <int TS2, bool NUM, bool PACK32>
-struct PairSmem {
-    using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
-    int keys[TS2];                       // (col << 1) | rowbit
-    double vals[NUM ? TS2 : 1];
-    packed_t packed[NUM ? TS2 : 2];
-    double sAvPair[NUM ? 64 : 1][2];     // per union entry: A value of row 0 / row 1
-    int sBase[64];
-    int sUse[64];                        // bit r set: row r uses this B row
-    int tags[128];                       // claim table: B row id
-    int tagIdx[128];                     // claim slot -> compacted union index
-    unsigned marks[2 * kMaxB];
-};
-
-template <int TS2, int LOG2TS2, bool NUM, bool PACK32>
-__global__ __launch_bounds__(64) BHS_WAVE_ATTR void k_row_pair(
-    const int4* __restrict__ desc, int qn,
-    const int* __restrict__ Aj, const double* __restrict__ Ax,
-    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx)
-{
-    using Smem = PairSmem<TS2, NUM, PACK32>;
-    using packed_t = typename Smem::packed_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
-    const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
-    constexpr int MAXB = NUM ? kMaxBNum : kMaxBSym;
-    constexpr int GRP = (MAXB % 3 == 0) ? 3 : 2;          // batches per insert group (x2 rows = probes in flight)
-
-    // XCD-aware persistent schedule over PAIRS of queue entries
-    const int nPairs = (qn + 1) >> 1;
-    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, perX = gridDim.x >> 3;
-    const int region = (nPairs + 7) >> 3;
-    const int pBeg = xcd * region;
-    const int pEnd = pBeg + region < nPairs ? pBeg + region : nPairs;
-    const int ps = pBeg + lb;
-    const int nIt = ps < pEnd ? (pEnd - ps + perX - 1) / perX : 0;
-    const int4 kNoRow = make_int4(-1, 0, 0, 0);
-    auto load_pair = [&](int it, int4& dA, int4& dB) {
-        dA = kNoRow; dB = kNoRow;
-        if (it < nIt) {
-            const int q = 2 * (ps + it * perX);
-            dA = desc[q];
-            if (q + 1 < qn) dB = desc[q + 1];
-        }
-    };
-    // this lane's descriptor of a pair and its first-chunk entry
-    auto my_of = [&](const int4& dA, const int4& dB) { return half ? dB : dA; };
-
-    // ---- software pipeline over pairs: descriptors (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
-    int4 dCa, dCb, d1a, d1b, d2a, d2b;
-    load_pair(0, dCa, dCb);
-    load_pair(1, d1a, d1b);
-    load_pair(2, d2a, d2b);
-    int cC = 0, c1 = 0;
-    double avC = 0.0, av1 = 0.0;
-    { const int4 my = my_of(dCa, dCb); if (l32 < my.z - my.y) { cC = Aj[my.y + l32]; if (NUM) avC = Ax[my.y + l32]; } }
-    { const int4 my = my_of(d1a, d1b); if (l32 < my.z - my.y) { c1 = Aj[my.y + l32]; if (NUM) av1 = Ax[my.y + l32]; } }
-    int b0C = 0, lenC = 0;
-    { const int4 my = my_of(dCa, dCb); if (l32 < my.z - my.y) { int2 be; __builtin_memcpy(&be, Bp + cC, 8); b0C = be.x; lenC = be.y - be.x; } }
-
-    for (int it = 0; it < nIt; ++it) {
-        // ---- prefetch for the pairs behind this one
-        int4 d3a, d3b;
-        load_pair(it + 3, d3a, d3b);
-        int c2 = 0;
-        double av2 = 0.0;
-        { const int4 my = my_of(d2a, d2b); if (l32 < my.z - my.y) { c2 = Aj[my.y + l32]; if (NUM) av2 = Ax[my.y + l32]; } }
-        int b01 = 0, len1 = 0;
-        { const int4 my = my_of(d1a, d1b); if (l32 < my.z - my.y) { int2 be; __builtin_memcpy(&be, Bp + c1, 8); b01 = be.x; len1 = be.y - be.x; } }
-
-        const int4 my = my_of(dCa, dCb);
-        const int myA0 = my.y, myNA = my.x >= 0 ? my.z - my.y : 0;
-        const int nA0 = dCa.z - dCa.y, nA1 = dCb.x >= 0 ? dCb.z - dCb.y : 0;
-        const int maxNA = nA0 > nA1 ? nA0 : nA1;
-        // ---- clear the table
-#pragma unroll
-        for (int k = 0; k < (TS2 + 255) / 256; ++k) {
-            const int s = k * 256 + lane * 4;
-            if (TS2 >= 256 || s < TS2) {
-                *reinterpret_cast<int4*>(&sm.keys[s]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
-                if (NUM) {
-                    *reinterpret_cast<double2*>(&sm.vals[s]) = make_double2(0.0, 0.0);
-                    *reinterpret_cast<double2*>(&sm.vals[s + 2]) = make_double2(0.0, 0.0);
-                }
-            }
-        }
-        int myNew0 = 0, myNew1 = 0;
-        for (int ck = 0; ck < maxNA; ck += 32) {
-            // ---- one A entry per lane: lanes 0-31 row 0, lanes 32-63 row 1
-            int c = cC, b0 = b0C, len = lenC;
-            double av = avC;
-            if (ck != 0) {                                   // rows with > 32 entries: later chunks, unpipelined
-                c = 0; b0 = 0; len = 0; av = 0.0;
-                if (ck + l32 < myNA) {
-                    c = Aj[myA0 + ck + l32];
-                    if (NUM) av = Ax[myA0 + ck + l32];
-                    int2 be;
-                    __builtin_memcpy(&be, Bp + c, 8);
-                    b0 = be.x;
-                    len = be.y - be.x;
-                }
-            }
-            // ---- union of the two rows' B rows: claim table
-            sm.tags[lane] = kEmpty;
-            sm.tags[lane + 64] = kEmpty;
-            sm.sUse[lane] = 0;
-            wave_sync();
-            bool owner = false;
-            unsigned th = 0;
-            if (len > 0) {
-                th = hash_col(c, 7);
-                for (;;) {
-                    const int old = atomicCAS(&sm.tags[th], kEmpty, c);
-                    if (old == kEmpty) { owner = true; break; }
-                    if (old == c) break;
-                    th = (th + 1) & 127;
-                }
-            }
-            const unsigned long long ownerMask = __ballot(owner);
-            const int jc = mbcnt64(ownerMask);              // compacted union index of an owner
-            wave_sync();
-            if (owner) sm.tagIdx[th] = jc;
-            wave_sync();
-            if (len > 0) {
-                const int j = sm.tagIdx[th];
-                atomicOr(&sm.sUse[j], 1 << half);
-                if (NUM) sm.sAvPair[j][half] = av;
-            }
-            const int olen = owner ? len : 0;
-            const int incl = wave_incl_scan_dpp(olen);
-            const int total = __builtin_amdgcn_readlane(incl, 63);   // products of the union
-            const int last = incl - 1;
-            if (owner) sm.sBase[jc] = b0 - (incl - olen);
-            wave_sync();
-            int done = 0;
-            for (int w0 = 0; w0 < total; w0 += 64 * MAXB) {
-                const int nb = (total - w0 + 63) >> 6;
-                if (lane < 2 * MAXB) sm.marks[lane] = 0;
-                wave_sync();
-                const int rel = last - w0;
-                if (owner && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
-                wave_sync();
-                int col[MAXB], jj[MAXB];
-                double bv[MAXB];
-                int cum = done;
-#pragma unroll
-                for (int u = 0; u < MAXB; ++u) {
-                    col[u] = kEmpty;
-                    jj[u] = 0;
-                    bv[u] = 0.0;
-                    if (u < nb) {
-                        const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
-                        const int p = w0 + u * 64 + lane;
-                        const int j = cum + mbcnt64(mk);
-                        cum += __popcll(mk);
-                        if (p < total) {
-                            const long long idx = (long long)sm.sBase[j] + p;
-                            col[u] = Bj[idx];
-                            jj[u] = j;
-                            if (NUM) bv[u] = Bx[idx];
-                        }
-                    }
-                }
-                done = cum;
-                // ---- inserts: element (col, bval) goes into the table once per row that uses its B row
-#pragma unroll
-                for (int g = 0; g < MAXB; g += GRP) {
-                    if (g < nb) {
-                        unsigned hh[2 * GRP];
-                        int cur[2 * GRP], key[2 * GRP];
-#pragma unroll
-                        for (int v = 0; v < 2 * GRP; ++v) {
-                            const int u = g + (v >> 1), r = v & 1;
-                            key[v] = kEmpty;
-                            hh[v] = 0;
-                            cur[v] = kEmpty;
-                            if (u < MAXB && col[u] != kEmpty && ((sm.sUse[jj[u]] >> r) & 1)) {
-                                key[v] = (col[u] << 1) | r;
-                                hh[v] = hash_col(key[v], LOG2TS2);
-                                cur[v] = atomicCAS(&sm.keys[hh[v]], kEmpty, key[v]);
-                            }
-                        }
-#pragma unroll
-                        for (int v = 0; v < 2 * GRP; ++v) {
-                            const int u = g + (v >> 1), r = v & 1;
-                            const int kv = key[v];
-                            if (kv != kEmpty) {
-                                bool fresh = cur[v] == kEmpty;
-                                if (!fresh && cur[v] != kv) {               // collision: linear probing
-                                    unsigned h = hh[v];
-                                    for (;;) {
-                                        h = (h + 1) & (TS2 - 1);
-                                        const int c2 = atomicCAS(&sm.keys[h], kEmpty, kv);
-                                        if (c2 == kEmpty) { fresh = true; break; }
-                                        if (c2 == kv) break;
-                                    }
-                                    hh[v] = h;
-                                }
-                                if (fresh) { if (r) ++myNew1; else ++myNew0; }
-                                if (NUM) unsafeAtomicAdd(&sm.vals[hh[v]], sm.sAvPair[jj[u]][r] * bv[u]);
-                            }
-                        }
-                    }
-                }
-            }
-            wave_sync();                                     // claim table / sUse / sBase are rewritten by the next chunk
-        }
-        wave_sync();
-        if (!NUM) {
-            myNew0 = wave_sum_dpp(myNew0);
-            myNew1 = wave_sum_dpp(myNew1);
-            if (lane == 0) {
-                cntOut[dCa.x] = myNew0;
-                if (dCb.x >= 0) cntOut[dCb.x] = myNew1;
-            }
-        } else {
-            // ---- compact occupied slots -> sort keys (rowbit, col | slot); row 0's entries sort first
-            int run = 0, run0 = 0;
-#pragma unroll
-            for (int s0 = 0; s0 < TS2; s0 += 64) {
-                const int s = s0 + lane;
-                const int key = sm.keys[s];
-                const bool valid = key != kEmpty;
-                const unsigned long long bal = __ballot(valid);
-                run0 += __popcll(__ballot(valid && !(key & 1)));
-                if (valid) {
-                    const unsigned rc = ((unsigned)(key & 1) << 31);
-                    packed_t pk;
-                    if constexpr (PACK32) pk = rc | ((unsigned)(key >> 1) << LOG2TS2) | (unsigned)s;
-                    else pk = ((unsigned long long)(rc | (unsigned)(key >> 1)) << 32) | (unsigned)s;
-                    sm.packed[run + mbcnt64(bal)] = pk;
-                }
-                run += __popcll(bal);
-            }
-            const int uniq = run, uniq0 = run0;
-            wave_sync();
-            const long long out0 = dCa.w, out1 = dCb.w;
-            auto emit = [&](packed_t x, int r) {
-                int colv;
-                unsigned slot;
-                if constexpr (PACK32) { colv = (int)((x & 0x7fffffffu) >> LOG2TS2); slot = x & ((1u << LOG2TS2) - 1); }
-                else { colv = (int)((unsigned)(x >> 32) & 0x7fffffffu); slot = (unsigned)x; }
-                const long long o = r < uniq0 ? out0 + r : out1 + (r - uniq0);
-                Cj[o] = colv;
-                Cx[o] = sm.vals[slot];
-            };
-            auto sort_regs = [&](auto EC) {
-                constexpr int E = decltype(EC)::value;
-                packed_t x[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = lane * E + e;
-                    x[e] = i < uniq ? sm.packed[i] : (packed_t)~(packed_t)0;
-                }
-                wave_bitonic_sort<packed_t, E>(x, lane);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int r = lane * E + e;
-                    if (r < uniq) emit(x[e], r);
-                }
-            };
-            if (uniq <= 64) sort_regs(std::integral_constant<int, 1>{});
-            else if (TS2 >= 128 && uniq <= 128) sort_regs(std::integral_constant<int, 2>{});
-            else if (TS2 >= 256 && uniq <= 256) sort_regs(std::integral_constant<int, 4>{});
-            else if (TS2 >= 512 && uniq <= 512) sort_regs(std::integral_constant<int, 8>{});
-            else if (TS2 >= 1024) {
-                int P = 1024;
-                while (P < uniq) P <<= 1;
-                for (int s = uniq + lane; s < P; s += 64) sm.packed[s] = (packed_t)~(packed_t)0;
-                wave_sync();
-                for (int kk = 2; kk <= P; kk <<= 1) {
-                    for (int j = kk >> 1; j > 0; j >>= 1) {
-                        for (int i = lane; i < (P >> 1); i += 64) {
-                            const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                            const int b = a | j;
-                            const bool up = (a & kk) == 0;
-                            const packed_t x = sm.packed[a], y = sm.packed[b];
-                            if ((x > y) == up) { sm.packed[a] = y; sm.packed[b] = x; }
-                        }
-                        wave_sync();
-                    }
-                }
-                for (int r = lane; r < uniq; r += 64) emit(sm.packed[r], r);
-            }
-        }
-        wave_sync();
-        // ---- rotate the pipeline
-        dCa = d1a; dCb = d1b; d1a = d2a; d1b = d2b; d2a = d3a; d2b = d3b;
-        cC = c1; avC = av1; c1 = c2; av1 = av2;
-        b0C = b01; lenC = len1;
-    }
-}
-
-// ===========================================================================
 // Quarter-wave accumulator for tiny rows (the reference's ESC_2heap territory,
 // bhsparse_cuda.h:653-722: poisson5pt rows have 25 products -> 13 entries).
 // FOUR rows per wavefront, 16 lanes each: a DPP "row" is 16 lanes, so the

@@ -132,7 +132,6 @@ struct bhs_handle {
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
     int wgPerCU = 0;                     // tuning hook: persistent workgroups per CU (0 = occupancy API)
-    int pairRows = 0;                    // wave bins: two adjacent rows per wavefront (k_row_pair); measured slower, off
     int symLoadPct = 75, numLoadPct = 75; // max table load factor (percent) that decides a row's bin
     int maxTableLog2 = 15;
     // timing
@@ -315,47 +314,6 @@ int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     }
 }
 
-template <int LOG2TS2, bool NUM, bool PACK32>
-int launch_row_pair_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
-{
-    constexpr int TS2 = 1 << LOG2TS2;
-    auto kern = k_row_pair<TS2, LOG2TS2, NUM, PACK32>;
-    const size_t smem = sizeof(PairSmem<TS2, NUM, PACK32>);
-    static int perCU = 0;
-    if (!perCU) {
-        if (smem > 48 * 1024)
-            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        int nb = 0;
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, smem));
-        perCU = std::max(1, std::min(nb, 32));
-    }
-    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
-    long long grid = std::min<long long>(((long long)qn + 1) / 2, (long long)h->numCU * useCU);
-    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->stream, queue, qn, h->dAj, h->dAx, h->dBp,
-                       h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
-    BHS_HIP(hipGetLastError());
-    return BHS_SUCCESS;
-}
-
-// Row-pair kernel for a wave bin whose single-row table has 2^LOG2TS slots (pair table: twice that).
-template <int LOG2TS, bool NUM>
-int launch_row_pair(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
-{
-    if constexpr (NUM) {
-        if ((long long)h->n <= (1LL << (31 - (LOG2TS + 1))) && !h->noPack32)
-            return launch_row_pair_impl<LOG2TS + 1, true, true>(h, queue, qn, CpOrCnt);
-        return launch_row_pair_impl<LOG2TS + 1, true, false>(h, queue, qn, CpOrCnt);
-    } else {
-#ifdef BHS_PAIR_SYM_SHRINK   /* experiment only: optimistic table, no overflow protection */
-        return launch_row_pair_impl<(LOG2TS + 1 - BHS_PAIR_SYM_SHRINK < 7 ? 7 : LOG2TS + 1 - BHS_PAIR_SYM_SHRINK), false, false>(h, queue, qn, CpOrCnt);
-#else
-        return launch_row_pair_impl<LOG2TS + 1, false, false>(h, queue, qn, CpOrCnt);
-#endif
-    }
-}
-
 template <bool NUM, bool PACK32>
 int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
@@ -394,13 +352,6 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_CASE(LG, BL, W)
-    // two adjacent rows per wavefront sharing one gather of their common B rows (keys carry a row bit)
-#define BHS_PAIR(LG) \
-    if (lg == LG && c.block == 64 && !win && h->forcePath != 2 && h->pairRows && (long long)h->n <= (1LL << 30)) \
-        return launch_row_pair<LG, NUM>(h, queue, qn, CpOrCnt)
-    BHS_PAIR(6); BHS_PAIR(7); BHS_PAIR(8); BHS_PAIR(9);
-    if constexpr (!NUM) { BHS_PAIR(10); }
-#undef BHS_PAIR
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
     BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);
@@ -936,7 +887,6 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
-    if (!strcmp(key, "pair_rows")) { h->pairRows = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
