@@ -287,6 +287,8 @@ def main():
         "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
         "stage_ms": [round(float(x) / args.steps, 4) for x in stage],
         "host_ms_per_step_spgemm": round(t_compute / args.steps, 4),
+        "gather_ms_per_step": round(ms_per_step - t_compute / args.steps, 4) if (world > 1 or force_gather) else 0.0,
+        "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),
         "pipeline_compulsory_bytes": int(bytes_alg_total),
         "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
         "kernels_ms_per_step": {k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items())},

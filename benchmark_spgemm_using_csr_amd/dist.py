@@ -7,9 +7,10 @@ bhsparse_cuda.h:100-101).
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm; "gloo"
 on CPU tensors for the world_size-2 tests).  The only data-path collective is
 the all-gatherv: message sizes differ per rank (nnz of each row block), so it
-is issued as one uneven all_gather (RCCL lowers it to a group of per-root
-broadcasts, which on the fully connected xGMI topology run on all 7 links at
-once) after a tiny all_gather of the per-rank sizes.
+is issued as one group of point-to-point transfers (ncclGroupStart / ncclSend /
+ncclRecv / ncclGroupEnd under torch's batch_isend_irecv): every GPU sends its
+block straight to each of its 7 peers over the fully connected xGMI links,
+after a 16-byte all_gather of the per-rank sizes.
 """
 import torch
 import torch.distributed as dist
@@ -23,24 +24,35 @@ def row_block(m, rank, world):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
-def _uneven_all_gather(full, local, sizes, offsets, group):
-    """full[offsets[r]:offsets[r]+sizes[r]] <- rank r's `local` on every rank."""
-    world = len(sizes)
-    outs = [full[offsets[r]:offsets[r] + sizes[r]] for r in range(world)]
-    if dist.get_backend(group) == "gloo" or any(s == 0 for s in sizes):
-        # gloo has no uneven all_gather; zero-size messages are skipped: per-root broadcasts
-        works = []
-        for r in range(world):
-            if sizes[r] == 0:
-                continue
-            if r == dist.get_rank(group):
-                outs[r].copy_(local)
-            works.append(dist.broadcast(outs[r], src=dist.get_global_rank(group, r) if group else r,
-                                        group=group, async_op=True))
-        for w in works:
+def _all_gatherv(parts, group):
+    """parts = [(full, local, sizes, offsets), ...]: for every part,
+    full[offsets[r]:offsets[r]+sizes[r]] <- rank r's `local`, on every rank.
+
+    Issued as ONE group of point-to-point transfers (every rank sends its blocks straight to every
+    peer and receives every peer's blocks in place): on RCCL this is ncclGroupStart / ncclSend /
+    ncclRecv / ncclGroupEnd, i.e. 7 simultaneous direct xGMI transfers per GPU on a fully connected
+    node, with no staging copy and no padding for the uneven block sizes.  gloo runs the same ops."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    for full, local, sizes, offsets in parts:
+        if sizes[rank]:
+            full[offsets[rank]:offsets[rank] + sizes[rank]].copy_(local[:sizes[rank]])
+    if world == 1:
+        return
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    ops = []
+    for step in range(1, world):                       # staggered peers: rank r talks to r+step / r-step
+        dst = (rank + step) % world
+        src = (rank - step) % world
+        for full, local, sizes, offsets in parts:      # same part order on both ends of every pair
+            if sizes[rank]:
+                ops.append(dist.P2POp(dist.isend, local[:sizes[rank]], peer(dst), group=group))
+            if sizes[src]:
+                ops.append(dist.P2POp(dist.irecv, full[offsets[src]:offsets[src] + sizes[src]], peer(src),
+                                      group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
             w.wait()
-    else:
-        dist.all_gather(outs, local, group=group)
 
 
 def allgatherv_csr(m_total, local_rowptr, local_col, local_val, group=None, out=None):
@@ -79,10 +91,9 @@ def allgatherv_csr(m_total, local_rowptr, local_col, local_val, group=None, out=
         col = torch.empty(nnz_total, dtype=torch.int32, device=dev)
         val = torch.empty(nnz_total, dtype=torch.float64, device=dev)
     # 2. the all-gatherv proper (values, columns), plus row pointers rebased by the rank's nnz offset
-    _uneven_all_gather(val, local_val[:nnz_local], nnzs, nnz_off, group)
-    _uneven_all_gather(col, local_col[:nnz_local], nnzs, nnz_off, group)
     rebased = (local_rowptr[:m_local] + nnz_off[rank]).to(torch.int32)
-    _uneven_all_gather(rowptr, rebased, rows, row_off, group)
+    _all_gatherv([(val, local_val[:nnz_local], nnzs, nnz_off), (col, local_col[:nnz_local], nnzs, nnz_off),
+                  (rowptr, rebased, rows, row_off)], group)
     rowptr[m_total] = nnz_total
     return rowptr, col, val, {"rows": rows, "nnz": nnzs}
 
