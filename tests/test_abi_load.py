@@ -31,7 +31,8 @@ def test_code_object_is_gfx950():
     assert os.path.exists(so)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob
-    assert b"k_row_hash" in blob      # the accumulator kernels are in the fat binary
+    for kern in (b"k_row_wave", b"k_row_quad", b"k_row_block", b"k_row_spa", b"k_upper_bound"):
+        assert kern in blob           # the accumulator kernels are in the fat binary
 
 
 def test_strerror_and_version(hiplib):
