@@ -749,6 +749,9 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
 #ifndef BHS_WPB
 #define BHS_WPB 1
 #endif
+#ifndef BHS_XCD_CHUNK
+#define BHS_XCD_CHUNK 2048
+#endif
 #ifndef BHS_NT_STORES
 #define BHS_NT_STORES 0
 #endif
@@ -910,21 +913,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     constexpr int MAXB = NUM ? kMaxBNum : kMaxBSym;
     constexpr int GRP = (MAXB % 4 == 0) ? 4 : (MAXB % 3 == 0 ? 3 : 2);                   // probes in flight per insert group
 
-    // XCD-aware persistent schedule (gridDim.x is a multiple of 8)
-    // the WPB waves of a workgroup take consecutive queue entries, so that rows which share B rows
-    // run on the same CU at the same time and meet in its L1
+    // XCD-aware persistent schedule (gridDim.x is a multiple of 8; block b runs on XCD b % 8, tools/xcc_probe.hip).
+    // The queue is cut into chunks of kChunk consecutive entries and chunk k belongs to XCD k % 8: inside a
+    // chunk neighbouring rows share B rows through that XCD's private L2, while all eight XCDs stay within the
+    // same few thousand rows of the matrix, so the B rows reused across grid planes form ONE working set in the
+    // 256 MB Infinity Cache instead of eight.
+    constexpr int kChunk = BHS_XCD_CHUNK;
     const int xcd = blockIdx.x & 7, lb = (blockIdx.x >> 3) * WPB + wave, perX = (gridDim.x >> 3) * WPB;
-    const int region = (qn + 7) >> 3;
-    const int qBeg = xcd * region;
-    const int qEnd = qBeg + region < qn ? qBeg + region : qn;
-    const int qs = qBeg + lb;
-    const int nIt = qs < qEnd ? (qEnd - qs + perX - 1) / perX : 0;
+    const int nChunks = (qn + kChunk - 1) / kChunk;
+    int positions = 0;                                   // queue entries that belong to this XCD
+    if (nChunks > xcd) {
+        positions = ((nChunks - xcd + 7) >> 3) * kChunk;
+        if (((nChunks - 1) & 7) == xcd) positions -= nChunks * kChunk - qn;
+    }
+    const int nIt = lb < positions ? (positions - lb + perX - 1) / perX : 0;
+    auto q_of = [&](int it) {                             // it-th entry of this wave (it < nIt)
+        const int t = lb + it * perX;
+        return (((t / kChunk) << 3) + xcd) * kChunk + (t % kChunk);
+    };
     const int4 kNoRow = make_int4(-1, 0, 0, 0);
 
     // ---- software pipeline over rows: descriptor (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
-    int4 dC = nIt > 0 ? desc[qs] : kNoRow;
-    int4 d1 = nIt > 1 ? desc[qs + perX] : kNoRow;
-    int4 d2 = nIt > 2 ? desc[qs + 2 * perX] : kNoRow;
+    int4 dC = nIt > 0 ? desc[q_of(0)] : kNoRow;
+    int4 d1 = nIt > 1 ? desc[q_of(1)] : kNoRow;
+    int4 d2 = nIt > 2 ? desc[q_of(2)] : kNoRow;
     int cC = 0, c1 = 0;
     double avC = 0.0, av1 = 0.0;
     if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
 #endif
     for (int it = 0; it < nIt; ++it) {
         // ---- prefetch for the rows behind this one
-        const int4 d3 = (it + 3 < nIt) ? desc[qs + (it + 3) * perX] : kNoRow;
+        const int4 d3 = (it + 3 < nIt) ? desc[q_of(it + 3)] : kNoRow;
         int c2 = 0;
         double av2 = 0.0;
         if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
