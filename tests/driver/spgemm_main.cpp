@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../benchmark_spgemm_using_csr_amd/host/bhsparse.h"
+#include "../../benchmark_spgemm_using_csr_amd/host/csr_sort.h"
 #include "../../benchmark_spgemm_using_csr_amd/host/mtx_reader.h"
 #include "../../oracle/ref_spgemm_oracle.h"
 
@@ -121,6 +122,9 @@ static int benchmark_spgemm(const char *dataset_name1, const char *dataset_name2
         cout << " B: " << dataset_name2 << endl;
         if (read_matrix_market(dataset_name2, B, &msg)) { cout << msg << endl; return -10; }
         if (A.num_cols != B.num_rows) { cout << "dimension mismatch" << endl; return -11; }
+        // main.cu:62-64 (the reader already sorts; kept so that the call sequence is the reference's)
+        csr_sort_indices<index_type, value_type>(A.num_rows, A.row_offsets.data(), A.column_indices.data(), A.values.data());
+        csr_sort_indices<index_type, value_type>(B.num_rows, B.row_offsets.data(), B.column_indices.data(), B.values.data());
     }
     if (!opt.keepvalues) {            // main.cu:79-94, with a fixed seed instead of time(NULL)
         fill_values(A.values, opt.seed, 0);

@@ -31,6 +31,38 @@ def test_facade_keeps_reference_signatures():
     assert "hip_runtime" not in src          # host code carries no HIP headers
 
 
+def test_host_csr_sort_indices_matches_oracle(oracle, tmp_path):
+    """host/csr_sort.h (signature of ref_spgemm::csr_sort_indices, ref_spgemm.h:37-62) against the oracle's."""
+    import numpy as np
+    src = tmp_path / "t.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <vector>
+#include "%s/benchmark_spgemm_using_csr_amd/host/csr_sort.h"
+int main() {
+    int n; if (scanf("%%d", &n) != 1) return 1;
+    std::vector<int> Ap(n + 1); for (auto &x : Ap) if (scanf("%%d", &x) != 1) return 1;
+    std::vector<int> Aj(Ap[n]); std::vector<double> Ax(Ap[n]);
+    for (int i = 0; i < Ap[n]; ++i) if (scanf("%%d %%lf", &Aj[i], &Ax[i]) != 2) return 1;
+    csr_sort_indices<int, double>(n, Ap.data(), Aj.data(), Ax.data());
+    for (int i = 0; i < Ap[n]; ++i) printf("%%d %%.17g\\n", Aj[i], Ax[i]);
+    return 0;
+}''' % ROOT)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), str(src)])
+    rng = np.random.default_rng(2)
+    lens = rng.integers(0, 40, 25)
+    rp = np.zeros(26, np.int32); rp[1:] = np.cumsum(lens)
+    col = np.concatenate([rng.permutation(200)[:L] for L in lens]).astype(np.int32)
+    val = rng.standard_normal(len(col))
+    inp = "25\n" + " ".join(map(str, rp)) + "\n" + "\n".join("%d %.17g" % (c, v) for c, v in zip(col, val)) + "\n"
+    out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, check=True).stdout.split()
+    got_c = np.array(out[0::2], np.int32); got_v = np.array(out[1::2], np.float64)
+    c2, v2 = col.copy(), val.copy()
+    oracle.csr_sort_indices(rp, c2, v2)
+    assert np.array_equal(got_c, c2) and np.array_equal(got_v, v2)
+
+
 def test_driver_builds_and_fails_cleanly_without_gpu(driver):
     import torch
     if torch.cuda.is_available():
