@@ -455,7 +455,8 @@ int run_pipeline(bhs_handle* h)
     unsigned long long tot;
     memcpy(&tot, hs + S_TOTAL_CT, 8);
     h->nnzCt = (long long)tot;
-    BHS_HIP(hipMemcpyAsync(small + S_SYM_START, symStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+    memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
+    BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
         long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
         BHS_TRY(timed_begin(h, "fill_queues", &ep));
@@ -510,7 +511,8 @@ int run_pipeline(bhs_handle* h)
     }
     BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
     BHS_TRY(ensure(h, h->Cx, sizeof(double) * (size_t)std::max<long long>(nnzC, 1)));
-    BHS_HIP(hipMemcpyAsync(small + S_NUM_START, numStart, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+    memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
+    BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
         long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
         BHS_TRY(timed_begin(h, "fill_queues", &ep));
@@ -654,7 +656,7 @@ int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
     if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evScanDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evCopyDone, hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
-    if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * S_SMALL_INTS, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * (S_SMALL_INTS + 2 * kMaxBins), hipHostMallocDefault) != hipSuccess) {
         delete h;
         return BHS_ERR_ALLOC;
     }
