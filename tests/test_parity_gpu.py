@@ -262,6 +262,41 @@ def test_hub_row_power_law(oracle):
     _check(oracle, m, m, m, (rp, col, valf), (rp, col, valf), exact=False)
 
 
+def test_huge_column_space():
+    """n = 2^31 - 1 columns: column indices up to INT_MAX - 1, 64-bit sort keys, dense accumulator
+    impossible (falls back to column windows).  Checked against a numpy reference built here because
+    the oracle's dense marker array would need 16 GB per thread."""
+    rng = np.random.default_rng(9)
+    n = 2 ** 31 - 1
+    k = 300
+    lensB = rng.integers(1, 60, k)
+    lensB[:3] = 9000                                         # three long B rows -> one C row beyond the LDS tables
+    Bp = np.zeros(k + 1, np.int64); np.cumsum(lensB, out=Bp[1:])
+    Bj = np.concatenate([np.sort(rng.choice(n // 7, L, replace=False).astype(np.int64) * 7 + (n - 1) % 7)
+                         for L in lensB]).astype(np.int32)
+    Bj[-1] = n - 1                                           # the largest legal column
+    for j in range(k):
+        Bj[Bp[j]:Bp[j + 1]].sort()
+    Bx = rng.integers(1, 10, len(Bj)).astype(np.float64)
+    rowsA = [np.array([0, 1, 2, 5, 9]), np.array([k - 1]), np.empty(0, np.int64), np.arange(3, 40)]
+    Ap = np.zeros(len(rowsA) + 1, np.int32); Ap[1:] = np.cumsum([len(r) for r in rowsA])
+    Aj = np.concatenate(rowsA).astype(np.int32)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    Cp, Cj, Cx, info = spgemm_csr(len(rowsA), k, n, Ap, Aj, Ax, Bp.astype(np.int32), Bj, Bx)
+    # reference: per row, accumulate products in a dict-free numpy way
+    exp_ptr, exp_col, exp_val = [0], [], []
+    for i in range(len(rowsA)):
+        cols = np.concatenate([Bj[Bp[j]:Bp[j + 1]] for j in Aj[Ap[i]:Ap[i + 1]]] + [np.empty(0, np.int32)])
+        vals = np.concatenate([Ax[Ap[i] + t] * Bx[Bp[j]:Bp[j + 1]] for t, j in enumerate(Aj[Ap[i]:Ap[i + 1]])] +
+                              [np.empty(0)])
+        u, inv = np.unique(cols, return_inverse=True)
+        exp_col.append(u); exp_val.append(np.bincount(inv, weights=vals, minlength=len(u)))
+        exp_ptr.append(exp_ptr[-1] + len(u))
+    assert Cp.tolist() == exp_ptr
+    assert np.array_equal(Cj, np.concatenate(exp_col)) and np.array_equal(Cx, np.concatenate(exp_val))
+    assert Cj.max() == n - 1 and np.diff(Cp).max() > 6144
+
+
 def test_repeated_spgemm_and_data_swap(oracle):
     """One handle, several multiplies and data sets: pooled workspace must not leak state."""
     plats = [False] * bhmod.NUM_PLATFORMS
