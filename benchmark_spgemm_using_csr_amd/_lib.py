@@ -50,33 +50,40 @@ SYMBOLS = {
     "bhs_version": (C.c_char_p, []),
 }
 
+# value_type float build of the same sources (-DBHS_VALUE_FLOAT; README.md:84-86 of the reference)
+SO_PATH_F32 = os.path.join(CSRC, "libbhsparse_hip_f32.so")
 _lib = None
+_libs = {}
 
 
 def build(force=False):
-    """Compile libbhsparse_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("bhsparse_hip.hip", "bhs_kernels.hip.h")] + [HEADER]
-    stale = (not os.path.exists(SO_PATH) or
-             any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs))
+    """Compile libbhsparse_hip.so and libbhsparse_hip_f32.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_wave.hip.h")] + [HEADER]
+    outs = [os.path.join(CSRC, "libbhsparse_hip.so"), SO_PATH_F32]
+    stale = any(not os.path.exists(o) or any(os.path.getmtime(s) > os.path.getmtime(o) for s in srcs) for o in outs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j2"] + (["-B"] if force else []))
     return SO_PATH
 
 
-def load():
+def load(f32=False):
+    """The double library (default) or the float one.  Raises if it is not built: no fallback."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(SO_PATH):
+    path = SO_PATH_F32 if f32 else SO_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise ImportError(
-                "libbhsparse_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
-                "g.build()'` or `make -C %s`. There is no CPU fallback." % (SO_PATH, CSRC))
-        L = C.CDLL(SO_PATH)
+                "%s is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C %s`. There is no CPU fallback." % (os.path.basename(path), path, CSRC))
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)      # AttributeError if the library does not export it
             f.restype = res
             f.argtypes = args
-        _lib = L
-    return _lib
+        _libs[path] = L
+    if not f32:
+        _lib = _libs[path]
+    return _libs[path]
 
 
 def strerror(code):

@@ -37,6 +37,25 @@ __device__ unsigned long long g_phase_cycles[16];
 
 namespace bhs {
 
+// value_type of the matrices: double (default, SpGEMM_cuda/common.h:31) or float when the library is built
+// with -DBHS_VALUE_FLOAT (the reference's other supported build, README.md:84-86)
+#ifdef BHS_VALUE_FLOAT
+using value_t = float;
+#else
+using value_t = double;
+#endif
+
+// zero four consecutive LDS value slots (16-byte aligned start)
+__device__ __forceinline__ void clear4(value_t* p)
+{
+    if constexpr (sizeof(value_t) == 8) {
+        *reinterpret_cast<double2*>(p) = make_double2(0.0, 0.0);
+        *reinterpret_cast<double2*>(p + 2) = make_double2(0.0, 0.0);
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 constexpr int kEmpty = -1;          // empty hash slot (column indices are >= 0)
 constexpr int kMaxBins = 16;
 
@@ -378,8 +397,8 @@ __global__ __launch_bounds__(256) void k_check_sorted(int k, const int* __restri
 template <int TS, int BLOCK, bool NUM>
 struct BlockSmem {
     int keys[TS];
-    double vals[NUM ? TS : 1];
-    double sAv[NUM ? BLOCK : 1];
+    value_t vals[NUM ? TS : 1];
+    value_t sAv[NUM ? BLOCK : 1];
     int sIncl[BLOCK];
     int sBase[BLOCK];
     int wtot[BLOCK / 64];
@@ -389,10 +408,10 @@ struct BlockSmem {
 template <int TS, int LOG2TS, int BLOCK, bool NUM>
 __global__ __launch_bounds__(BLOCK) void k_row_block(
     const int4* __restrict__ desc, int qn, int ncolsB, int bSorted,
-    const int* __restrict__ Aj, const double* __restrict__ Ax,
-    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
+    const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     const int* __restrict__ ubArr,          // symbolic: per-row upper bound (first window guess)
-    int* __restrict__ CpOrCnt, int* __restrict__ Cj, double* __restrict__ Cx,
+    int* __restrict__ CpOrCnt, int* __restrict__ Cj, value_t* __restrict__ Cx,
     int* __restrict__ errFlag, int* __restrict__ ticket)
 {
     static_assert((1 << LOG2TS) == TS, "table size must be 2^LOG2TS");
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                 // ---- one A entry per lane, restricted to the column window
                 const int e = ca + tid;
                 int b0 = 0, len = 0;
-                double av = 0.0;
+                value_t av = 0.0;
                 if (e < a1) {
                     const int c = Aj[e];
                     if (NUM) av = Ax[e];
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 
                 for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
                     int col[U];
-                    double pv[U];
+                    value_t pv[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int p = p0 + u * BLOCK + tid;
@@ -545,7 +564,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                             const unsigned x = (unsigned)sm.keys[a], y = (unsigned)sm.keys[b];
                             if ((x > y) == up && x != y) {
                                 sm.keys[a] = (int)y; sm.keys[b] = (int)x;
-                                const double va = sm.vals[a], vb = sm.vals[b];
+                                const value_t va = sm.vals[a], vb = sm.vals[b];
                                 sm.vals[a] = vb; sm.vals[b] = va;
                             }
                         }
@@ -581,12 +600,12 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 template <int BLOCK, bool NUM>
 __global__ __launch_bounds__(BLOCK) void k_row_spa(
     const int4* __restrict__ desc, int qn, int ncolsB,
-    const int* __restrict__ Aj, const double* __restrict__ Ax,
-    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx,
-    int* __restrict__ ticket, double* __restrict__ spaBase, unsigned* __restrict__ bitsBase)
+    const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx,
+    int* __restrict__ ticket, value_t* __restrict__ spaBase, unsigned* __restrict__ bitsBase)
 {
-    __shared__ double sAv[NUM ? BLOCK : 1];
+    __shared__ value_t sAv[NUM ? BLOCK : 1];
     __shared__ int sIncl[BLOCK];
     __shared__ int sBase[BLOCK];
     __shared__ int wtot[BLOCK / 64];
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
     constexpr int U = 4, NW = BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nWords = (ncolsB + 31) >> 5;
-    double* spa = NUM ? spaBase + (size_t)blockIdx.x * (size_t)ncolsB : nullptr;
+    value_t* spa = NUM ? spaBase + (size_t)blockIdx.x * (size_t)ncolsB : nullptr;
     unsigned* bits = bitsBase + (size_t)blockIdx.x * (size_t)nWords;
 
     for (;;) {
@@ -609,7 +628,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
         for (int ca = a0; ca < a1; ca += BLOCK) {
             const int e = ca + tid;
             int b0 = 0, len = 0;
-            double av = 0.0;
+            value_t av = 0.0;
             if (e < a1) {
                 const int c = Aj[e];
                 if (NUM) av = Ax[e];
@@ -704,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
             const long long base = d.w;
             for (int r0 = 0; r0 < rowCount; r0 += BLOCK * U) {
                 int c[U];
-                double v[U];
+                value_t v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int r = r0 + u * BLOCK + tid;
@@ -793,11 +812,11 @@ template <int TS, bool NUM, bool PACK32>
 struct WaveSmem {
     using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
     int keys[TS];
-    double vals[NUM ? TS : 1];
+    value_t vals[NUM ? TS : 1];
     packed_t packed[NUM ? TS : 2];
-    double sAv[NUM ? 64 : 1];
+    value_t sAv[NUM ? 64 : 1];
     int sBase[64];
-    unsigned marks[2 * kMaxB];
+    alignas(8) unsigned marks[2 * kMaxB];   // read as 64-bit words
 };
 
 template <typename T>
@@ -864,8 +883,8 @@ __device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
 }
 
 template <int LOG2TS, bool PACK32, int E, typename T>
-__device__ __forceinline__ void wave_sort_and_store(const T* packed, const double* vals, int uniq, int lane,
-                                                    int* __restrict__ Cj, double* __restrict__ Cx,
+__device__ __forceinline__ void wave_sort_and_store(const T* packed, const value_t* vals, int uniq, int lane,
+                                                    int* __restrict__ Cj, value_t* __restrict__ Cx,
                                                     long long outBase)
 {
     T x[E];
@@ -897,9 +916,9 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const doubl
 template <int TS, int LOG2TS, bool NUM, bool PACK32>
 __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     const int4* __restrict__ desc, int qn,
-    const int* __restrict__ Aj, const double* __restrict__ Ax,
-    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx)
+    const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
 {
     // measurement-only ablation mask, compile time (tools/build_variants.sh builds variants with -DBHS_ABL=..):
     // 1 no value atomics, 2 no sort, 4 no inserts, 8 no stores, 16 no colIndB load, 32 no valB load, 64 no sAv read
@@ -938,7 +957,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     int4 d1 = nIt > 1 ? desc[q_of(1)] : kNoRow;
     int4 d2 = nIt > 2 ? desc[q_of(2)] : kNoRow;
     int cC = 0, c1 = 0;
-    double avC = 0.0, av1 = 0.0;
+    value_t avC = 0.0, av1 = 0.0;
     if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
     if (lane < d1.z - d1.y) { c1 = Aj[d1.y + lane]; if (NUM) av1 = Ax[d1.y + lane]; }
     int b0C = 0, lenC = 0;
@@ -952,7 +971,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         // ---- prefetch for the rows behind this one
         const int4 d3 = (it + 3 < nIt) ? desc[q_of(it + 3)] : kNoRow;
         int c2 = 0;
-        double av2 = 0.0;
+        value_t av2 = 0.0;
         if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
         int b01 = 0, len1 = 0;
         if (lane < d1.z - d1.y) { b01 = Bp[c1]; len1 = Bp[c1 + 1] - b01; }
@@ -974,7 +993,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         for (int ca = a0; ca < a1; ca += 64) {
             // ---- one A entry per lane: B row extent, flat product offsets
             int b0 = b0C, len = lenC;
-            double av = avC;
+            value_t av = avC;
             if (ca != a0) {                                   // rows with > 64 entries: later chunks, unpipelined
                 const int ea = ca + lane;
                 b0 = 0; len = 0; av = 0.0;
@@ -1005,7 +1024,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
                 wave_sync();
                 int col[MAXB];
-                double pv[MAXB];
+                value_t pv[MAXB];
                 int cum = done;
                 // ---- all loads of the window first
 #pragma unroll
@@ -1022,7 +1041,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                             if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
                             else col[u] = Bj[idx];
                             if (NUM) {
-                                const double avj = (abl & 64) ? 1.0 : sm.sAv[j];
+                                const value_t avj = (abl & 64) ? 1.0 : sm.sAv[j];
                                 pv[u] = (abl & 32) ? avj : avj * Bx[idx];
                             }
                         }
@@ -1179,9 +1198,9 @@ template <bool NUM, bool PACK32>
 struct QuadSmem {
     using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
     int keys[4][64];
-    double vals[NUM ? 4 : 1][NUM ? 64 : 1];
+    value_t vals[NUM ? 4 : 1][NUM ? 64 : 1];
     packed_t packed[NUM ? 4 : 1][NUM ? 64 : 2];
-    double sAv[NUM ? 4 : 1][NUM ? 16 : 1];
+    value_t sAv[NUM ? 4 : 1][NUM ? 16 : 1];
     int sBase[4][16];
     unsigned long long marks[4];
 };
@@ -1189,9 +1208,9 @@ struct QuadSmem {
 template <bool NUM, bool PACK32>
 __global__ __launch_bounds__(64) void k_row_quad(
     const int4* __restrict__ desc, int qn,
-    const int* __restrict__ Aj, const double* __restrict__ Ax,
-    const int* __restrict__ Bp, const int* __restrict__ Bj, const double* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, double* __restrict__ Cx)
+    const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
 {
     using Smem = QuadSmem<NUM, PACK32>;
     using packed_t = typename Smem::packed_t;
@@ -1215,7 +1234,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
         const int nA = d.x >= 0 ? d.z - d.y : 0;
         // ---- one A entry per lane of the quarter
         int b0 = 0, len = 0;
-        double av = 0.0;
+        value_t av = 0.0;
         if (l16 < nA) {
             const int c = Aj[d.y + l16];
             if (NUM) av = Ax[d.y + l16];
@@ -1261,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
             wave_sync();
             const unsigned long long mk = sm.marks[g];
             int col[4];
-            double pv[4];
+            value_t pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 col[u] = kEmpty;

@@ -109,7 +109,7 @@ struct bhs_handle {
     bool hasData = false, ownAB = false, hasC = false;
     int m = 0, k = 0, n = 0, nnzA = 0, nnzB = 0;
     const int *dAp = nullptr, *dAj = nullptr, *dBp = nullptr, *dBj = nullptr;
-    const double *dAx = nullptr, *dBx = nullptr;
+    const value_t *dAx = nullptr, *dBx = nullptr;
     DevBuf ownA[3], ownB[3];
     int bSorted = 1;
     int logL = 5, ubG = 8;
@@ -231,7 +231,7 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     long long grid = std::max<long long>(1, std::min<long long>((long long)qn, (long long)h->numCU * perCU));
     BHS_HIP(hipMemsetAsync((int*)h->small.p + S_TICKET, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->stream, queue, qn, h->n, h->bSorted, h->dAj,
-                       h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p,
+                       h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
                        (int*)h->small.p + S_ERR, (int*)h->small.p + S_TICKET);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -245,15 +245,15 @@ int ensure_spa(bhs_handle* h)
     if (h->spaCols == h->n && h->spaSlots > 0 && !h->spaDirty) return BHS_SUCCESS;
     size_t freeB = 0, totalB = 0;
     BHS_HIP(hipMemGetInfo(&freeB, &totalB));
-    const size_t perSlot = n * sizeof(double) + nWords * sizeof(unsigned);
+    const size_t perSlot = n * sizeof(value_t) + nWords * sizeof(unsigned);
     long long slots = (long long)(std::min(totalB / 16, freeB / 2) / perSlot);
     slots = std::min<long long>(slots, h->spaMaxSlots > 0 ? (long long)h->spaMaxSlots : (long long)h->numCU);   // 1 per CU measured best
     if (slots < 8) { h->spaSlots = 0; return BHS_SUCCESS; }       // too wide: the column-window path stays in charge
     if (h->spaCols != h->n || h->spaSlots != (int)slots) {
-        BHS_TRY(ensure(h, h->spaVals, (size_t)slots * n * sizeof(double)));
+        BHS_TRY(ensure(h, h->spaVals, (size_t)slots * n * sizeof(value_t)));
         BHS_TRY(ensure(h, h->spaBits, (size_t)slots * nWords * sizeof(unsigned)));
     }
-    BHS_HIP(hipMemsetAsync(h->spaVals.p, 0, (size_t)slots * n * sizeof(double), h->stream));
+    BHS_HIP(hipMemsetAsync(h->spaVals.p, 0, (size_t)slots * n * sizeof(value_t), h->stream));
     BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->stream));
     h->spaSlots = (int)slots;
     h->spaCols = h->n;
@@ -269,8 +269,8 @@ int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     int* small = (int*)h->small.p;
     BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->stream, queue, qn, h->n,
-                       h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p,
-                       small + S_TICKET, (double*)h->spaVals.p, (unsigned*)h->spaBits.p);
+                       h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
+                       small + S_TICKET, (value_t*)h->spaVals.p, (unsigned*)h->spaBits.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -296,7 +296,7 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);       // XCD-aware schedule needs a multiple of 8
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, h->dAj, h->dAx,
-                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
+                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -328,7 +328,7 @@ int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->stream, queue, qn, h->dAj, h->dAx, h->dBp, h->dBj,
-                       h->dBx, CpOrCnt, (int*)h->Cj.p, (double*)h->Cx.p);
+                       h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -510,7 +510,7 @@ int run_pipeline(bhs_handle* h)
         numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
     }
     BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
-    BHS_TRY(ensure(h, h->Cx, sizeof(double) * (size_t)std::max<long long>(nnzC, 1)));
+    BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
     BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
@@ -722,8 +722,8 @@ static int check_dims(int m, int k, int n, int nnzA, int nnzB)
     return (m < 0 || k < 0 || n < 0 || nnzA < 0 || nnzB < 0) ? BHS_ERR_INVALID_ARG : BHS_SUCCESS;
 }
 
-int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const double* csrValA, const int* csrRowPtrA,
-                 const int* csrColIndA, int nnzB, const double* csrValB, const int* csrRowPtrB,
+int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const bhs_value_t* csrValA, const int* csrRowPtrA,
+                 const int* csrColIndA, int nnzB, const bhs_value_t* csrValB, const int* csrRowPtrB,
                  const int* csrColIndB)
 {
     if (!h || check_dims(m, k, n, nnzA, nnzB)) return BHS_ERR_INVALID_ARG;
@@ -734,30 +734,30 @@ int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const double* csr
     h->m = m; h->k = k; h->n = n; h->nnzA = nnzA; h->nnzB = nnzB;
     BHS_TRY(ensure(h, h->ownA[0], sizeof(int) * ((size_t)m + 1)));
     BHS_TRY(ensure(h, h->ownA[1], sizeof(int) * (size_t)std::max(nnzA, 1)));
-    BHS_TRY(ensure(h, h->ownA[2], sizeof(double) * (size_t)std::max(nnzA, 1)));
+    BHS_TRY(ensure(h, h->ownA[2], sizeof(value_t) * (size_t)std::max(nnzA, 1)));
     BHS_TRY(ensure(h, h->ownB[0], sizeof(int) * ((size_t)k + 1)));
     BHS_TRY(ensure(h, h->ownB[1], sizeof(int) * (size_t)std::max(nnzB, 1)));
-    BHS_TRY(ensure(h, h->ownB[2], sizeof(double) * (size_t)std::max(nnzB, 1)));
+    BHS_TRY(ensure(h, h->ownB[2], sizeof(value_t) * (size_t)std::max(nnzB, 1)));
     BHS_HIP(hipMemcpyAsync(h->ownA[0].p, csrRowPtrA, sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice, h->stream));
     if (nnzA) {
         BHS_HIP(hipMemcpyAsync(h->ownA[1].p, csrColIndA, sizeof(int) * (size_t)nnzA, hipMemcpyHostToDevice, h->stream));
-        BHS_HIP(hipMemcpyAsync(h->ownA[2].p, csrValA, sizeof(double) * (size_t)nnzA, hipMemcpyHostToDevice, h->stream));
+        BHS_HIP(hipMemcpyAsync(h->ownA[2].p, csrValA, sizeof(value_t) * (size_t)nnzA, hipMemcpyHostToDevice, h->stream));
     }
     BHS_HIP(hipMemcpyAsync(h->ownB[0].p, csrRowPtrB, sizeof(int) * ((size_t)k + 1), hipMemcpyHostToDevice, h->stream));
     if (nnzB) {
         BHS_HIP(hipMemcpyAsync(h->ownB[1].p, csrColIndB, sizeof(int) * (size_t)nnzB, hipMemcpyHostToDevice, h->stream));
-        BHS_HIP(hipMemcpyAsync(h->ownB[2].p, csrValB, sizeof(double) * (size_t)nnzB, hipMemcpyHostToDevice, h->stream));
+        BHS_HIP(hipMemcpyAsync(h->ownB[2].p, csrValB, sizeof(value_t) * (size_t)nnzB, hipMemcpyHostToDevice, h->stream));
     }
     BHS_HIP(hipStreamSynchronize(h->stream));
-    h->dAp = (const int*)h->ownA[0].p; h->dAj = (const int*)h->ownA[1].p; h->dAx = (const double*)h->ownA[2].p;
-    h->dBp = (const int*)h->ownB[0].p; h->dBj = (const int*)h->ownB[1].p; h->dBx = (const double*)h->ownB[2].p;
+    h->dAp = (const int*)h->ownA[0].p; h->dAj = (const int*)h->ownA[1].p; h->dAx = (const value_t*)h->ownA[2].p;
+    h->dBp = (const int*)h->ownB[0].p; h->dBj = (const int*)h->ownB[1].p; h->dBx = (const value_t*)h->ownB[2].p;
     h->ownAB = true;
     BHS_TRY(ensure_host_rowptr(h, sizeof(int) * ((size_t)m + 1)));   // pinned staging, outside the timed region
     return finish_set_data(h);
 }
 
-int bhs_set_data_device(bhs_handle* h, int m, int k, int n, int nnzA, const double* d_valA, const int* d_rowPtrA,
-                        const int* d_colIndA, int nnzB, const double* d_valB, const int* d_rowPtrB,
+int bhs_set_data_device(bhs_handle* h, int m, int k, int n, int nnzA, const bhs_value_t* d_valA, const int* d_rowPtrA,
+                        const int* d_colIndA, int nnzB, const bhs_value_t* d_valB, const int* d_rowPtrB,
                         const int* d_colIndB)
 {
     if (!h || check_dims(m, k, n, nnzA, nnzB)) return BHS_ERR_INVALID_ARG;
@@ -824,7 +824,7 @@ int bhs_get_nnzC(bhs_handle* h, int* nnzC_out)
     return BHS_SUCCESS;
 }
 
-int bhs_get_C(bhs_handle* h, int* csrColIndC, double* csrValC)
+int bhs_get_C(bhs_handle* h, int* csrColIndC, bhs_value_t* csrValC)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasC) return BHS_ERR_NOT_READY;
@@ -832,7 +832,7 @@ int bhs_get_C(bhs_handle* h, int* csrColIndC, double* csrValC)
     BHS_HIP(hipSetDevice(h->device));
     if (h->nnzC) {
         BHS_HIP(hipMemcpyAsync(csrColIndC, h->Cj.p, sizeof(int) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipMemcpyAsync(csrValC, h->Cx.p, sizeof(double) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(csrValC, h->Cx.p, sizeof(value_t) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
     }
     BHS_HIP(hipStreamSynchronize(h->stream));
     return BHS_SUCCESS;
@@ -848,13 +848,13 @@ int bhs_get_rowptrC(bhs_handle* h, int* csrRowPtrC)
     return BHS_SUCCESS;
 }
 
-int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC, const double** d_valC)
+int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC, const bhs_value_t** d_valC)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasC) return BHS_ERR_NOT_READY;
     if (d_rowPtrC) *d_rowPtrC = (const int*)h->Cp.p;
     if (d_colIndC) *d_colIndC = (const int*)h->Cj.p;
-    if (d_valC) *d_valC = (const double*)h->Cx.p;
+    if (d_valC) *d_valC = (const bhs_value_t*)h->Cx.p;
     return BHS_SUCCESS;
 }
 
@@ -915,7 +915,11 @@ const char* bhs_strerror(int status)
     }
 }
 
-const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950)"; }
+#ifdef BHS_VALUE_FLOAT
+const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type float)"; }
+#else
+const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type double)"; }
+#endif
 
 #if BHS_PHASES
 // measurement-only builds (tools/build_variants.sh -DBHS_PHASES=1): read and reset the phase counters

@@ -42,9 +42,13 @@ def _ptr(a):
 
 
 class bhsparse(object):
-    """index_type = int32, value_type = float64 (common.h:30-31)."""
+    """index_type = int32, value_type = float64 (common.h:30-31), or float32 with
+    `bhsparse(value_dtype=np.float32)` (libbhsparse_hip_f32.so, the reference's float build)."""
 
-    def __init__(self):
+    def __init__(self, value_dtype=np.float64):
+        self._vdt = np.dtype(value_dtype)
+        if self._vdt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("value_type is double or float")
         self._h = None
         self._lib = None
         self._m = 0
@@ -61,7 +65,7 @@ class bhsparse(object):
         plats = list(spgemm_platform)
         if not any(plats[i] for i in (BHSPARSE_CUDA, BHSPARSE_OPENCL, BHSPARSE_HIP) if i < len(plats)):
             return _lib.BHS_ERR_INVALID_ARG
-        self._lib = _lib.load()            # raises if the HIP library is missing: no fallback
+        self._lib = _lib.load(f32=self._vdt == np.dtype(np.float32))   # raises if missing: no fallback
         h = C.c_void_p()
         dev = C.c_int(int(device))
         err = self._lib.bhs_create(C.byref(h), 1, C.byref(dev))
@@ -80,8 +84,8 @@ class bhsparse(object):
         variant's trailing flag (SpGEMM_opencl/bhsparse.h:44-47) and is ignored."""
         if self._h is None:
             return _lib.BHS_ERR_NOT_READY
-        for a, dt in ((csrValA, np.float64), (csrRowPtrA, np.int32), (csrColIndA, np.int32),
-                      (csrValB, np.float64), (csrRowPtrB, np.int32), (csrColIndB, np.int32)):
+        for a, dt in ((csrValA, self._vdt), (csrRowPtrA, np.int32), (csrColIndA, np.int32),
+                      (csrValB, self._vdt), (csrRowPtrB, np.int32), (csrColIndB, np.int32)):
             if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous):
                 return _lib.BHS_ERR_INVALID_ARG
         if csrRowPtrC is not None and not (isinstance(csrRowPtrC, np.ndarray) and
@@ -144,7 +148,7 @@ class bhsparse(object):
         if self._h is None:
             return _lib.BHS_ERR_NOT_READY
         nnz = self.get_nnzC()
-        for a, dt in ((csrColIndC, np.int32), (csrValC, np.float64)):
+        for a, dt in ((csrColIndC, np.int32), (csrValC, self._vdt)):
             if nnz and not (isinstance(a, np.ndarray) and a.dtype == dt and a.size >= nnz and
                             a.flags.c_contiguous):
                 return _lib.BHS_ERR_INVALID_ARG
@@ -196,12 +200,12 @@ class bhsparse(object):
         return err
 
 
-def spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, device=0, warmups=0, options=None):
+def spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, device=0, warmups=0, options=None, value_dtype=np.float64):
     """Convenience: run the reference call sequence once on host CSR arrays and
-    return (rowPtrC int32[m+1], colIndC int32[nnzC], valC f64[nnzC], info)."""
+    return (rowPtrC int32[m+1], colIndC int32[nnzC], valC value_dtype[nnzC], info)."""
     plats = [False] * NUM_PLATFORMS
     plats[BHSPARSE_HIP] = True
-    bh = bhsparse()
+    bh = bhsparse(value_dtype=value_dtype)
     err = bh.initPlatform(plats, device=device)
     if err:
         raise BhsparseError("initPlatform", err)
@@ -211,9 +215,9 @@ def spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, device=0, warmups=0, options=Non
             if err:
                 raise BhsparseError("set_option(%s)" % key, err)
         Ap, Aj, Ax = (np.ascontiguousarray(Ap, np.int32), np.ascontiguousarray(Aj, np.int32),
-                      np.ascontiguousarray(Ax, np.float64))
+                      np.ascontiguousarray(Ax, value_dtype))
         Bp, Bj, Bx = (np.ascontiguousarray(Bp, np.int32), np.ascontiguousarray(Bj, np.int32),
-                      np.ascontiguousarray(Bx, np.float64))
+                      np.ascontiguousarray(Bx, value_dtype))
         Cp = np.zeros(m + 1, np.int32)
         err = bh.initData(m, k, n, len(Aj), Ax, Ap, Aj, len(Bj), Bx, Bp, Bj, Cp)
         if err:
@@ -227,7 +231,7 @@ def spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, device=0, warmups=0, options=Non
             raise BhsparseError("spgemm", err)
         nnzC = bh.get_nnzC()
         Cj = np.empty(nnzC, np.int32)
-        Cx = np.empty(nnzC, np.float64)
+        Cx = np.empty(nnzC, value_dtype)
         err = bh.get_C(Cj, Cx)
         if err:
             raise BhsparseError("get_C", err)

@@ -14,7 +14,11 @@
 #define BHSPARSE_SUCCESS 0
 
 typedef int    index_type;
+#ifdef BHS_VALUE_FLOAT          // float build: compile with -DBHS_VALUE_FLOAT and link libbhsparse_hip_f32.so
+typedef float  value_type;
+#else
 typedef double value_type;
+#endif
 
 #define NUM_PLATFORMS   9
 #define NAIVE           0

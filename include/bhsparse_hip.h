@@ -12,8 +12,8 @@
  * (same threading contract as the reference: single host thread, synchronous
  * calls).
  *
- * Types: index_type = int32 (SpGEMM_cuda/common.h:30), value_type = double
- * (common.h:31).  Intermediate-product counts are int64 (the reference's int
+ * Types: index_type = int32 (SpGEMM_cuda/common.h:30), value_type = bhs_value_t: double
+ * (common.h:31) or float in the f32 build.  Intermediate-product counts are int64 (the reference's int
  * overflows beyond 2^31 products, bhsparse.h:367,431).
  */
 #ifndef BHSPARSE_HIP_H
@@ -29,6 +29,15 @@ extern "C" {
 #define BHS_API __attribute__((visibility("default")))
 #else
 #define BHS_API
+#endif
+
+/* value_type of A, B and C: double (libbhsparse_hip.so; SpGEMM_cuda/common.h:31) or float
+ * (libbhsparse_hip_f32.so, the same sources built with -DBHS_VALUE_FLOAT; the reference supports it by
+ * editing the same typedef, README.md:84-86).  Callers of the f32 library define BHS_VALUE_FLOAT too. */
+#ifdef BHS_VALUE_FLOAT
+typedef float bhs_value_t;
+#else
+typedef double bhs_value_t;
 #endif
 
 typedef struct bhs_handle bhs_handle;
@@ -67,16 +76,16 @@ BHS_API int bhs_set_verbose(bhs_handle *h, int level);
  * CSR.  Rows of B should be column-sorted (reference precondition, SURVEY.md
  * §8b); unsorted B is detected and still multiplied correctly.               */
 BHS_API int bhs_set_data(bhs_handle *h, int m, int k, int n,
-                         int nnzA, const double *csrValA, const int *csrRowPtrA, const int *csrColIndA,
-                         int nnzB, const double *csrValB, const int *csrRowPtrB, const int *csrColIndB);
+                         int nnzA, const bhs_value_t *csrValA, const int *csrRowPtrA, const int *csrColIndA,
+                         int nnzB, const bhs_value_t *csrValB, const int *csrRowPtrB, const int *csrColIndB);
 
 /* Same, but the six arrays are DEVICE pointers on the handle's device (borrowed
  * until bhs_free_data; never written).  This is the entry the benchmark uses so
  * that inputs are HBM-resident when the timed region starts, and the entry a
  * multi-GPU host uses to hand each rank its row block of A with B replicated. */
 BHS_API int bhs_set_data_device(bhs_handle *h, int m, int k, int n,
-                                int nnzA, const double *d_valA, const int *d_rowPtrA, const int *d_colIndA,
-                                int nnzB, const double *d_valB, const int *d_rowPtrB, const int *d_colIndB);
+                                int nnzA, const bhs_value_t *d_valA, const int *d_rowPtrA, const int *d_colIndA,
+                                int nnzB, const bhs_value_t *d_valB, const int *d_rowPtrB, const int *d_colIndB);
 
 /* replaces bhsparse::free_mem -> bhsparse_cuda::free_mem (bhsparse.h:151-178,
  * bhsparse_cuda.h:121-149).  Drops A, B, C; keeps the workspace pool.         */
@@ -109,14 +118,14 @@ BHS_API int bhs_get_nnzC(bhs_handle *h, int *nnzC_out);
  * D2H of colIndC / valC; the reference also re-copies rowPtrC there — pass
  * rowPtrC_out to bhs_spgemm or use bhs_get_rowptrC).  Caller buffers hold
  * nnzC entries.                                                               */
-BHS_API int bhs_get_C(bhs_handle *h, int *csrColIndC, double *csrValC);
+BHS_API int bhs_get_C(bhs_handle *h, int *csrColIndC, bhs_value_t *csrValC);
 BHS_API int bhs_get_rowptrC(bhs_handle *h, int *csrRowPtrC /* m+1 */);
 
 /* Device-resident result for callers that keep C on the GPU (multi-GPU
  * all-gatherv of row blocks, chained products).  Pointers stay valid until the
  * next bhs_spgemm / bhs_free_data / bhs_destroy on this handle.               */
 BHS_API int bhs_get_C_device(bhs_handle *h, const int **d_rowPtrC, const int **d_colIndC,
-                             const double **d_valC);
+                             const bhs_value_t **d_valC);
 
 /* ---- measurement ----------------------------------------------------------
  * Per-kernel-family device times of the LAST bhs_spgemm, measured with

@@ -25,7 +25,7 @@ def oracle():
 def hiplib():
     """Builds (if stale) and loads libbhsparse_hip.so. No fallback."""
     from benchmark_spgemm_using_csr_amd import _lib
-    if not os.path.exists(_lib.SO_PATH):
+    if not (os.path.exists(_lib.SO_PATH) and os.path.exists(_lib.SO_PATH_F32)):
         _lib.build()
     return _lib.load()
 

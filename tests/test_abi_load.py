@@ -26,6 +26,15 @@ def test_library_exports_every_declared_symbol(hiplib):
         assert getattr(raw, name) is not None
 
 
+def test_float_library_exports_the_same_abi(hiplib):
+    assert os.path.exists(_lib.SO_PATH_F32)
+    raw = C.CDLL(_lib.SO_PATH_F32)
+    for name in _declared_symbols():
+        assert getattr(raw, name) is not None
+    raw.bhs_version.restype = C.c_char_p
+    assert b"float" in raw.bhs_version() and b"double" in hiplib.bhs_version()
+
+
 def test_code_object_is_gfx950():
     so = _lib.SO_PATH
     assert os.path.exists(so)
@@ -38,7 +47,7 @@ def test_code_object_is_gfx950():
 def test_strerror_and_version(hiplib):
     assert hiplib.bhs_strerror(0) == b"success"
     assert b"int32" in hiplib.bhs_strerror(_lib.BHS_ERR_NNZ_OVERFLOW)
-    assert b"gfx950" in hiplib.bhs_version()
+    assert b"gfx950" in hiplib.bhs_version() and b"double" in hiplib.bhs_version()
 
 
 def test_null_handle_is_rejected(hiplib):

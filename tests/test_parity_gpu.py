@@ -297,6 +297,44 @@ def test_huge_column_space():
     assert Cj.max() == n - 1 and np.diff(Cp).max() > 6144
 
 
+F32_TOL = 2e-5      # float accumulation of <= a few thousand products per entry
+
+
+@pytest.mark.parametrize("case", ["p27", "p5", "rect", "hub"])
+def test_float_value_type_build(oracle, case):
+    """libbhsparse_hip_f32.so (value_type float, the reference's other build: README.md:84-86) against the
+    double oracle: structure bit-exact, values within F32_TOL relative; integer-valued inputs whose sums stay
+    below 2^24 are exact in float too."""
+    rng = np.random.default_rng(3)
+    if case == "p27":
+        m, rp, col, val = poisson_case("poisson27pt", 13, 13, 13); k = n = m
+        A = B = (rp, col, val)
+    elif case == "p5":
+        m, rp, col, val = poisson_case("poisson5pt", 60, 60); k = n = m
+        A = B = (rp, col, val)
+    elif case == "rect":
+        m, k, n = 500, 400, 3000
+        A = random_csr(m, k, 0.03, rng, empty_rows=(0, 7), values="normal")
+        B = random_csr(k, n, 0.02, rng, values="normal")
+    else:
+        from benchmark_spgemm_using_csr_amd import gallery
+        m = k = n = 20000
+        rp, col = gallery.powerlaw_csr(m, m, 70000, 2500, hubs=3)
+        A = B = (rp, col, gallery.fill_values(len(col)))
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, A[0], A[1], A[2].astype(np.float32), B[0], B[1], B[2].astype(np.float32),
+                                  value_dtype=np.float32)
+    assert Cx.dtype == np.float32
+    ref = oracle.spgemm(m, k, n, A[0], A[1], A[2].astype(np.float32).astype(np.float64),
+                        B[0], B[1], B[2].astype(np.float32).astype(np.float64))
+    assert np.array_equal(Cp, ref[0]) and np.array_equal(Cj, ref[1])
+    if case in ("p27", "p5", "hub"):
+        assert np.array_equal(Cx.astype(np.float64), ref[2])          # small integers: exact
+    else:
+        scale = np.maximum(np.abs(ref[2]), 1e-3)
+        assert np.max(np.abs(Cx.astype(np.float64) - ref[2]) / scale) < 50 * F32_TOL
+    check_csr_invariants(m, n, Cp, Cj)
+
+
 def test_repeated_spgemm_and_data_swap(oracle):
     """One handle, several multiplies and data sets: pooled workspace must not leak state."""
     plats = [False] * bhmod.NUM_PLATFORMS
