@@ -45,16 +45,10 @@ using value_t = float;
 using value_t = double;
 #endif
 
-// zero four consecutive LDS value slots (16-byte aligned start)
-__device__ __forceinline__ void clear4(value_t* p)
-{
-    if constexpr (sizeof(value_t) == 8) {
-        *reinterpret_cast<double2*>(p) = make_double2(0.0, 0.0);
-        *reinterpret_cast<double2*>(p + 2) = make_double2(0.0, 0.0);
-    } else {
-        *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
+// LDS accumulators are fp64 in BOTH builds: on gfx950 ds_add_f32 is a slow path (measured: the float build's
+// numeric pass took 8.9 ms with fp32 LDS atomics against 4.0 ms without the adds, while ds_add_f64 costs next to
+// nothing), so float values are widened on load, accumulated in double and narrowed when the row is stored.
+using acc_t = double;
 
 constexpr int kEmpty = -1;          // empty hash slot (column indices are >= 0)
 constexpr int kMaxBins = 16;
@@ -397,7 +391,7 @@ __global__ __launch_bounds__(256) void k_check_sorted(int k, const int* __restri
 template <int TS, int BLOCK, bool NUM>
 struct BlockSmem {
     int keys[TS];
-    value_t vals[NUM ? TS : 1];
+    acc_t vals[NUM ? TS : 1];
     value_t sAv[NUM ? BLOCK : 1];
     int sIncl[BLOCK];
     int sBase[BLOCK];
@@ -495,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 
                 for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
                     int col[U];
-                    value_t pv[U];
+                    acc_t pv[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int p = p0 + u * BLOCK + tid;
@@ -508,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                             const int c = Bj[idx];
                             if (full || bSorted || ((long long)c >= lo && (long long)c < hi)) {
                                 col[u] = c;
-                                if (NUM) pv[u] = sm.sAv[l] * Bx[idx];
+                                if (NUM) pv[u] = (acc_t)sm.sAv[l] * (acc_t)Bx[idx];
                             }
                         }
                     }
@@ -564,7 +558,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                             const unsigned x = (unsigned)sm.keys[a], y = (unsigned)sm.keys[b];
                             if ((x > y) == up && x != y) {
                                 sm.keys[a] = (int)y; sm.keys[b] = (int)x;
-                                const value_t va = sm.vals[a], vb = sm.vals[b];
+                                const acc_t va = sm.vals[a], vb = sm.vals[b];
                                 sm.vals[a] = vb; sm.vals[b] = va;
                             }
                         }
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                 }
                 for (int r = tid; r < uniq; r += BLOCK) {
                     Cj[outBase + r] = sm.keys[r];
-                    Cx[outBase + r] = sm.vals[r];
+                    Cx[outBase + r] = (value_t)sm.vals[r];
                 }
                 outBase += uniq;
                 __syncthreads();
@@ -812,7 +806,7 @@ template <int TS, bool NUM, bool PACK32>
 struct WaveSmem {
     using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
     int keys[TS];
-    value_t vals[NUM ? TS : 1];
+    acc_t vals[NUM ? TS : 1];
     packed_t packed[NUM ? TS : 2];
     value_t sAv[NUM ? 64 : 1];
     int sBase[64];
@@ -883,7 +877,7 @@ __device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
 }
 
 template <int LOG2TS, bool PACK32, int E, typename T>
-__device__ __forceinline__ void wave_sort_and_store(const T* packed, const value_t* vals, int uniq, int lane,
+__device__ __forceinline__ void wave_sort_and_store(const T* packed, const acc_t* vals, int uniq, int lane,
                                                     int* __restrict__ Cj, value_t* __restrict__ Cx,
                                                     long long outBase)
 {
@@ -904,10 +898,10 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const value
             else { col = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
 #if BHS_NT_STORES
             __builtin_nontemporal_store(col, &Cj[outBase + r]);
-            __builtin_nontemporal_store(vals[slot], &Cx[outBase + r]);
+            __builtin_nontemporal_store((value_t)vals[slot], &Cx[outBase + r]);
 #else
             Cj[outBase + r] = col;
-            Cx[outBase + r] = vals[slot];
+            Cx[outBase + r] = (value_t)vals[slot];
 #endif
         }
     }
@@ -1024,7 +1018,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
                 wave_sync();
                 int col[MAXB];
-                value_t pv[MAXB];
+                acc_t pv[MAXB];
                 int cum = done;
                 // ---- all loads of the window first
 #pragma unroll
@@ -1041,8 +1035,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                             if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
                             else col[u] = Bj[idx];
                             if (NUM) {
-                                const value_t avj = (abl & 64) ? 1.0 : sm.sAv[j];
-                                pv[u] = (abl & 32) ? avj : avj * Bx[idx];
+                                const acc_t avj = (abl & 64) ? 1.0 : (acc_t)sm.sAv[j];
+                                pv[u] = (abl & 32) ? avj : avj * (acc_t)Bx[idx];
                             }
                         }
                     }
@@ -1135,7 +1129,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                     for (int r = lane; r < uniq; r += 64) {
                         const packed_t e = sm.packed[r];
                         Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
-                        Cx[outBase + r] = sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
+                        Cx[outBase + r] = (value_t)sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
                     }
             } else if (uniq <= 64)
                 wave_sort_and_store<LOG2TS, PACK32, 1>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
@@ -1164,7 +1158,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 for (int r = lane; r < uniq; r += 64) {
                     const packed_t e = sm.packed[r];
                     Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
-                    Cx[outBase + r] = sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
+                    Cx[outBase + r] = (value_t)sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
                 }
             }
         }
@@ -1198,7 +1192,7 @@ template <bool NUM, bool PACK32>
 struct QuadSmem {
     using packed_t = typename std::conditional<PACK32, unsigned, unsigned long long>::type;
     int keys[4][64];
-    value_t vals[NUM ? 4 : 1][NUM ? 64 : 1];
+    acc_t vals[NUM ? 4 : 1][NUM ? 64 : 1];
     packed_t packed[NUM ? 4 : 1][NUM ? 64 : 2];
     value_t sAv[NUM ? 4 : 1][NUM ? 16 : 1];
     int sBase[4][16];
@@ -1280,7 +1274,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
             wave_sync();
             const unsigned long long mk = sm.marks[g];
             int col[4];
-            value_t pv[4];
+            acc_t pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 col[u] = kEmpty;
@@ -1291,7 +1285,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
                     const int j = done + __popcll(mk & ((1ull << pr) - 1ull));
                     const long long idx = (long long)sm.sBase[g][j] + p;
                     col[u] = Bj[idx];
-                    if (NUM) pv[u] = sm.sAv[g][j] * Bx[idx];
+                    if (NUM) pv[u] = (acc_t)sm.sAv[g][j] * (acc_t)Bx[idx];
                 }
             }
             done += __popcll(mk);
@@ -1369,7 +1363,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
                     if constexpr (PACK32) { c = (int)(x[e] >> LOG2TS); slot = x[e] & 63u; }
                     else { c = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
                     Cj[outBase + r] = c;
-                    Cx[outBase + r] = sm.vals[g][slot];
+                    Cx[outBase + r] = (value_t)sm.vals[g][slot];
                 }
             }
         }

@@ -11,14 +11,16 @@ if name == "webbase":
     val = gallery.fill_values(len(col))
     Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 else:
-    st, dims = {"p27_160": ("poisson27pt", (160, 160, 160)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
+    st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
                 "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1))}[name]
     Bp, Bj = gallery.poisson_csr_torch(st, *dims, device=dev)
     Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
+f32 = os.environ.get('BHS_F32') == '1'
+if f32: Bx = Bx.to(torch.float32)
 Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
 m = Bp.numel() - 1
 plats = [False] * 9; plats[3] = True
-bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
+bh = facade.bhsparse(value_dtype=np.float32 if f32 else np.float64); assert bh.initPlatform(plats) == 0
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
 for kv in os.environ.get('BHS_OPTS','').split(','):
     if kv: k_, v_ = kv.split('='); assert bh.set_option(k_, int(v_)) == 0
