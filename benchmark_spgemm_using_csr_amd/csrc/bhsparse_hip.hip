@@ -351,7 +351,6 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
     if (c.win && h->spaSlots > 0 && h->useSpa && h->maxTableLog2 >= 15) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
-#define BHS_CASE(LG, BL, W)
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
     BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);
@@ -369,7 +368,6 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
         if (lg >= 11) return launch_row_block<11, 256, true>(h, queue, qn, CpOrCnt);
         return launch_row_block<8, 256, true>(h, queue, qn, CpOrCnt);
     }
-#undef BHS_CASE
 }
 
 const char* kSymNames[kNumSymBins] = {"", "symbolic_quad<64>", "symbolic_wave<64>", "symbolic_wave<128>", "symbolic_wave<256>",

@@ -144,10 +144,16 @@ typedef struct bhs_kernel_stat {
 } bhs_kernel_stat;
 BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
 
-/* Tunables (mostly for tests that force a particular accumulator path):
- *   "force_path"    0 auto | 1 wave-per-row hash | 2 workgroup-per-row hash
- *   "max_table_log2" cap on the LDS table size => forces the column-window path
- *   "verbose"       same as bhs_set_verbose
+/* Tunables (tests use them to force a particular accumulator path; defaults are the measured best):
+ *   "force_path"      0 auto | 1 no quarter-wave bin (tiny rows take the wave kernel) |
+ *                     2 wave bins are served by the workgroup-per-row kernel
+ *   "max_table_log2"  cap (6..15) on the LDS table size => forces the column-window path
+ *   "no_pack32"       1: always 64-bit sort keys
+ *   "sym_load_pct", "num_load_pct"  table load factor (5..75 %) that decides a row's bin
+ *   "spa"             0: rows beyond the LDS tables use column windows instead of the dense HBM accumulator
+ *   "spa_slots"       dense-accumulator slots (default: one per CU)
+ *   "wg_per_cu"       persistent workgroups per CU of the wave kernels (default: occupancy API)
+ *   "verbose"         same as bhs_set_verbose
  * Returns BHS_ERR_INVALID_ARG for unknown keys.                               */
 BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
 
