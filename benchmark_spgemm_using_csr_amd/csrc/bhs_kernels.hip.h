@@ -955,7 +955,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
     if (lane < d1.z - d1.y) { c1 = Aj[d1.y + lane]; if (NUM) av1 = Ax[d1.y + lane]; }
     int b0C = 0, lenC = 0;
-    if (lane < dC.z - dC.y) { b0C = Bp[cC]; lenC = Bp[cC + 1] - b0C; }
+    if (lane < dC.z - dC.y) { int2 be; __builtin_memcpy(&be, Bp + cC, 8); b0C = be.x; lenC = be.y - be.x; }
 
 #if BHS_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         value_t av2 = 0.0;
         if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
         int b01 = 0, len1 = 0;
-        if (lane < d1.z - d1.y) { b01 = Bp[c1]; len1 = Bp[c1 + 1] - b01; }
+        if (lane < d1.z - d1.y) { int2 be; __builtin_memcpy(&be, Bp + c1, 8); b01 = be.x; len1 = be.y - be.x; }   // one 8-byte gather
 
         const int row = dC.x, a0 = dC.y, a1 = dC.z;
         // ---- clear the table
@@ -994,8 +994,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 if (ea < a1) {
                     const int c = Aj[ea];
                     if (NUM) av = Ax[ea];
-                    b0 = Bp[c];
-                    len = Bp[c + 1] - b0;
+                    int2 be;
+                    __builtin_memcpy(&be, Bp + c, 8);
+                    b0 = be.x;
+                    len = be.y - be.x;
                 }
             }
             const int incl = wave_incl_scan_dpp(len);
