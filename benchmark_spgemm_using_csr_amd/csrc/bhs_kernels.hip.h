@@ -6,7 +6,8 @@
 // Reference functions these kernels replace (SpGEMM_cuda/bhsparse_cuda.h):
 //   k_upper_bound      <- compute_nnzCt_cudakernel            :210-237
 //   k_fill_queues      <- bhsparse::statistics (host)         bhsparse.h:365-481
-//   k_row_*<..,NUM=0>  <- (symbolic) no counterpart: the reference sizes Ct by
+//   k_row_{quad,wave,block,spa}<..,NUM=0>
+//                      <- (symbolic) no counterpart: the reference sizes Ct by
 //                         upper bound and compacts later (create_Ct :285-301,
 //                         copyCt2C_* :2813-2911); here an exact count replaces both
 //   k_row_*<..,NUM=1>  <- ESC_0/ESC_1 :1582-1640, ESC_2heap_noncoalesced :653-722,
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
 // Wavefront-per-row accumulator (the workhorse; one 64-lane workgroup per row
 // in flight, persistent over an XCD-aware slice of the row queue).
 //
-// Differences from k_row_hash<BLOCK=64> that matter on CDNA4:
+// What matters on CDNA4:
 //  * no dependent load chain per A entry: the whole A row (<= 64 entries per
 //    pass) is fetched by one coalesced load, the B row extents by one gather,
 //    and a wave scan turns the B row lengths into a flat product index space;

@@ -2,11 +2,13 @@
 //
 // Pipeline of one bhs_spgemm() (replaces bhsparse::spgemm_cuda, bhsparse.h:297-339):
 //   stage 1  k_upper_bound (ub per row, nnzCt, symbolic-bin histogram)          <- compute_nnzCt + statistics()
-//            k_fill_queues  (row ids grouped by symbolic bin, on device)
-//   stage 2  k_row_hash<.., NUM=0> per non-empty bin: exact nnz of every C row  <- replaces upper-bound Ct + copy stage
+//            k_fill_queues  (16-byte row descriptors grouped by symbolic bin, on device)
+//   stage 2  symbolic pass per non-empty bin: exact nnz of every C row          <- replaces upper-bound Ct + copy stage
+//            (k_row_quad / k_row_wave / k_row_block / k_row_spa with NUM = false)
 //   stage 3  k_scan_* : rowPtrC = exclusive scan, nnz(C), numeric-bin histogram <- create_C
 //            (grow-only pool) make room for C; k_fill_queues by nnz per row
-//   stage 4  k_row_hash<.., NUM=1> per non-empty bin: C written once, sorted    <- ESC_*/EM_* + copyCt2C_*
+//   stage 4  numeric pass per non-empty bin: C written once, sorted             <- ESC_*/EM_* + copyCt2C_*
+//            (the same four kernel families with NUM = true)
 // Two host<->device round trips of a few hundred bytes (bin counts, nnzCt, nnzC)
 // instead of the reference's whole-array D2H/H2D of rowPtrCt, the 6*m queue and
 // rowPtrC (bhsparse_cuda.h:280, 289, 2787-2808).
