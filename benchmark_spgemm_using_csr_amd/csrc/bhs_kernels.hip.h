@@ -1222,24 +1222,50 @@ __global__ __launch_bounds__(64) void k_row_quad(
     const int gBeg = xcd * region;
     const int gEnd = gBeg + region < nGroups ? gBeg + region : nGroups;
 
-    int4 dNext = make_int4(-1, 0, 0, 0);
-    if (gBeg + lb < gEnd && (gBeg + lb) * 4 + g < qn) dNext = desc[(gBeg + lb) * 4 + g];
-    for (int grp = gBeg + lb; grp < gEnd; grp += perX) {
-        const int4 d = dNext;                                  // this quarter's row (row < 0: idle quarter)
-        dNext = make_int4(-1, 0, 0, 0);
-        if (grp + perX < gEnd && (grp + perX) * 4 + g < qn) dNext = desc[(grp + perX) * 4 + g];
-        const int nA = d.x >= 0 ? d.z - d.y : 0;
-        // ---- one A entry per lane of the quarter
-        int b0 = 0, len = 0;
-        value_t av = 0.0;
-        if (l16 < nA) {
-            const int c = Aj[d.y + l16];
-            if (NUM) av = Ax[d.y + l16];
-            int2 be;
-            __builtin_memcpy(&be, Bp + c, sizeof(be));
-            b0 = be.x;
-            len = be.y - be.x;
+    // Row pipeline (same shape as k_row_wave): descriptor of group i+3, A entries of group i+2 and
+    // B extents of group i+1 are in flight while group i is accumulated, so the three dependent
+    // global round trips of a row never sit on the critical path.
+    auto load_desc = [&](int grp_) {
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (grp_ < gEnd && grp_ * 4 + g < qn) r = desc[grp_ * 4 + g];
+        return r;
+    };
+    auto load_a = [&](const int4& dd, int& c_, value_t& av_) {
+        c_ = -1;
+        av_ = 0.0;
+        const int nA_ = dd.x >= 0 ? dd.z - dd.y : 0;
+        if (l16 < nA_) {
+            c_ = Aj[dd.y + l16];
+            if (NUM) av_ = Ax[dd.y + l16];
         }
+    };
+    auto load_b = [&](int c_, int& b0_, int& len_) {
+        b0_ = 0;
+        len_ = 0;
+        if (c_ >= 0) {
+            int2 be;
+            __builtin_memcpy(&be, Bp + c_, sizeof(be));
+            b0_ = be.x;
+            len_ = be.y - be.x;
+        }
+    };
+    const int g0 = gBeg + lb;
+    int4 dC = load_desc(g0), d1 = load_desc(g0 + perX), d2 = load_desc(g0 + 2 * perX);
+    int cC, c1, b0C, lenC;
+    value_t avC, av1;
+    load_a(dC, cC, avC);
+    load_a(d1, c1, av1);
+    load_b(cC, b0C, lenC);
+    for (int grp = g0; grp < gEnd; grp += perX) {
+        const int4 d = dC;                                     // this quarter's row (row < 0: idle quarter)
+        const int4 d3 = load_desc(grp + 3 * perX);
+        int c2, b01, len1;
+        value_t av2;
+        load_a(d2, c2, av2);
+        load_b(c1, b01, len1);
+        // ---- one A entry per lane of the quarter
+        const int b0 = b0C, len = lenC;
+        const value_t av = avC;
         // ---- clear the four tables (64 lanes x 4 slots = 256 slots)
         *reinterpret_cast<int4*>(&sm.keys[0][lane * 4]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
         if (NUM) {
@@ -1349,28 +1375,48 @@ __global__ __launch_bounds__(64) void k_row_quad(
             }
             const int uniq = run;
             wave_sync();
-            packed_t x[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = l16 * 4 + e;
-                x[e] = i < uniq ? sm.packed[g][i] : (packed_t)~(packed_t)0;
-            }
-            wave_bitonic_sort<packed_t, 4, 16>(x, lane);
             const long long outBase = d.w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = l16 * 4 + e;
-                if (r < uniq) {
+            if (__ballot(uniq > 16) == 0ull) {
+                // all four rows have <= 16 entries (poisson5pt: 13): one key per lane, 10 DPP stages
+                packed_t x1[1];
+                x1[0] = l16 < uniq ? sm.packed[g][l16] : (packed_t)~(packed_t)0;
+                wave_bitonic_sort<packed_t, 1, 16>(x1, lane);
+                if (l16 < uniq) {
                     int c;
                     unsigned slot;
-                    if constexpr (PACK32) { c = (int)(x[e] >> LOG2TS); slot = x[e] & 63u; }
-                    else { c = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
-                    Cj[outBase + r] = c;
-                    Cx[outBase + r] = (value_t)sm.vals[g][slot];
+                    if constexpr (PACK32) { c = (int)(x1[0] >> LOG2TS); slot = x1[0] & 63u; }
+                    else { c = (int)(x1[0] >> 32); slot = (unsigned)x1[0]; }
+                    Cj[outBase + l16] = c;
+                    Cx[outBase + l16] = (value_t)sm.vals[g][slot];
+                }
+            } else {
+                packed_t x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = l16 * 4 + e;
+                    x[e] = i < uniq ? sm.packed[g][i] : (packed_t)~(packed_t)0;
+                }
+                wave_bitonic_sort<packed_t, 4, 16>(x, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = l16 * 4 + e;
+                    if (r < uniq) {
+                        int c;
+                        unsigned slot;
+                        if constexpr (PACK32) { c = (int)(x[e] >> LOG2TS); slot = x[e] & 63u; }
+                        else { c = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
+                        Cj[outBase + r] = c;
+                        Cx[outBase + r] = (value_t)sm.vals[g][slot];
+                    }
                 }
             }
         }
         wave_sync();
+        // ---- rotate the pipeline
+        dC = d1; d1 = d2; d2 = d3;
+        avC = av1; av1 = av2;
+        c1 = c2;
+        b0C = b01; lenC = len1;
     }
 }
 
