@@ -30,8 +30,10 @@
 #if BHS_PHASES
 __device__ unsigned long long g_phase_cycles[16];
 #define BHS_TICK(i) do { if (NUM) { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPrev; tPrev = t__; } } while (0)
+#define BHS_TICK_SPA(i) do { if (NUM && tid == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], t__ - tSpa); tSpa = t__; } } while (0)
 #else
 #define BHS_TICK(i) do { } while (0)
+#define BHS_TICK_SPA(i) do { } while (0)
 #endif
 #include <stdint.h>
 #include <type_traits>
@@ -581,14 +583,20 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 }
 
 // ---------------------------------------------------------------------------
-// Dense accumulator (SPA) in HBM for rows whose result does not fit the LDS table
-// of k_row_block (hub rows of power-law matrices: webbase-1M has C rows with
-// ~100 k entries).  Each resident workgroup owns one slot: an n-entry fp64
-// vector (numeric) and an n-bit occupancy bitmap.  Products are added with
-// global_atomic_add_f64 / global_atomic_or (they execute in the XCD's L2; the
-// slot is private to the workgroup, so there is no cross-XCD traffic); the
-// bitmap scan then yields the row in ascending column order — no column
-// windows, no sort — and restores the slot to all-zero on the way out.
+// Bitmap accumulator for rows whose result does not fit the LDS table of
+// k_row_block (hub rows of power-law matrices: webbase-1M has C rows with
+// ~100 k entries).  Each resident workgroup owns one slot: an n-bit occupancy
+// bitmap plus (numeric) one rank word per 32 columns.
+//   pass 1  every product sets its column's bit (global_atomic_or; the slot is
+//           private to the workgroup and lives in this XCD's L2);
+//   scan    the bitmap yields the row's columns in ascending order -- no column
+//           windows, no sort -- and the prefix popcounts (rank) map a column to
+//           its position in the row; Cj is written and Cx zeroed here;
+//   pass 2  (numeric) every product is added straight into its final place,
+//           Cx[rowBase + rank[c/32] + popc(bits[c/32] below c)], with
+//           global_atomic_add_f64: the accumulation target is the row of C
+//           itself (compact, cache resident), not an n-entry dense vector whose
+//           random 8-byte updates would each move a whole line to and from HBM.
 // Replaces, for those rows, the reference's EM_mergepath_global rounds
 // (bhsparse_cuda.h:2270-2525) and their progressive re-allocation (:2527-2780).
 // ---------------------------------------------------------------------------
@@ -598,28 +606,24 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx,
-    int* __restrict__ ticket, value_t* __restrict__ spaBase, unsigned* __restrict__ bitsBase)
+    int* __restrict__ ticket, int* __restrict__ rankBase, unsigned* __restrict__ bitsBase)
 {
     __shared__ value_t sAv[NUM ? BLOCK : 1];
     __shared__ int sIncl[BLOCK];
     __shared__ int sBase[BLOCK];
     __shared__ int wtot[BLOCK / 64];
     __shared__ int bcast;
-    constexpr int U = 4, NW = BLOCK / 64;
+#ifndef BHS_SPA_U
+#define BHS_SPA_U 4
+#endif
+    constexpr int U = BHS_SPA_U, NW = BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nWords = (ncolsB + 31) >> 5;
-    value_t* spa = NUM ? spaBase + (size_t)blockIdx.x * (size_t)ncolsB : nullptr;
+    const int nWords = (int)((((long long)ncolsB + 31) >> 5) + 3) & ~3;   // slot stride: whole 16-byte groups
+    int* rank = NUM ? rankBase + (size_t)blockIdx.x * (size_t)nWords : nullptr;
     unsigned* bits = bitsBase + (size_t)blockIdx.x * (size_t)nWords;
 
-    for (;;) {
-        if (tid == 0) bcast = atomicAdd(ticket, 1);
-        __syncthreads();
-        const int q = bcast;
-        __syncthreads();
-        if (q >= qn) break;
-        const int4 d = desc[q];
-        const int row = d.x, a0 = d.y, a1 = d.z;
-        // ---- expand: one A entry per lane, flat product space per chunk of BLOCK entries
+    // flat product space per chunk of BLOCK A entries; f(column, product index in B, A entry slot)
+    auto expand = [&](int a0, int a1, auto&& f) {
         for (int ca = a0; ca < a1; ca += BLOCK) {
             const int e = ca + tid;
             int b0 = 0, len = 0;
@@ -655,30 +659,65 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
                         int l = 0, r = BLOCK - 1;                // first entry j with sIncl[j] > p
                         while (l < r) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
                         const long long idx = (long long)sBase[l] + p;
-                        const int c = Bj[idx];
-                        atomicOr(&bits[c >> 5], 1u << (c & 31));
-                        if (NUM) unsafeAtomicAdd(&spa[c], sAv[l] * Bx[idx]);
+                        f(Bj[idx], idx, l);
                     }
                 }
             }
             __syncthreads();
         }
+    };
+
+    for (;;) {
+        if (tid == 0) bcast = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int q = bcast;
+        __syncthreads();
+        if (q >= qn) break;
+        const int4 d = desc[q];
+        const int row = d.x, a0 = d.y, a1 = d.z;
+#if BHS_PHASES
+        unsigned long long tSpa = __builtin_readcyclecounter();
+#endif
+        // ---- pass 1: occupancy bits
+        expand(a0, a1, [&](int c, long long, int) {
+            if (BHS_ABL & 4096) { if (c < 0) bits[0] = 1u; }   // measurement only (with 2048): no bit atomics
+            else atomicOr(&bits[c >> 5], 1u << (c & 31));
+        });
         // The slot is private to this workgroup and every access to it is served by this XCD's L2
         // (device-scope atomics, sc1 loads, write-through stores), so a workgroup barrier (which drains
         // each wave's vmcnt) orders them; an agent-scope fence would write back the whole L2 (buffer_wbl2).
         __syncthreads();
-        // ---- scan the bitmap: thread t owns words [t*per, (t+1)*per); loads go out 8 at a time
-        const int per = (nWords + BLOCK - 1) / BLOCK;
+        BHS_TICK_SPA(8);
+        // ---- scan the bitmap: thread t owns the words [t*per, (t+1)*per), per a multiple of 4.  The bits were
+        // set by atomics in L2, so stale L1 lines are dropped first (acquire = buffer_inv, no write-back);
+        // then plain 16-byte loads.  Up to kWC words per thread stay in registers for all three sweeps
+        // (count, expand, clear): one memory round trip instead of a dozen on this latency-bound path.
+        constexpr int kWC = 32;
+        const int per = (((nWords + BLOCK - 1) / BLOCK) + 3) & ~3;
         const int wBeg = tid * per < nWords ? tid * per : nWords;
         const int wEnd = wBeg + per < nWords ? wBeg + per : nWords;
+        const bool cached = per <= kWC;                       // workgroup-uniform
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        unsigned wc[kWC];
         int mine = 0;
-        for (int w = wBeg; w < wEnd; w += 8) {
-            unsigned m[8];
+        if (cached) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                m[t] = (w + t < wEnd) ? __hip_atomic_load(&bits[w + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            for (int t = 0; t < kWC; t += 4) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (wBeg + t < wEnd) v = *reinterpret_cast<const uint4*>(&bits[wBeg + t]);
+                wc[t] = v.x; wc[t + 1] = v.y; wc[t + 2] = v.z; wc[t + 3] = v.w;
+            }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) mine += __popc(m[t]);
+            for (int t = 0; t < kWC; ++t) mine += __popc(wc[t]);
+        } else {
+            for (int w = wBeg; w < wEnd; w += 16) {
+                uint4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    v[t] = (w + 4 * t < wEnd) ? *reinterpret_cast<const uint4*>(&bits[w + 4 * t]) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mine += __popc(v[t].x) + __popc(v[t].y) + __popc(v[t].z) + __popc(v[t].w);
+            }
         }
         int inc2 = wave_incl_scan_dpp(mine);
         if (lane == 63) wtot[wv] = inc2;
@@ -691,49 +730,216 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
             rowCount += t;
         }
         off += inc2 - mine;                                   // entries of this row before this thread's words
-        if (!NUM) {
-            for (int w = wBeg; w < wEnd; ++w) bits[w] = 0u;     // leave the slot clean
-            if (tid == 0) cntOut[row] = rowCount;
+        BHS_TICK_SPA(9);
+        const long long base = d.w;
+        if (NUM) {
+            // each thread expands its words: rank per occupied word, columns in order, values zeroed
+            int run = off;
+            auto emit = [&](int w, unsigned mm) {
+                if (mm) rank[w] = run;                          // only occupied words are ever looked up
+                while (mm) {
+                    const int b = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    Cj[base + run] = (w << 5) + b;
+                    Cx[base + run] = (value_t)0;
+                    ++run;
+                }
+            };
+            if (cached) {
+#pragma unroll
+                for (int t = 0; t < kWC; ++t) emit(wBeg + t, wc[t]);
+            } else {
+                for (int w = wBeg; w < wEnd; w += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&bits[w]);
+                    emit(w, v.x); emit(w + 1, v.y); emit(w + 2, v.z); emit(w + 3, v.w);
+                }
+            }
+            __syncthreads();
+            BHS_TICK_SPA(10);
+            // ---- pass 2: every product lands in its final place
+            if (!(BHS_ABL & 2048))      // measurement only: 1024 = no adds, 2048 = no pass 2
+            expand(a0, a1, [&](int c, long long idx, int l) {
+                const int w = c >> 5;
+                const unsigned word = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int pos = __hip_atomic_load(&rank[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                __popc(word & ((1u << (c & 31)) - 1u));
+                if (BHS_ABL & 1024) { if (pos < 0) Cx[base] = sAv[l] * Bx[idx]; }
+                else unsafeAtomicAdd(&Cx[base + pos], (value_t)(sAv[l] * Bx[idx]));
+            });
+            __syncthreads();
+            BHS_TICK_SPA(11);
+        } else if (tid == 0) {
+            cntOut[row] = rowCount;
+        }
+        // ---- leave the slot clean
+        if (cached) {
+#pragma unroll
+            for (int t = 0; t < kWC; ++t)
+                if (wc[t]) bits[wBeg + t] = 0u;
         } else {
-            // column indices: each thread expands its words (stores only, nothing waits on them)
-            long long out = (long long)d.w + off;
-            for (int w = wBeg; w < wEnd; w += 8) {
-                unsigned m[8];
+            for (int w = wBeg; w < wEnd; w += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&bits[w]);
+                if (v.x | v.y | v.z | v.w) *reinterpret_cast<uint4*>(&bits[w]) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        __syncthreads();
+        BHS_TICK_SPA(12);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same bitmap accumulator with the bitmap in LDS, for matrices with up to
+// kLdsBitmapCols (2^20) columns: 128 KB of occupancy bits + 16 KB of rank words
+// (one per 256 columns) fill the CU's 160 KB, so one 1024-lane workgroup per CU.
+// Bit sets, the ordered sweep, the rank lookups of pass 2 and the final clear
+// are all LDS traffic; HBM/L2 see only the B rows (twice), the row of C and the
+// fp64 adds into it.  The sweep gives each lane one bitmap word per step, so a
+// wave's stores of Cj/Cx land on one contiguous run of the row.
+// ---------------------------------------------------------------------------
+constexpr int kLdsBitmapCols = 1 << 20;
+constexpr int kLdsBitmapBlock = 1024, kLdsBitmapChunk = 512;
+
+template <bool NUM>
+constexpr size_t lds_bitmap_smem(int nWords)
+{
+    return (size_t)nWords * 4 + (NUM ? (size_t)(nWords / 8) * 4 : 0) +
+           (size_t)kLdsBitmapChunk * (2 * sizeof(int) + (NUM ? sizeof(value_t) : 0)) + 32 * sizeof(int);
+}
+
+template <bool NUM>
+__global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
+    const int4* __restrict__ desc, int qn, int nWords,       // nWords: bitmap words, a multiple of 1024
+    const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket)
+{
+    constexpr int BLOCK = kLdsBitmapBlock, CH = kLdsBitmapChunk, U = 4, NW = BLOCK / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    unsigned* bm = reinterpret_cast<unsigned*>(smemRaw);
+    int* rank8 = reinterpret_cast<int*>(bm + nWords);
+    int* sIncl = rank8 + (NUM ? nWords / 8 : 0);
+    int* sBase = sIncl + CH;
+    int* wtot = sBase + CH;                                   // [NW] + broadcast word
+    value_t* sAv = reinterpret_cast<value_t*>(wtot + 32);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    for (int i = tid; i < nWords / 4; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // flat product space per chunk of CH A entries; f(column, product index in B, A entry slot)
+    auto expand = [&](int a0, int a1, auto&& f) {
+        for (int ca = a0; ca < a1; ca += CH) {
+            const int e = ca + tid;
+            int b0 = 0, len = 0;
+            value_t av = 0.0;
+            if (tid < CH && e < a1) {
+                const int c = Aj[e];
+                if (NUM) av = Ax[e];
+                int2 be;
+                __builtin_memcpy(&be, Bp + c, sizeof(be));
+                b0 = be.x;
+                len = be.y - be.x;
+            }
+            int incl = wave_incl_scan_dpp(len);
+            if (lane == 63) wtot[wv] = incl;
+            __syncthreads();
+            int woff = 0, total = 0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    m[t] = (w + t < wEnd) ? __hip_atomic_load(&bits[w + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            for (int w = 0; w < CH / 64; ++w) {
+                const int t = wtot[w];
+                if (w < wv) woff += t;
+                total += t;
+            }
+            incl += woff;
+            if (tid < CH) {
+                sIncl[tid] = incl;
+                sBase[tid] = b0 - (incl - len);
+                if (NUM) sAv[tid] = av;
+            }
+            __syncthreads();
+            for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    unsigned mm = m[t];
-                    if (mm) bits[w + t] = 0u;
-                    while (mm) {
-                        const int b = __ffs((int)mm) - 1;
-                        mm &= mm - 1;
-                        Cj[out++] = ((w + t) << 5) + b;
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * BLOCK + tid;
+                    if (p < total) {
+                        int l = 0, r = CH - 1;                   // first entry j with sIncl[j] > p
+                        while (l < r) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
+                        const long long idx = (long long)sBase[l] + p;
+                        f(Bj[idx], idx, l);
                     }
                 }
             }
             __syncthreads();
-            // values: all lanes gather spa[col] for the row's sorted columns, coalesced and independent
-            const long long base = d.w;
-            for (int r0 = 0; r0 < rowCount; r0 += BLOCK * U) {
-                int c[U];
-                value_t v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int r = r0 + u * BLOCK + tid;
-                    c[u] = r < rowCount ? __hip_atomic_load(&Cj[base + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    v[u] = c[u] >= 0 ? __hip_atomic_load(&spa[c[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int r = r0 + u * BLOCK + tid;
-                    if (c[u] >= 0) { Cx[base + r] = v[u]; spa[c[u]] = 0.0; }
-                }
-            }
         }
+    };
+
+    const int steps = nWords / BLOCK;                         // bitmap words per lane; wave wv owns words [wv*steps*64, ..)
+    for (;;) {
+        if (tid == 0) wtot[NW] = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int q = wtot[NW];
+        __syncthreads();
+        if (q >= qn) break;
+        const int4 d = desc[q];
+        const int row = d.x, a0 = d.y, a1 = d.z;
+        // ---- pass 1: occupancy bits
+        expand(a0, a1, [&](int c, long long, int) { atomicOr(&bm[c >> 5], 1u << (c & 31)); });
+        // ---- entries before each wave's words
+        const int w0 = wv * steps * 64;
+        int mine = 0;
+        for (int i = 0; i < steps; ++i) mine += __popc(bm[w0 + i * 64 + lane]);
+        const int waveCount = wave_sum_dpp(mine);
+        if (lane == 0) wtot[wv] = waveCount;
+        __syncthreads();
+        int run = 0, rowCount = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int t = wtot[w];
+            if (w < wv) run += t;
+            rowCount += t;
+        }
+        if (!NUM) {
+            if (tid == 0) cntOut[row] = rowCount;
+        } else {
+            // ---- ordered sweep: one word per lane per step; rank of every 8-word group, columns, zeroed values
+            const long long base = d.w;
+            for (int i = 0; i < steps; ++i) {
+                const int w = w0 + i * 64 + lane;
+                unsigned mm = bm[w];
+                const int cnt = __popc(mm);
+                const int incl = wave_incl_scan_dpp(cnt);
+                int r = run + incl - cnt;
+                if ((lane & 7) == 0) rank8[w >> 3] = r;
+                while (mm) {
+                    const int b = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    Cj[base + r] = (w << 5) + b;
+                    Cx[base + r] = (value_t)0;
+                    ++r;
+                }
+                run += __builtin_amdgcn_readlane(incl, 63);
+            }
+            // the zeroed values must be in L2 before any wave adds to them: the barrier drains every wave's stores
+            __syncthreads();
+            // ---- pass 2: every product is added straight into its place in the row of C
+            expand(a0, a1, [&](int c, long long idx, int l) {
+                const int w = c >> 5;
+                const uint4 lo = *reinterpret_cast<const uint4*>(&bm[w & ~7]);
+                const uint4 hi = *reinterpret_cast<const uint4*>(&bm[(w & ~7) + 4]);
+                const unsigned g[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const int k = w & 7;
+                int pos = rank8[w >> 3];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const unsigned mask = t < k ? 0xffffffffu : (t == k ? (1u << (c & 31)) - 1u : 0u);
+                    pos += __popc(g[t] & mask);
+                }
+                unsafeAtomicAdd(&Cx[base + pos], (value_t)(sAv[l] * Bx[idx]));
+            });
+        }
+        __syncthreads();
+        // ---- leave the bitmap clean
+        for (int i = tid; i < nWords / 4; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
 }

@@ -121,8 +121,8 @@ struct bhs_handle {
     long long nnzCt = 0;
     // workspace
     DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
-    DevBuf spaVals, spaBits;             // dense-accumulator slots for rows beyond the LDS tables (kept all-zero)
-    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0;
+    DevBuf spaRank, spaBits;             // bitmap-accumulator slots for rows beyond the LDS tables (bitmaps kept all-zero)
+    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1;
     bool spaDirty = false;
     int* hostSmall = nullptr;            // pinned mirror of `small`
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
@@ -239,23 +239,23 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     return BHS_SUCCESS;
 }
 
-// Dense-accumulator slots: one n-entry fp64 vector + n-bit bitmap per resident workgroup, sized against
-// 1/16 of the device memory, allocated once per column count and kept all-zero by the kernel itself.
+// Bitmap-accumulator slots: one n-bit bitmap + one rank word per 32 columns per resident workgroup, sized
+// against 1/16 of the device memory, allocated once per column count; the kernel leaves the bitmaps all-zero.
 int ensure_spa(bhs_handle* h)
 {
-    const size_t n = (size_t)std::max(h->n, 1), nWords = (n + 31) / 32;
+    const size_t n = (size_t)std::max(h->n, 1), nWords = ((n + 31) / 32 + 3) & ~(size_t)3;   // 16-byte groups
     if (h->spaCols == h->n && h->spaSlots > 0 && !h->spaDirty) return BHS_SUCCESS;
     size_t freeB = 0, totalB = 0;
     BHS_HIP(hipMemGetInfo(&freeB, &totalB));
-    const size_t perSlot = n * sizeof(value_t) + nWords * sizeof(unsigned);
+    const size_t perSlot = nWords * (sizeof(int) + sizeof(unsigned));
     long long slots = (long long)(std::min(totalB / 16, freeB / 2) / perSlot);
     slots = std::min<long long>(slots, h->spaMaxSlots > 0 ? (long long)h->spaMaxSlots : (long long)h->numCU);   // 1 per CU measured best
-    if (slots < 8) { h->spaSlots = 0; return BHS_SUCCESS; }       // too wide: the column-window path stays in charge
+    // every row scans the whole bitmap: beyond 2^25 columns (4 MB of bits) the column-window path stays in charge
+    if (slots < 8 || n > ((size_t)1 << 25)) { h->spaSlots = 0; return BHS_SUCCESS; }
     if (h->spaCols != h->n || h->spaSlots != (int)slots) {
-        BHS_TRY(ensure(h, h->spaVals, (size_t)slots * n * sizeof(value_t)));
+        BHS_TRY(ensure(h, h->spaRank, (size_t)slots * nWords * sizeof(int)));      // rank words
         BHS_TRY(ensure(h, h->spaBits, (size_t)slots * nWords * sizeof(unsigned)));
     }
-    BHS_HIP(hipMemsetAsync(h->spaVals.p, 0, (size_t)slots * n * sizeof(value_t), h->stream));
     BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->stream));
     h->spaSlots = (int)slots;
     h->spaCols = h->n;
@@ -266,13 +266,38 @@ int ensure_spa(bhs_handle* h)
 template <bool NUM>
 int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
-    constexpr int BLOCK = 512;
+#ifndef BHS_SPA_BLOCK
+#define BHS_SPA_BLOCK 1024
+#endif
+    constexpr int BLOCK = BHS_SPA_BLOCK;
     const long long grid = std::max<long long>(1, std::min<long long>(qn, h->spaSlots));
     int* small = (int*)h->small.p;
     BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->stream, queue, qn, h->n,
                        h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
-                       small + S_TICKET, (value_t*)h->spaVals.p, (unsigned*)h->spaBits.p);
+                       small + S_TICKET, (int*)h->spaRank.p, (unsigned*)h->spaBits.p);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+// Long rows of matrices with <= 2^20 columns: bitmap accumulator in LDS, one 1024-lane workgroup per CU.
+template <bool NUM>
+int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    auto kern = k_row_bitmap_lds<NUM>;
+    static bool attrSet = false;
+    if (!attrSet) {
+        BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bitmap_smem<NUM>(kLdsBitmapCols / 32)));
+        attrSet = true;
+    }
+    const int nWords = (int)((((long long)std::max(h->n, 1) + 31) / 32 + 1023) / 1024 * 1024);
+    const long long grid = std::max<long long>(1, std::min<long long>(qn, h->numCU));
+    int* small = (int*)h->small.p;
+    BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->stream, queue,
+                       qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
+                       small + S_TICKET);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -350,7 +375,10 @@ template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
-    if (c.win && h->spaSlots > 0 && h->useSpa && h->maxTableLog2 >= 15) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
+    if (c.win && h->useSpa && h->maxTableLog2 >= 15) {           // long rows: bitmap accumulators
+        if (h->useLdsBitmap && h->n <= kLdsBitmapCols) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
+        if (h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
+    }
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_WAVE(LG) \
@@ -703,7 +731,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->queue);
     release(h->blockSum);
     release(h->small);
-    release(h->spaVals);
+    release(h->spaRank);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
     if (h->hostRowPtr) (void)hipHostFree(h->hostRowPtr);
@@ -890,6 +918,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
         if (value < 5 || value > 75) return BHS_ERR_INVALID_ARG;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Measurement helper: per-phase workgroup cycles of numeric_long_rows (library built with -DBHS_PHASES=1)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from benchmark_spgemm_using_csr_amd import gallery, facade, _lib
+dev = torch.device("cuda", 0)
+rp, col = gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
+val = gallery.fill_values(len(col))
+Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
+Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+m = Bp.numel() - 1
+plats = [False] * 9; plats[3] = True
+bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
+assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
+raw = C.CDLL(_lib.SO_PATH)
+buf = (C.c_ulonglong * 16)()
+print("data ready", flush=True)
+for _ in range(2): assert bh.spgemm() == 0
+print("warm done", flush=True)
+raw.bhs_debug_phases(buf)
+assert bh.spgemm() == 0
+raw.bhs_debug_phases(buf)
+names = ["pass 1 (bits)", "count scan", "(block scan)", "expand cols + rank", "pass 2 (adds)", "clear"]
+idx = [8, 9, 9, 10, 11, 12]
+tot = sum(buf[i] for i in range(8, 13))
+for i, n in zip([8, 9, 10, 11, 12], ["pass 1 (bits)", "count + block scan", "columns + rank + zero", "pass 2 (adds)", "clear bits"]):
+    print("  %-24s %12d cycles  %5.1f %%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
+print({s["name"]: round(s["ms"], 3) for s in bh.kernel_stats() if s["ms"] > 0.1})

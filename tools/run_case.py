@@ -12,7 +12,9 @@ if name == "webbase":
     Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 else:
     st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
-                "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1))}[name]
+                "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1)),
+                "p27_slab16": ("poisson27pt", (16, 16, 8192)), "p27_slab32": ("poisson27pt", (32, 32, 2048)),
+                "p27_slab64": ("poisson27pt", (64, 64, 512))}[name]
     Bp, Bj = gallery.poisson_csr_torch(st, *dims, device=dev)
     Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
 f32 = os.environ.get('BHS_F32') == '1'
@@ -24,7 +26,7 @@ bh = facade.bhsparse(value_dtype=np.float32 if f32 else np.float64); assert bh.i
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
 for kv in os.environ.get('BHS_OPTS','').split(','):
     if kv: k_, v_ = kv.split('='); assert bh.set_option(k_, int(v_)) == 0
-for _ in range(2): assert bh.spgemm() == 0
+for _ in range(int(os.environ.get("BHS_WARM", "2"))): assert bh.spgemm() == 0
 acc = {}; info = {}; st = np.zeros(4); n = 5
 for _ in range(n):
     assert bh.spgemm() == 0
