@@ -27,13 +27,21 @@
 #ifndef BHS_PHASES
 #define BHS_PHASES 0
 #endif
-#if BHS_PHASES
+#ifndef BHS_PHASES_SPA
+#define BHS_PHASES_SPA 0
+#endif
+#if BHS_PHASES || BHS_PHASES_SPA
 __device__ unsigned long long g_phase_cycles[16];
-#define BHS_TICK(i) do { if (NUM) { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPrev; tPrev = t__; } } while (0)
+#endif
+#if BHS_PHASES_SPA
 #define BHS_TICK_SPA(i) do { if (NUM && tid == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], t__ - tSpa); tSpa = t__; } } while (0)
 #else
-#define BHS_TICK(i) do { } while (0)
 #define BHS_TICK_SPA(i) do { } while (0)
+#endif
+#if BHS_PHASES
+#define BHS_TICK(i) do { if (NUM) { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPrev; tPrev = t__; } } while (0)
+#else
+#define BHS_TICK(i) do { } while (0)
 #endif
 #include <stdint.h>
 #include <type_traits>
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
         if (q >= qn) break;
         const int4 d = desc[q];
         const int row = d.x, a0 = d.y, a1 = d.z;
-#if BHS_PHASES
+#if BHS_PHASES_SPA
         unsigned long long tSpa = __builtin_readcyclecounter();
 #endif
         // ---- pass 1: occupancy bits
@@ -802,8 +810,9 @@ constexpr int kLdsBitmapBlock = 1024, kLdsBitmapChunk = 512;
 template <bool NUM>
 constexpr size_t lds_bitmap_smem(int nWords)
 {
-    return (size_t)nWords * 4 + (NUM ? (size_t)(nWords / 8) * 4 : 0) +
-           (size_t)kLdsBitmapChunk * (2 * sizeof(int) + (NUM ? sizeof(value_t) : 0)) + 32 * sizeof(int);
+    // bitmap + (numeric) rank per 8 words + duplicate flags per 16 columns + A-chunk arrays + wave totals
+    return (size_t)nWords * 4 + (NUM ? (size_t)(nWords / 8) * 4 + (size_t)(nWords / 16) * 4 : 0) +
+           (size_t)kLdsBitmapChunk * 2 * sizeof(int) + 32 * sizeof(int);
 }
 
 template <bool NUM>
@@ -817,24 +826,25 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     unsigned* bm = reinterpret_cast<unsigned*>(smemRaw);
     int* rank8 = reinterpret_cast<int*>(bm + nWords);
-    int* sIncl = rank8 + (NUM ? nWords / 8 : 0);
+    // dup: one flag per 16 columns, set when a column of the group is hit twice.  Only those entries need the
+    // zero + atomic-add treatment; everything else (98.7 % of the products of a web graph) is a plain store.
+    unsigned* dup = reinterpret_cast<unsigned*>(rank8 + (NUM ? nWords / 8 : 0));
+    int* sIncl = reinterpret_cast<int*>(dup + (NUM ? nWords / 16 : 0));
     int* sBase = sIncl + CH;
     int* wtot = sBase + CH;                                   // [NW] + broadcast word
-    value_t* sAv = reinterpret_cast<value_t*>(wtot + 32);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nClear = (nWords + (NUM ? nWords / 8 + nWords / 16 : 0)) / 4;   // bitmap .. dup are contiguous
 
-    for (int i = tid; i < nWords / 4; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < nClear; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
-    // flat product space per chunk of CH A entries; f(column, product index in B, A entry slot)
+    // flat product space per chunk of CH A entries; f(column, product index in B, A entry index)
     auto expand = [&](int a0, int a1, auto&& f) {
         for (int ca = a0; ca < a1; ca += CH) {
             const int e = ca + tid;
             int b0 = 0, len = 0;
-            value_t av = 0.0;
             if (tid < CH && e < a1) {
                 const int c = Aj[e];
-                if (NUM) av = Ax[e];
                 int2 be;
                 __builtin_memcpy(&be, Bp + c, sizeof(be));
                 b0 = be.x;
@@ -854,7 +864,6 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
             if (tid < CH) {
                 sIncl[tid] = incl;
                 sBase[tid] = b0 - (incl - len);
-                if (NUM) sAv[tid] = av;
             }
             __syncthreads();
             for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                         int l = 0, r = CH - 1;                   // first entry j with sIncl[j] > p
                         while (l < r) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
                         const long long idx = (long long)sBase[l] + p;
-                        f(Bj[idx], idx, l);
+                        f(Bj[idx], idx, ca + l);
                     }
                 }
             }
@@ -875,6 +884,9 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
 
     const int steps = nWords / BLOCK;                         // bitmap words per lane; wave wv owns words [wv*steps*64, ..)
     for (;;) {
+#if BHS_PHASES_SPA
+        unsigned long long tSpa = __builtin_readcyclecounter();
+#endif
         if (tid == 0) wtot[NW] = atomicAdd(ticket, 1);
         __syncthreads();
         const int q = wtot[NW];
@@ -882,8 +894,14 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
         if (q >= qn) break;
         const int4 d = desc[q];
         const int row = d.x, a0 = d.y, a1 = d.z;
+        BHS_TICK_SPA(8);
         // ---- pass 1: occupancy bits
-        expand(a0, a1, [&](int c, long long, int) { atomicOr(&bm[c >> 5], 1u << (c & 31)); });
+        expand(a0, a1, [&](int c, long long, int) {
+            const unsigned bit = 1u << (c & 31);
+            const unsigned old = atomicOr(&bm[c >> 5], bit);
+            if (NUM && (old & bit)) atomicOr(&dup[c >> 9], 1u << ((c >> 4) & 31));
+        });
+        BHS_TICK_SPA(9);
         // ---- entries before each wave's words
         const int w0 = wv * steps * 64;
         int mine = 0;
@@ -898,6 +916,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
             if (w < wv) run += t;
             rowCount += t;
         }
+        BHS_TICK_SPA(10);
         if (!NUM) {
             if (tid == 0) cntOut[row] = rowCount;
         } else {
@@ -906,6 +925,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
             for (int i = 0; i < steps; ++i) {
                 const int w = w0 + i * 64 + lane;
                 unsigned mm = bm[w];
+                const unsigned dd = (dup[w >> 4] >> ((w & 15) * 2)) & 3u;   // flags of this word's two 16-column halves
                 const int cnt = __popc(mm);
                 const int incl = wave_incl_scan_dpp(cnt);
                 int r = run + incl - cnt;
@@ -914,15 +934,16 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                     const int b = __ffs((int)mm) - 1;
                     mm &= mm - 1;
                     Cj[base + r] = (w << 5) + b;
-                    Cx[base + r] = (value_t)0;
+                    if ((dd >> (b >> 4)) & 1u) Cx[base + r] = (value_t)0;
                     ++r;
                 }
                 run += __builtin_amdgcn_readlane(incl, 63);
             }
             // the zeroed values must be in L2 before any wave adds to them: the barrier drains every wave's stores
             __syncthreads();
+            BHS_TICK_SPA(11);
             // ---- pass 2: every product is added straight into its place in the row of C
-            expand(a0, a1, [&](int c, long long idx, int l) {
+            expand(a0, a1, [&](int c, long long idx, int e) {
                 const int w = c >> 5;
                 const uint4 lo = *reinterpret_cast<const uint4*>(&bm[w & ~7]);
                 const uint4 hi = *reinterpret_cast<const uint4*>(&bm[(w & ~7) + 4]);
@@ -934,13 +955,17 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                     const unsigned mask = t < k ? 0xffffffffu : (t == k ? (1u << (c & 31)) - 1u : 0u);
                     pos += __popc(g[t] & mask);
                 }
-                unsafeAtomicAdd(&Cx[base + pos], (value_t)(sAv[l] * Bx[idx]));
+                const value_t v = Ax[e] * Bx[idx];
+                if ((dup[c >> 9] >> ((c >> 4) & 31)) & 1u) unsafeAtomicAdd(&Cx[base + pos], v);
+                else Cx[base + pos] = v;                       // the only product of this column
             });
         }
         __syncthreads();
+        BHS_TICK_SPA(12);
         // ---- leave the bitmap clean
-        for (int i = tid; i < nWords / 4; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < nClear; i += BLOCK) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+        BHS_TICK_SPA(13);
     }
 }
 

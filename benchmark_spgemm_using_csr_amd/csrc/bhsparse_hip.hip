@@ -122,7 +122,7 @@ struct bhs_handle {
     // workspace
     DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
     DevBuf spaRank, spaBits;             // bitmap-accumulator slots for rows beyond the LDS tables (bitmaps kept all-zero)
-    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1;
+    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1, ldsBitmapMinLog2 = 12;
     bool spaDirty = false;
     int* hostSmall = nullptr;            // pinned mirror of `small`
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
@@ -379,6 +379,9 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
         if (h->useLdsBitmap && h->n <= kLdsBitmapCols) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
         if (h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     }
+    if (NUM && c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->useSpa && h->useLdsBitmap && h->n <= kLdsBitmapCols &&
+        h->maxTableLog2 >= 15 && h->forcePath == 0)
+        return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
 #define BHS_WAVE(LG) \
@@ -918,6 +921,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
@@ -950,7 +954,7 @@ const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type flo
 const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type double)"; }
 #endif
 
-#if BHS_PHASES
+#if BHS_PHASES || BHS_PHASES_SPA
 // measurement-only builds (tools/build_variants.sh -DBHS_PHASES=1): read and reset the phase counters
 __attribute__((visibility("default"))) int bhs_debug_phases(unsigned long long* out)
 {

@@ -21,9 +21,7 @@ print("warm done", flush=True)
 raw.bhs_debug_phases(buf)
 assert bh.spgemm() == 0
 raw.bhs_debug_phases(buf)
-names = ["pass 1 (bits)", "count scan", "(block scan)", "expand cols + rank", "pass 2 (adds)", "clear"]
-idx = [8, 9, 9, 10, 11, 12]
-tot = sum(buf[i] for i in range(8, 13))
-for i, n in zip([8, 9, 10, 11, 12], ["pass 1 (bits)", "count + block scan", "columns + rank + zero", "pass 2 (adds)", "clear bits"]):
-    print("  %-24s %12d cycles  %5.1f %%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
+tot = sum(buf[i] for i in range(8, 14))
+for i, n in zip(range(8, 14), ["ticket + descriptor", "pass 1 (bits)", "count sweep + block scan", "ordered sweep (Cj, zero Cx, rank)", "pass 2 (adds)", "clear bitmap"]):
+    print("  %-36s %12d cycles  %5.1f %%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
 print({s["name"]: round(s["ms"], 3) for s in bh.kernel_stats() if s["ms"] > 0.1})
