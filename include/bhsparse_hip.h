@@ -150,8 +150,11 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "max_table_log2"  cap (6..15) on the LDS table size => forces the column-window path
  *   "no_pack32"       1: always 64-bit sort keys
  *   "sym_load_pct", "num_load_pct"  table load factor (5..75 %) that decides a row's bin
- *   "spa"             0: rows beyond the LDS tables use column windows instead of the dense HBM accumulator
- *   "spa_slots"       dense-accumulator slots (default: one per CU)
+ *   "spa"             0: rows beyond the LDS tables use column windows instead of the bitmap accumulators
+ *   "lds_bitmap"      0: keep the long-row bitmap in HBM even when the matrix has <= 2^20 columns
+ *   "lds_bitmap_min_log2"  numeric workgroup bins with tables of at least 2^v slots go to the LDS bitmap
+ *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
+ *   "spa_slots"       HBM bitmap slots (default: one per CU)
  *   "wg_per_cu"       persistent workgroups per CU of the wave kernels (default: occupancy API)
  *   "verbose"         same as bhs_set_verbose
  * Returns BHS_ERR_INVALID_ARG for unknown keys.                               */

@@ -254,12 +254,47 @@ def test_hub_row_power_law(oracle):
     assert np.diff(Cp).max() > 6144      # at least one row is beyond every LDS table
     names = [k["name"] for k in info["kernels"]]
     assert "numeric_long_rows" in names
-    # dense accumulator in HBM (default) vs the column-window fallback: same bits
-    Cp2, Cj2, Cx2, _ = _check(oracle, m, m, m, A, A, options={"spa": 0})
-    assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
+    # the three long-row paths give the same bits: bitmap in LDS (default for n <= 2^20), bitmap in HBM
+    # (wider matrices), column windows (fallback of both)
+    for opts in ({"lds_bitmap": 0}, {"spa": 0}):
+        Cp2, Cj2, Cx2, _ = _check(oracle, m, m, m, A, A, options=opts)
+        assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
     # float values through the global fp64 atomics stay within tolerance
     valf = np.random.default_rng(1).standard_normal(len(col))
     _check(oracle, m, m, m, (rp, col, valf), (rp, col, valf), exact=False)
+
+
+@pytest.mark.parametrize("n", [2 ** 20, 2 ** 20 + 1, 3000000])
+def test_long_rows_bitmap_accumulators(oracle, n):
+    """Rows beyond the LDS hash tables, with and without duplicate columns, either side of the 2^20-column limit
+    of the LDS-resident bitmap (wider matrices keep the bitmap in HBM).  Replaces the reference's
+    EM_mergepath_global rounds (bhsparse_cuda.h:2270-2525)."""
+    rng = np.random.default_rng(n % 1000)
+    k = 2000
+    pool = np.sort(rng.choice(n, 5000, replace=False))           # half of the B rows collide inside this pool
+    rowsB = []
+    for j in range(k):
+        L = int(rng.integers(20, 60))
+        cols = rng.choice(pool, L, replace=False) if j < k // 2 else rng.choice(n, L, replace=False)
+        rowsB.append(np.sort(cols))
+    rowsB[k - 1] = np.array([0, 15, 16, 31, 32, n - 2, n - 1])   # first / last columns, 16-column group edges
+    rowsB[k - 2] = np.array([0, 16, n - 1])
+    Bp = np.zeros(k + 1, np.int32); Bp[1:] = np.cumsum([len(r) for r in rowsB])
+    Bj = np.concatenate(rowsB).astype(np.int32)
+    Bx = rng.integers(1, 10, len(Bj)).astype(np.float64)
+    rowsA = [np.sort(rng.choice(k, 1500, replace=False)), np.arange(k), np.sort(rng.choice(k, 10, replace=False)),
+             np.empty(0, np.int64), np.sort(rng.choice(k // 2, 600, replace=False)),
+             k // 2 + np.sort(rng.choice(k // 2, 300, replace=False)), np.arange(k - 700, k)]
+    Ap = np.zeros(len(rowsA) + 1, np.int32); Ap[1:] = np.cumsum([len(r) for r in rowsA])
+    Aj = np.concatenate(rowsA).astype(np.int32)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    A, B = (Ap, Aj, Ax), (Bp, Bj, Bx)
+    Cp, Cj, Cx, info = _check(oracle, len(rowsA), k, n, A, B)
+    assert np.diff(Cp).max() > 6144
+    assert "numeric_long_rows" in [kk["name"] for kk in info["kernels"]]
+    for opts in ({"lds_bitmap": 0}, {"spa": 0}, {"lds_bitmap_min_log2": 99}):
+        Cp2, Cj2, Cx2, _ = _check(oracle, len(rowsA), k, n, A, B, options=opts)
+        assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
 
 
 def test_huge_column_space():
