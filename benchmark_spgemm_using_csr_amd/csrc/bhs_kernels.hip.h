@@ -1141,7 +1141,7 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const acc_t
 
 template <int TS, int LOG2TS, bool NUM, bool PACK32>
 __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
-    const int4* __restrict__ desc, int qn,
+    const int4* __restrict__ desc, int qn, int chunkLog2,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
@@ -1159,22 +1159,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     constexpr int GRP = (MAXB % 4 == 0) ? 4 : (MAXB % 3 == 0 ? 3 : 2);                   // probes in flight per insert group
 
     // XCD-aware persistent schedule (gridDim.x is a multiple of 8; block b runs on XCD b % 8, tools/xcc_probe.hip).
-    // The queue is cut into chunks of kChunk consecutive entries and chunk k belongs to XCD k % 8: inside a
+    // The queue is cut into chunks of 2^chunkLog2 consecutive entries and chunk k belongs to XCD k % 8: inside a
     // chunk neighbouring rows share B rows through that XCD's private L2, while all eight XCDs stay within the
     // same few thousand rows of the matrix, so the B rows reused across grid planes form ONE working set in the
-    // 256 MB Infinity Cache instead of eight.
-    constexpr int kChunk = BHS_XCD_CHUNK;
+    // 256 MB Infinity Cache instead of eight.  The host picks 2048-entry chunks for long queues and smaller ones
+    // for short queues, so that every XCD still gets an equal share of a bin with only a few thousand rows.
+    const int chunk = 1 << chunkLog2;
     const int xcd = blockIdx.x & 7, lb = (blockIdx.x >> 3) * WPB + wave, perX = (gridDim.x >> 3) * WPB;
-    const int nChunks = (qn + kChunk - 1) / kChunk;
+    const int nChunks = (qn + chunk - 1) >> chunkLog2;
     int positions = 0;                                   // queue entries that belong to this XCD
     if (nChunks > xcd) {
-        positions = ((nChunks - xcd + 7) >> 3) * kChunk;
-        if (((nChunks - 1) & 7) == xcd) positions -= nChunks * kChunk - qn;
+        positions = ((nChunks - xcd + 7) >> 3) << chunkLog2;
+        if (((nChunks - 1) & 7) == xcd) positions -= (nChunks << chunkLog2) - qn;
     }
     const int nIt = lb < positions ? (positions - lb + perX - 1) / perX : 0;
     auto q_of = [&](int it) {                             // it-th entry of this wave (it < nIt)
         const int t = lb + it * perX;
-        return (((t / kChunk) << 3) + xcd) * kChunk + (t % kChunk);
+        return ((((t >> chunkLog2) << 3) + xcd) << chunkLog2) + (t & (chunk - 1));
     };
     const int4 kNoRow = make_int4(-1, 0, 0, 0);
 
@@ -1216,11 +1217,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
         }
         int myNew = 0;
+        // Rows with more than 64 A entries (power-law matrices: hundreds of short B rows per row) walk them in
+        // chunks of 64.  In the larger-table instantiations, where such rows live, the chunks are pipelined
+        // like the rows are: the B extents of chunk i+1 and the A entries of chunk i+2 are in flight while
+        // chunk i is accumulated.
+        constexpr bool kChunkPipe = NUM ? (TS >= 512) : (TS >= 2048);
+        const bool multi = kChunkPipe && (a1 - a0 > 64);
+        int cA = 0, cB = 0, b0N = 0, lenN = 0;
+        value_t avA = 0.0, avB = 0.0, avN = 0.0;
+        auto load_a = [&](int ea, int& c_, value_t& av_) {
+            c_ = 0; av_ = 0.0;
+            if (ea < a1) { c_ = Aj[ea]; if (NUM) av_ = Ax[ea]; }
+        };
+        auto gather_b = [&](int ea, int c_) {                 // extents of the chunk whose entries start at ea - lane
+            b0N = 0; lenN = 0;
+            if (ea < a1) { int2 be; __builtin_memcpy(&be, Bp + c_, 8); b0N = be.x; lenN = be.y - be.x; }
+        };
+        if (multi) load_a(a0 + 64 + lane, cA, avA);
         for (int ca = a0; ca < a1; ca += 64) {
             // ---- one A entry per lane: B row extent, flat product offsets
             int b0 = b0C, len = lenC;
             value_t av = avC;
-            if (ca != a0) {                                   // rows with > 64 entries: later chunks, unpipelined
+            if (multi) {
+                if (ca == a0) {
+                    load_a(ca + 128 + lane, cB, avB);
+                } else {
+                    b0 = b0N; len = lenN; av = avN;
+                    gather_b(ca + 64 + lane, cA);
+                    avN = avA;
+                    load_a(ca + 128 + lane, cA, avA);
+                }
+            } else if (ca != a0) {                            // small-table instantiations: later chunks, unpipelined
                 const int ea = ca + lane;
                 b0 = 0; len = 0; av = 0.0;
                 if (ea < a1) {
@@ -1330,6 +1357,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                         }
                     }
                 }
+            }
+            if (multi && ca == a0) {                          // first chunk done: its successor's extents (entries loaded at row start)
+                gather_b(ca + 64 + lane, cA);
+                avN = avA;
+                cA = cB; avA = avB;
             }
         }
         wave_sync();

@@ -322,7 +322,10 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);       // XCD-aware schedule needs a multiple of 8
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, h->dAj, h->dAx,
+    // XCD chunk: BHS_XCD_CHUNK entries for long queues; short queues get >= 8 chunks per XCD
+    int chunkLog2 = 0;
+    while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, chunkLog2, h->dAj, h->dAx,
                        h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
