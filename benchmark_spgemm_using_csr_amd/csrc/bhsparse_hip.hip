@@ -128,6 +128,16 @@ struct bhs_handle {
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
     size_t hostRowPtrCap = 0;
     hipStream_t copyStream = nullptr;    // D2H of rowPtrC overlaps the numeric stage
+    // The bins of a stage touch disjoint rows, so their kernels are independent: they are launched on a few
+    // side streams (forked from / joined into `stream` with events) and the small bins fill the tail of the
+    // large ones instead of each paying its own ramp-up and drain.
+    static constexpr int kBinStreams = 4;
+    hipStream_t binStream[kBinStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evFork = nullptr, evJoin[kBinStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t ls = nullptr;            // stream the launch helpers use (== stream unless a bin is being launched)
+    int ticketSlot = 101;                // ticket word (index into `small`) of the bin being launched; S_TICKET
+    int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
+    bool binsForked = false;
     hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
     bool wantHostRowPtr = false, rowPtrStaged = false;
     // options
@@ -146,14 +156,15 @@ struct bhs_handle {
 
 namespace {
 
-// layout of the `small` device buffer (ints)
+// layout of the `small` device buffer (ints): see the enum below
 enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S_NUM_START = 64,
        S_NUM_CURSOR = 80, S_TOTAL_CT = 96 /* 2 ints = u64 */, S_TOTAL_C = 98 /* 2 ints = i64 */,
        S_ERR = 100, S_TICKET = 101 /* dynamic row scheduler of the workgroup-per-row kernels */,
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
        S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_MAXROW = 301, S_SMALL_INTS = 320 };
+       S_SORTED = 300, S_MAXROW = 301,
+       S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */, S_SMALL_INTS = 320 };
 
 int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
 {
@@ -204,14 +215,14 @@ int timed_begin(bhs_handle* h, const char* name, EventPair** out)
     }
     EventPair* p = &h->evPool[h->evUsed++];
     p->stat = stat_index(h, name);
-    BHS_HIP(hipEventRecord(p->a, h->stream));
+    BHS_HIP(hipEventRecord(p->a, h->ls));
     *out = p;
     return BHS_SUCCESS;
 }
 
 int timed_end(bhs_handle* h, EventPair* p)
 {
-    BHS_HIP(hipEventRecord(p->b, h->stream));
+    BHS_HIP(hipEventRecord(p->b, h->ls));
     return BHS_SUCCESS;
 }
 
@@ -231,10 +242,10 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
         perCU = std::max(1, nb);
     }
     long long grid = std::max<long long>(1, std::min<long long>((long long)qn, (long long)h->numCU * perCU));
-    BHS_HIP(hipMemsetAsync((int*)h->small.p + S_TICKET, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->stream, queue, qn, h->n, h->bSorted, h->dAj,
+    BHS_HIP(hipMemsetAsync((int*)h->small.p + h->ticketSlot, 0, sizeof(int), h->ls));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->ls, queue, qn, h->n, h->bSorted, h->dAj,
                        h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
-                       (int*)h->small.p + S_ERR, (int*)h->small.p + S_TICKET);
+                       (int*)h->small.p + S_ERR, (int*)h->small.p + h->ticketSlot);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -256,7 +267,7 @@ int ensure_spa(bhs_handle* h)
         BHS_TRY(ensure(h, h->spaRank, (size_t)slots * nWords * sizeof(int)));      // rank words
         BHS_TRY(ensure(h, h->spaBits, (size_t)slots * nWords * sizeof(unsigned)));
     }
-    BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->stream));
+    BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->ls));
     h->spaSlots = (int)slots;
     h->spaCols = h->n;
     h->spaDirty = false;
@@ -272,10 +283,10 @@ int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     constexpr int BLOCK = BHS_SPA_BLOCK;
     const long long grid = std::max<long long>(1, std::min<long long>(qn, h->spaSlots));
     int* small = (int*)h->small.p;
-    BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->stream, queue, qn, h->n,
+    BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
+    hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->ls, queue, qn, h->n,
                        h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
-                       small + S_TICKET, (int*)h->spaRank.p, (unsigned*)h->spaBits.p);
+                       small + h->ticketSlot, (int*)h->spaRank.p, (unsigned*)h->spaBits.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -294,10 +305,10 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     const int nWords = (int)((((long long)std::max(h->n, 1) + 31) / 32 + 1023) / 1024 * 1024);
     const long long grid = std::max<long long>(1, std::min<long long>(qn, h->numCU));
     int* small = (int*)h->small.p;
-    BHS_HIP(hipMemsetAsync(small + S_TICKET, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->stream, queue,
+    BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->ls, queue,
                        qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
-                       small + S_TICKET);
+                       small + h->ticketSlot);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -325,7 +336,7 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     // XCD chunk: BHS_XCD_CHUNK entries for long queues; short queues get >= 8 chunks per XCD
     int chunkLog2 = 0;
     while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->stream, queue, qn, chunkLog2, h->dAj, h->dAx,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj, h->dAx,
                        h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -357,7 +368,7 @@ int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->stream, queue, qn, h->dAj, h->dAx, h->dBp, h->dBj,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->ls, queue, qn, h->dAj, h->dAx, h->dBp, h->dBj,
                        h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -443,8 +454,44 @@ int pow2_at_least(double x, int lo, int hi)
     return v;
 }
 
+// Concurrent bins: fork the side streams from `stream`, give every bin its own stream (round robin) and ticket
+// word, join them back.  Otherwise everything stays on `stream`, one kernel after another.
+int fork_bins(bhs_handle* h, const int* count, int nbins)
+{
+    h->ls = h->stream;
+    int used = 0;
+    for (int b = 1; b < nbins; ++b) used += count[b] > 0;
+    // forking and joining four streams costs ~70 us of event traffic: it pays for power-law matrices whose rows
+    // spread over many small bins, not for a stencil with one dominant bin
+    h->binsForked = h->concurrentBins == 1 || (h->concurrentBins == 2 && used >= 8);
+    if (!h->binsForked) return BHS_SUCCESS;
+    BHS_HIP(hipEventRecord(h->evFork, h->stream));
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i) BHS_HIP(hipStreamWaitEvent(h->binStream[i], h->evFork, 0));
+    return BHS_SUCCESS;
+}
+
+void bin_stream(bhs_handle* h, int bin)
+{
+    h->ticketSlot = S_TICKETS + bin;
+    h->ls = h->binsForked ? h->binStream[bin % bhs_handle::kBinStreams] : h->stream;
+}
+
+int join_bins(bhs_handle* h)
+{
+    h->ls = h->stream;
+    h->ticketSlot = S_TICKET;
+    if (!h->binsForked) return BHS_SUCCESS;
+    h->binsForked = false;
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i) {
+        BHS_HIP(hipEventRecord(h->evJoin[i], h->binStream[i]));
+        BHS_HIP(hipStreamWaitEvent(h->stream, h->evJoin[i], 0));
+    }
+    return BHS_SUCCESS;
+}
+
 int run_pipeline(bhs_handle* h)
 {
+    h->ls = h->stream;
     const int m = h->m;
     h->evUsed = 0;
     for (auto& s : h->stats) { s.launches = 0; s.ms = 0; s.rows = s.products = s.nnz_out = s.nnzA_rows = 0; }
@@ -507,16 +554,20 @@ int run_pipeline(bhs_handle* h)
     // ------------------------------------------------------------ stage 2: symbolic
     int symStat[kMaxBins], numStat[kMaxBins];
     for (int b = 0; b < kMaxBins; ++b) symStat[b] = numStat[b] = -1;
-    for (int b = 1; b < kNumSymBins; ++b) {
+    BHS_TRY(fork_bins(h, symCount, kNumSymBins));
+    for (int i = 1; i < kNumSymBins; ++i) {
+        const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
         if (!symCount[b]) continue;
+        bin_stream(h, b);
         BHS_TRY(timed_begin(h, kSymNames[b], &ep));
         int rc = dispatch_bin<false>(h, kSymCfg[b], (const int4*)h->queue.p + symStart[b], symCount[b], (int*)h->Cp.p);
-        if (rc) return rc;
+        if (rc) { h->ls = h->stream; return rc; }
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += symCount[b];
         symStat[b] = ep->stat;
     }
+    BHS_TRY(join_bins(h));
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
 
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
@@ -573,16 +624,20 @@ int run_pipeline(bhs_handle* h)
     }
 
     // ------------------------------------------------------------ stage 4: numeric
-    for (int b = 1; b < kNumNumBins; ++b) {
+    BHS_TRY(fork_bins(h, numCount, kNumNumBins));
+    for (int i = 1; i < kNumNumBins; ++i) {
+        const int b = kNumNumBins - i;
         if (!numCount[b]) continue;
+        bin_stream(h, b);
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
         int rc = dispatch_bin<true>(h, kNumCfg[b], (const int4*)h->queue.p + numStart[b], numCount[b], (int*)h->Cp.p);
-        if (rc) return rc;
+        if (rc) { h->ls = h->stream; return rc; }
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += numCount[b];
         numStat[b] = ep->stat;
     }
+    BHS_TRY(join_bins(h));
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipEventRecord(h->ev[4], h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
@@ -690,6 +745,11 @@ int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
     if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->evScanDone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->evCopyDone, hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    if (hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i)
+        if (hipStreamCreateWithFlags(&h->binStream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
+    h->ls = h->stream;
     if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * (S_SMALL_INTS + 2 * kMaxBins), hipHostMallocDefault) != hipSuccess) {
         delete h;
         return BHS_ERR_ALLOC;
@@ -741,6 +801,11 @@ int bhs_destroy(bhs_handle* h)
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
     if (h->hostRowPtr) (void)hipHostFree(h->hostRowPtr);
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i) {
+        if (h->binStream[i]) (void)hipStreamDestroy(h->binStream[i]);
+        if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
+    }
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->evScanDone) (void)hipEventDestroy(h->evScanDone);
     if (h->evCopyDone) (void)hipEventDestroy(h->evCopyDone);
@@ -924,6 +989,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }

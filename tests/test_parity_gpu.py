@@ -256,7 +256,8 @@ def test_hub_row_power_law(oracle):
     assert "numeric_long_rows" in names
     # the three long-row paths give the same bits: bitmap in LDS (default for n <= 2^20), bitmap in HBM
     # (wider matrices), column windows (fallback of both)
-    for opts in ({"lds_bitmap": 0}, {"spa": 0}):
+    # ... and so do the bins of a stage launched concurrently on side streams or one after another
+    for opts in ({"lds_bitmap": 0}, {"spa": 0}, {"concurrent_bins": 1}, {"concurrent_bins": 0}):
         Cp2, Cj2, Cx2, _ = _check(oracle, m, m, m, A, A, options=opts)
         assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
     # float values through the global fp64 atomics stay within tolerance
