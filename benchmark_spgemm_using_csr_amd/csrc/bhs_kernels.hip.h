@@ -394,11 +394,18 @@ __global__ __launch_bounds__(256) void k_check_sorted(int k, const int* __restri
 //     restricts its B row to the range by two binary searches; an overflowing
 //     range is halved and retried, a sparse one doubles the next.  Ranges come
 //     out in ascending column order, so the concatenation is the sorted row;
-//   * numeric: the table is sorted IN PLACE (keys with their values, empty
-//     slots = 0xffffffff sort last) by a bitonic network in LDS and the first
-//     `uniq` slots are streamed to C — no second copy of the table, which lets
-//     an 8192-slot fp64 table fit the 160 KiB LDS.
+//   * numeric: every lane packs TS/BLOCK slots as (column << 32 | slot) and the
+//     workgroup sorts them in REGISTERS: a DPP bitonic sort per wave, then
+//     flip-merges across waves that exchange through the (no longer needed)
+//     key array -- a dozen barriers instead of one per network stage, and no
+//     second copy of the table, which lets an 8192-slot fp64 table fit the
+//     160 KiB LDS.  Values never move: they are read by slot when C is written.
 // ---------------------------------------------------------------------------
+// sorts the occupied slots of a workgroup's table by column and streams (column, value) to C; defined below
+template <int TS, int BLOCK>
+__device__ __forceinline__ void block_sort_and_store(int* keys, const acc_t* vals, int uniq, int tid,
+                                                     int* __restrict__ Cj, value_t* __restrict__ Cx, long long outBase);
+
 template <int TS, int BLOCK, bool NUM>
 struct BlockSmem {
     int keys[TS];
@@ -556,30 +563,11 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                 else width = (width + 1) >> 1;
                 continue;
             }
-            if (!NUM) {
+            if constexpr (!NUM) {
                 rowTotal += uniq;
             } else if (uniq > 0) {
-                // ---- in-place bitonic sort of the whole table (keys as unsigned: empty = 0xffffffff last)
-                for (int kk = 2; kk <= TS; kk <<= 1) {
-                    for (int j = kk >> 1; j > 0; j >>= 1) {
-                        for (int i = tid; i < (TS >> 1); i += BLOCK) {
-                            const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                            const int b = a | j;
-                            const bool up = (a & kk) == 0;
-                            const unsigned x = (unsigned)sm.keys[a], y = (unsigned)sm.keys[b];
-                            if ((x > y) == up && x != y) {
-                                sm.keys[a] = (int)y; sm.keys[b] = (int)x;
-                                const acc_t va = sm.vals[a], vb = sm.vals[b];
-                                sm.vals[a] = vb; sm.vals[b] = va;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
-                for (int r = tid; r < uniq; r += BLOCK) {
-                    Cj[outBase + r] = sm.keys[r];
-                    Cx[outBase + r] = (value_t)sm.vals[r];
-                }
+                // ---- sort by column in registers (no second copy of the table) and stream the row out
+                block_sort_and_store<TS, BLOCK>(sm.keys, sm.vals, uniq, tid, Cj, Cx, outBase);
                 outBase += uniq;
                 __syncthreads();
             }
@@ -1104,6 +1092,94 @@ __device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
                     }
                 }
             }
+        }
+    }
+}
+
+// ascending merge of a wave's 64*E keys that form a bitonic sequence (element index i = lane*E + e)
+template <typename T, int E>
+__device__ __forceinline__ void wave_merge_asc(T (&x)[E], int lane)
+{
+#pragma unroll
+    for (int j = 32 * E; j > 0; j >>= 1) {
+        if (j >= E) {
+            const int lj = j / E;
+            const bool lower = (lane & lj) == 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T y = lane_xor_any<T>(x[e], lj, lane);
+                const T lo = x[e] < y ? x[e] : y;
+                const T hi = x[e] < y ? y : x[e];
+                x[e] = lower ? lo : hi;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if ((e & j) == 0) {
+                    const T a = x[e], b = x[e | j];
+                    const bool sw = a > b;
+                    x[e] = sw ? b : a;
+                    x[e | j] = sw ? a : b;
+                }
+            }
+        }
+    }
+}
+
+template <int TS, int BLOCK>
+__device__ __forceinline__ void block_sort_and_store(int* keys, const acc_t* vals, int uniq, int tid,
+                                                     int* __restrict__ Cj, value_t* __restrict__ Cx, long long outBase)
+{
+    constexpr int E = TS / BLOCK;                 // slots per lane
+    constexpr int SEG = 64 * E;                   // keys per wave
+    using T = unsigned long long;
+    const int lane = tid & 63;
+    const int i0 = tid * E;                       // element index of x[0]: wave w owns [w*SEG, (w+1)*SEG)
+    T x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = keys[i0 + e];
+        x[e] = k == kEmpty ? ~0ull : (((T)(unsigned)k << 32) | (unsigned)(i0 + e));   // empty slots sort last
+    }
+    wave_bitonic_sort<T, E>(x, lane);             // every wave: its SEG keys ascending
+    __syncthreads();                              // all lanes have read their keys: the array is free
+    unsigned* xch = reinterpret_cast<unsigned*>(keys);
+    // partner exchange across waves: high words, then low words, through the key array
+    auto exchange = [&](int mask) {
+        T y[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) xch[i0 + e] = (unsigned)(x[e] >> 32);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) y[e] = (T)xch[(i0 + e) ^ mask] << 32;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) xch[i0 + e] = (unsigned)x[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) y[e] |= (T)xch[(i0 + e) ^ mask];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool lower = (i0 + e) < ((i0 + e) ^ mask);
+            const T lo = x[e] < y[e] ? x[e] : y[e];
+            const T hi = x[e] < y[e] ? y[e] : x[e];
+            x[e] = lower ? lo : hi;
+        }
+    };
+#pragma unroll
+    for (int kk = 2 * SEG; kk <= TS; kk <<= 1) {
+        exchange(kk - 1);                         // flip: two ascending runs -> two bitonic halves
+#pragma unroll
+        for (int j = kk >> 2; j >= SEG; j >>= 1) exchange(j);
+        wave_merge_asc<T, E>(x, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int r = i0 + e;
+        if (r < uniq) {
+            Cj[outBase + r] = (int)(x[e] >> 32);
+            Cx[outBase + r] = (value_t)vals[(unsigned)x[e]];
         }
     }
 }
