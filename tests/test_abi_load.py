@@ -40,7 +40,7 @@ def test_code_object_is_gfx950():
     assert os.path.exists(so)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob
-    for kern in (b"k_row_wave", b"k_row_quad", b"k_row_block", b"k_row_spa", b"k_upper_bound"):
+    for kern in (b"k_row_wave", b"k_row_quad", b"k_row_block", b"k_row_spa", b"k_row_bitmap_lds", b"k_upper_bound"):
         assert kern in blob           # the accumulator kernels are in the fat binary
 
 

@@ -299,8 +299,8 @@ def test_long_rows_bitmap_accumulators(oracle, n):
 
 
 def test_huge_column_space():
-    """n = 2^31 - 1 columns: column indices up to INT_MAX - 1, 64-bit sort keys, dense accumulator
-    impossible (falls back to column windows).  Checked against a numpy reference built here because
+    """n = 2^31 - 1 columns: column indices up to INT_MAX - 1, 64-bit sort keys, bitmap accumulators
+    out of range (falls back to column windows).  Checked against a numpy reference built here because
     the oracle's dense marker array would need 16 GB per thread."""
     rng = np.random.default_rng(9)
     n = 2 ** 31 - 1

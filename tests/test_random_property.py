@@ -1,6 +1,6 @@
 """Property tests on random CSR pairs (hypothesis): the oracle against scipy on the CPU, the HIP path
 against the oracle on the GPU.  Shapes, densities and row-length skew are drawn so that every
-accumulator family (quarter-wave, wave, workgroup, dense HBM accumulator) is reachable."""
+accumulator family (quarter-wave, wave, workgroup, bitmap accumulator) is reachable."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
