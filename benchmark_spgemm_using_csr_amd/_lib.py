@@ -6,6 +6,7 @@ product path never routes through a CPU implementation.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -75,6 +76,14 @@ def load(f32=False):
             raise ImportError(
                 "%s is not built (%s). Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C %s`. There is no CPU fallback." % (os.path.basename(path), path, CSRC))
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and two HSA runtimes in one
+        # process cannot both own the GPU (the one initialised second reports no device).  When torch is
+        # installed, let it load its runtime first: this library then binds to the same copy by soname.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)      # AttributeError if the library does not export it

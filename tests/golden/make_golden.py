@@ -106,5 +106,43 @@ def main():
     print(json.dumps(sums, indent=1, sort_keys=True))
 
 
+def full_size():
+    """BASELINE.json configs[1] and configs[2] at full size (poisson5pt 1024^2, poisson27pt 128^3): digests only,
+    merged into checksums.json (scipy needs ~2 minutes and ~12 GB for the 27-point case)."""
+    path = os.path.join(HERE, "checksums.json")
+    sums = json.load(open(path))
+    for tag, name, dims in (("p5_1024", "poisson5pt", (1024, 1024, 1)), ("p27_128", "poisson27pt", (128, 128, 128)),
+                            ("powerlaw_1m", "powerlaw", (1000005, 3105536, 4700))):
+        if tag in sums and "--force" not in sys.argv:
+            continue
+        if name == "powerlaw":        # stand-in for configs[3] (webbase-1M: the SuiteSparse file is not in the image)
+            rp, col = gallery.powerlaw_csr(dims[0], dims[0], dims[1], dims[2])
+        else:
+            rp, col = gallery.poisson_csr(name, *dims)
+        val = gallery.fill_values(len(col))
+        m = len(rp) - 1
+        A = sp.csr_matrix((val, col, rp), shape=(m, m))
+        C, _ = product_no_ct(A, A)
+        ones = sp.csr_matrix((np.ones(A.nnz), A.indices, A.indptr), shape=A.shape)
+        ct = int((ones @ np.diff(A.indptr).astype(np.float64)).sum())       # sum over A entries of the B row length
+        d = digest(C, ct)
+        t = np.arange(C.nnz, dtype=np.uint64) % np.uint64(8191) + np.uint64(1)
+        d["wsum_val"] = float((C.data * t.astype(np.float64)).sum())      # integers < 2^53: exact in any order
+        d.update({"stencil": name, "dims": list(dims), "m": m, "nnzA": int(A.nnz)})
+        sums[tag] = d
+        print(tag, d, flush=True)
+    with open(path, "w") as f:
+        json.dump(sums, f, indent=1, sort_keys=True)
+
+
+def product_no_ct(A, B):
+    C = (A @ B).tocsr()
+    C.sort_indices()
+    return C, None
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--full":
+        full_size()
+    else:
+        main()
