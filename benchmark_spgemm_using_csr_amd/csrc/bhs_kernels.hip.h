@@ -1479,9 +1479,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 wave_sort_and_store<LOG2TS, PACK32, 2>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
             else if (TS >= 256 && uniq <= 256)
                 wave_sort_and_store<LOG2TS, PACK32, 4>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
-            else if (TS >= 512) {
-                // large tables: bitonic network in LDS (rare bins)
-                int P = 512;
+            else if (TS >= 512 && uniq <= 512)
+                wave_sort_and_store<LOG2TS, PACK32, 8>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+            else if (TS >= 1024 && uniq <= 1024)
+                wave_sort_and_store<LOG2TS, PACK32, 16>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+            else if (TS >= 2048) {
+                // tables beyond 1024 slots (only reachable with forced options): bitonic network in LDS
+                int P = 2048;
                 while (P < uniq) P <<= 1;
                 for (int s = uniq + lane; s < P; s += 64) sm.packed[s] = (packed_t)~(packed_t)0;
                 wave_sync();
