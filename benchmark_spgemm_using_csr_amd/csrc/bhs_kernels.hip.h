@@ -507,12 +507,13 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
 
                 for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
                     int col[U];
-                    acc_t pv[U];
+                    value_t bxu[U], avu[U];                          // multiplied at insert time: no wait behind each load
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int p = p0 + u * BLOCK + tid;
                         col[u] = kEmpty;
-                        pv[u] = 0.0;
+                        bxu[u] = 0.0;
+                        avu[u] = 0.0;
                         if (p < total) {
                             int l = 0, r = BLOCK - 1;            // first entry j with sIncl[j] > p
                             while (l < r) { const int mid = (l + r) >> 1; if (sm.sIncl[mid] > p) r = mid; else l = mid + 1; }
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                             const int c = Bj[idx];
                             if (full || bSorted || ((long long)c >= lo && (long long)c < hi)) {
                                 col[u] = c;
-                                if (NUM) pv[u] = (acc_t)sm.sAv[l] * (acc_t)Bx[idx];
+                                if (NUM) { avu[u] = sm.sAv[l]; bxu[u] = Bx[idx]; }
                             }
                         }
                     }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                                 h = (h + 1) & (TS - 1);
                                 if (++probes >= TS) { ovf = true; break; }
                             }
-                            if (NUM && !ovf) unsafeAtomicAdd(&sm.vals[h], pv[u]);
+                            if (NUM && !ovf) unsafeAtomicAdd(&sm.vals[h], (acc_t)avu[u] * (acc_t)bxu[u]);
                         }
                     }
                     // ---- fill level after this batch (one LDS atomic per wave)
@@ -988,10 +989,16 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
 #ifndef BHS_NT_STORES
 #define BHS_NT_STORES 0
 #endif
-// ask the register allocator for >= 6 waves per SIMD: the accumulator is latency-bound (LDS round trips),
-// measured -8 % on the numeric pass versus the 5 waves the unconstrained allocation reaches
+// numeric loads: valB and the A value of a batch stay in registers and are multiplied when the batch is
+// inserted (1; 2 keeps the A entry index instead of its value; 0 = multiply behind the load, which makes every
+// valB load wait for its data before the next batch's loads are issued: measured 3.92 -> 3.80 ms on p27 128^3)
+#ifndef BHS_DEFER_MUL
+#define BHS_DEFER_MUL 1
+#endif
+// ask the register allocator for >= 5 waves per SIMD (<= 96 VGPRs).  With the deferred multiply the window
+// holds 6 x (col, valB, av) in registers; 6 waves (80 VGPRs) spill, measured 3.80 vs 3.49 ms.
 #ifndef BHS_WAVE_ATTR
-#define BHS_WAVE_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
+#define BHS_WAVE_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 // first probe = one ds_cmpst_rtn (claims an empty slot or returns the resident key) instead of
 // ds_read + conditional ds_cmpst: measured -19 % symbolic / -8 % numeric on poisson27pt
@@ -1356,12 +1363,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 wave_sync();
                 int col[MAXB];
                 acc_t pv[MAXB];
+#if BHS_DEFER_MUL == 1
+                value_t bxv[MAXB], avv[MAXB];
+#elif BHS_DEFER_MUL == 2
+                value_t bxv[MAXB];
+                int jjv[MAXB];
+#endif
                 int cum = done;
-                // ---- all loads of the window first
+                // ---- all loads of the window first.  The product av * valB is formed only when the batch is
+                // inserted: multiplying here would put an s_waitcnt on every valB load right behind its issue
+                // and serialise the window's loads.
 #pragma unroll
                 for (int u = 0; u < MAXB; ++u) {
                     col[u] = kEmpty;
                     pv[u] = 0.0;
+#if BHS_DEFER_MUL == 1
+                    bxv[u] = 0.0; avv[u] = 0.0;
+#elif BHS_DEFER_MUL == 2
+                    bxv[u] = 0.0; jjv[u] = 0;
+#endif
                     if (u < nb) {
                         const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
                         const int p = w0 + u * 64 + lane;
@@ -1372,8 +1392,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                             if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
                             else col[u] = Bj[idx];
                             if (NUM) {
+#if BHS_DEFER_MUL == 1
+                                avv[u] = sm.sAv[j];
+                                bxv[u] = Bx[idx];
+#elif BHS_DEFER_MUL == 2
+                                jjv[u] = j;
+                                bxv[u] = Bx[idx];
+#else
                                 const acc_t avj = (abl & 64) ? 1.0 : (acc_t)sm.sAv[j];
                                 pv[u] = (abl & 32) ? avj : avj * (acc_t)Bx[idx];
+#endif
                             }
                         }
                     }
@@ -1428,6 +1456,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                                     }
                                     hh[v] = h;
                                 }
+#if BHS_DEFER_MUL == 1
+                                if (NUM) pv[g + v] = (acc_t)avv[g + v] * (acc_t)bxv[g + v];
+#elif BHS_DEFER_MUL == 2
+                                if (NUM) pv[g + v] = (acc_t)sm.sAv[jjv[g + v]] * (acc_t)bxv[g + v];
+#endif
                                 if (NUM && !(abl & 1)) unsafeAtomicAdd(&sm.vals[hh[v]], pv[g + v]);
                             }
                         }
@@ -1646,18 +1679,19 @@ __global__ __launch_bounds__(64) void k_row_quad(
             wave_sync();
             const unsigned long long mk = sm.marks[g];
             int col[4];
-            acc_t pv[4];
+            value_t bxq[4], avq[4];                                 // multiplied at insert time: no wait behind each load
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 col[u] = kEmpty;
-                pv[u] = 0.0;
+                bxq[u] = 0.0;
+                avq[u] = 0.0;
                 const int pr = u * 16 + l16;                        // product index inside the window
                 const int p = w0 + pr;
                 if (p < total) {
                     const int j = done + __popcll(mk & ((1ull << pr) - 1ull));
                     const long long idx = (long long)sm.sBase[g][j] + p;
                     col[u] = Bj[idx];
-                    if (NUM) pv[u] = (acc_t)sm.sAv[g][j] * (acc_t)Bx[idx];
+                    if (NUM) { avq[u] = sm.sAv[g][j]; bxq[u] = Bx[idx]; }
                 }
             }
             done += __popcll(mk);
@@ -1685,7 +1719,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
                         }
                         hh[u] = h;
                     }
-                    if (NUM) unsafeAtomicAdd(&sm.vals[g][hh[u]], pv[u]);
+                    if (NUM) unsafeAtomicAdd(&sm.vals[g][hh[u]], (acc_t)avq[u] * (acc_t)bxq[u]);
                 }
             }
         }
