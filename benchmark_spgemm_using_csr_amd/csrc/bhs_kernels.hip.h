@@ -1260,12 +1260,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         const int t = lb + it * perX;
         return ((((t >> chunkLog2) << 3) + xcd) << chunkLog2) + (t & (chunk - 1));
     };
-    const int4 kNoRow = make_int4(-1, 0, 0, 0);
+    // Descriptor of this wave's it-th row, (-1,0,0,0) past the end.  Always a load from the queue (a clamped
+    // index, then a select of the VALUES): "cond ? desc[q] : constant" becomes a select of two ADDRESSES, one of
+    // them a stack copy of the constant, and the load a FLAT load -- which counts on lgkmcnt as well as vmcnt, so
+    // the next wait for any LDS read would also wait for this prefetch to come back from memory.  The laundered
+    // zero keeps the address in VGPRs: a global (vmcnt-only) load, not a scalar one (lgkmcnt again).
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    auto load_desc = [&](int it_) {
+        const bool has = it_ < nIt;
+        int4 r = desc[q_of(has ? it_ : 0) + vzero];
+        if (!has) r = make_int4(-1, 0, 0, 0);
+        return r;
+    };
 
     // ---- software pipeline over rows: descriptor (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
-    int4 dC = nIt > 0 ? desc[q_of(0)] : kNoRow;
-    int4 d1 = nIt > 1 ? desc[q_of(1)] : kNoRow;
-    int4 d2 = nIt > 2 ? desc[q_of(2)] : kNoRow;
+    if (nIt == 0) return;                                // (wave-uniform; there is no barrier in this kernel)
+    int4 dC = load_desc(0);
+    int4 d1 = load_desc(1);
+    int4 d2 = load_desc(2);
     int cC = 0, c1 = 0;
     value_t avC = 0.0, av1 = 0.0;
     if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
@@ -1279,7 +1292,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
 #endif
     for (int it = 0; it < nIt; ++it) {
         // ---- prefetch for the rows behind this one
-        const int4 d3 = (it + 3 < nIt) ? desc[q_of(it + 3)] : kNoRow;
+        const int4 d3 = load_desc(it + 3);
         int c2 = 0;
         value_t av2 = 0.0;
         if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
