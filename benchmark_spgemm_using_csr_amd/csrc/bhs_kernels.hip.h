@@ -512,8 +512,6 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                     for (int u = 0; u < U; ++u) {
                         const int p = p0 + u * BLOCK + tid;
                         col[u] = kEmpty;
-                        bxu[u] = 0.0;
-                        avu[u] = 0.0;
                         if (p < total) {
                             int l = 0, r = BLOCK - 1;            // first entry j with sIncl[j] > p
                             while (l < r) { const int mid = (l + r) >> 1; if (sm.sIncl[mid] > p) r = mid; else l = mid + 1; }
@@ -1388,12 +1386,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                 // and serialise the window's loads.
 #pragma unroll
                 for (int u = 0; u < MAXB; ++u) {
-                    col[u] = kEmpty;
+                    col[u] = kEmpty;                          // (valB / A value registers are only read where col is valid)
+#if !BHS_DEFER_MUL
                     pv[u] = 0.0;
-#if BHS_DEFER_MUL == 1
-                    bxv[u] = 0.0; avv[u] = 0.0;
-#elif BHS_DEFER_MUL == 2
-                    bxv[u] = 0.0; jjv[u] = 0;
 #endif
                     if (u < nb) {
                         const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
@@ -1696,8 +1691,6 @@ __global__ __launch_bounds__(64) void k_row_quad(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 col[u] = kEmpty;
-                bxq[u] = 0.0;
-                avq[u] = 0.0;
                 const int pr = u * 16 + l16;                        // product index inside the window
                 const int p = w0 + pr;
                 if (p < total) {
