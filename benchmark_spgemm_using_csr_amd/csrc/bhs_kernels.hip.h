@@ -1069,6 +1069,10 @@ template <typename T, int E, int GW = 64>
 __device__ __forceinline__ void wave_bitonic_sort(T (&x)[E], int lane)
 {
     // GW = lanes per independent sort (64: whole wave; 16: four quarter-wave sorts side by side, DPP only)
+    if constexpr (sizeof(T) == 4) {        // 32-bit keys: the cheaper ascending-only network (bhs_wave.hip.h)
+        wave_flip_sort_u32<E, GW>(x, lane);
+        return;
+    }
     lane &= GW - 1;
 #pragma unroll
     for (int k = 2; k <= GW * E; k <<= 1) {
@@ -1691,6 +1695,8 @@ __global__ __launch_bounds__(64) void k_row_quad(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 col[u] = kEmpty;
+                bxq[u] = 0.0;                                       // (left uninitialised the kernel gets slower: measured)
+                avq[u] = 0.0;
                 const int pr = u * 16 + l16;                        // product index inside the window
                 const int p = w0 + pr;
                 if (p < total) {
