@@ -98,6 +98,10 @@ __device__ __forceinline__ int wave_sum(int v) { return wave_sum_dpp(v); }
 // that colIndA reads are coalesced and lanes are busy).  Also: total product
 // count (int64), histogram of symbolic bins, and rowCnt[i] = 0 for empty rows.
 // ---------------------------------------------------------------------------
+// rows each lane group keeps in flight: short rows (G <= 8 lanes per row: poisson5pt, web graphs) are pure
+// latency, 8 rows hide it (poisson5pt 1024^2: 0.109 -> 0.066 ms); longer rows are gather-bound and 4 is best
+__host__ __device__ constexpr int ub_rows_in_flight(int G) { return G <= 8 ? 8 : 4; }
+
 template <int G>
 __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restrict__ Ap,
                                                      const int* __restrict__ Aj,
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
     // The per-row work is a chain of three dependent loads (rowPtrA -> colIndA -> rowPtrB) and little
     // else, so every lane group keeps R rows in flight: all rowPtrA pairs, then all colIndA, then all
     // rowPtrB gathers are issued before the first sum is needed.
-    constexpr int R = 4;
+    constexpr int R = ub_rows_in_flight(G);
     __shared__ int hist[kMaxBins];
     __shared__ unsigned long long bsum;
     const int tid = threadIdx.x;

@@ -429,7 +429,8 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
 {
     const int G = h->ubG;
     const int rowsPerBlock = 256 / G;
-    long long grid = ((long long)h->m + rowsPerBlock * 4 - 1) / (rowsPerBlock * 4);   // 4 rows per lane group per pass
+    const int R = ub_rows_in_flight(G);
+    long long grid = ((long long)h->m + rowsPerBlock * R - 1) / (rowsPerBlock * R);   // R rows per lane group per pass
     grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * 32));
     int* small = (int*)h->small.p;
 #define BHS_UB(GG)                                                                                   \
