@@ -229,14 +229,24 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
                 const int lbin = __shfl(b, leader, 64);
                 const bool mine = (b == lbin);
                 const unsigned long long peers = __ballot(mine);
-                unsigned long long s0 = mine ? (unsigned long long)(unsigned)ubv : 0ull;
-                unsigned long long s1 = (mine && FROM_ROWPTR) ? (unsigned long long)v : 0ull;
-                unsigned long long s2 = mine ? (unsigned long long)(a1 - a0) : 0ull;
+                // per-bin statistics of this wave's rows (bhs_get_kernel_stats): DPP sums while the addends are
+                // small (the usual case), 64-bit butterflies otherwise
+                unsigned long long s0, s1 = 0ull, s2;
+                const int x0 = mine ? ubv : 0, x1 = (mine && FROM_ROWPTR) ? v : 0, x2 = mine ? a1 - a0 : 0;
+                if (!__any((x0 | x1 | x2) >= (1 << 24))) {
+                    s0 = (unsigned long long)(unsigned)wave_sum_dpp(x0);
+                    if (FROM_ROWPTR) s1 = (unsigned long long)(unsigned)wave_sum_dpp(x1);
+                    s2 = (unsigned long long)(unsigned)wave_sum_dpp(x2);
+                } else {
+                    s0 = (unsigned long long)(unsigned)x0;
+                    s1 = (unsigned long long)(unsigned)x1;
+                    s2 = (unsigned long long)(unsigned)x2;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    s0 += __shfl_xor(s0, o, 64);
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
+                    for (int o = 32; o > 0; o >>= 1) {
+                        s0 += __shfl_xor(s0, o, 64);
+                        s1 += __shfl_xor(s1, o, 64);
+                        s2 += __shfl_xor(s2, o, 64);
+                    }
                 }
                 int wbase = 0;
                 if ((tid & 63) == leader) {
