@@ -191,7 +191,13 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
 // a block stay together so queue order stays close to row order (L2 locality
 // of the B rows they touch).
 // ---------------------------------------------------------------------------
-constexpr int kFillRounds = 8;                   // rows per thread per reservation
+#ifndef BHS_FILL_ROUNDS
+#define BHS_FILL_ROUNDS 16
+#endif
+#ifndef BHS_FILL_NOSTATS
+#define BHS_FILL_NOSTATS 0
+#endif
+constexpr int kFillRounds = BHS_FILL_ROUNDS;     // rows per thread per reservation
 constexpr int kFillTile = 256 * kFillRounds;     // rows per block per global reservation
 
 template <bool FROM_ROWPTR>
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
                 // small (the usual case), 64-bit butterflies otherwise
                 unsigned long long s0, s1 = 0ull, s2;
                 const int x0 = mine ? ubv : 0, x1 = (mine && FROM_ROWPTR) ? v : 0, x2 = mine ? a1 - a0 : 0;
-                if (!__any((x0 | x1 | x2) >= (1 << 24))) {
+                if (BHS_FILL_NOSTATS) { s0 = s2 = 0ull; }
+                else if (!__any((x0 | x1 | x2) >= (1 << 24))) {
                     s0 = (unsigned long long)(unsigned)wave_sum_dpp(x0);
                     if (FROM_ROWPTR) s1 = (unsigned long long)(unsigned)wave_sum_dpp(x1);
                     s2 = (unsigned long long)(unsigned)wave_sum_dpp(x2);
