@@ -1264,7 +1264,8 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const acc_t
     }
 }
 
-template <int TS, int LOG2TS, bool NUM, bool PACK32>
+// SMALLB: nnz(B) < 2^29, byte offsets into colIndB / valB fit 32 bits
+template <int TS, int LOG2TS, bool NUM, bool PACK32, bool SMALLB>
 __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     const int4* __restrict__ desc, int qn, int chunkLog2,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
@@ -1440,6 +1441,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                         const int j = cum + mbcnt64(mk);
                         cum += __popcll(mk);
                         if (p < total) {
+                            if constexpr (SMALLB && BHS_DEFER_MUL == 1 && !(NUM ? BHS_ABL : BHS_ABL_SYM)) {
+                                // nnz(B) < 2^29: byte offsets fit 32 bits, so the loads use SGPR base + 32-bit VGPR
+                                // offset addressing and the 64-bit address arithmetic per product disappears
+                                const unsigned idx32 = (unsigned)(sm.sBase[j] + p);
+                                col[u] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(Bj) + (idx32 << 2));
+#if BHS_DEFER_MUL == 1
+                                if (NUM) {
+                                    avv[u] = sm.sAv[j];
+                                    bxv[u] = *reinterpret_cast<const value_t*>(reinterpret_cast<const char*>(Bx) +
+                                                                               idx32 * (unsigned)sizeof(value_t));
+                                }
+#endif
+                                continue;
+                            }
                             const long long idx = (long long)sm.sBase[j] + p;
                             if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
                             else col[u] = Bj[idx];

@@ -138,6 +138,7 @@ struct bhs_handle {
     int ticketSlot = 101;                // ticket word (index into `small`) of the bin being launched; S_TICKET
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
+    int allowSmallB = 1;
     hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
     bool wantHostRowPtr = false, rowPtrStaged = false;
     // options
@@ -313,11 +314,11 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     return BHS_SUCCESS;
 }
 
-template <int LOG2TS, bool NUM, bool PACK32>
+template <int LOG2TS, bool NUM, bool PACK32, bool SMALLB>
 int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     constexpr int TS = 1 << LOG2TS;
-    auto kern = k_row_wave<TS, LOG2TS, NUM, PACK32>;
+    auto kern = k_row_wave<TS, LOG2TS, NUM, PACK32, SMALLB>;
     constexpr int WPB = kWavesPerBlock;
     const size_t smem = sizeof(WaveSmem<TS, NUM, PACK32>) * WPB;
     static int perCU = 0;
@@ -345,13 +346,20 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 template <int LOG2TS, bool NUM>
 int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
+    // byte offsets into colIndB / valB fit 32 bits: the common case gets its own instantiation
+    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
     if constexpr (NUM) {
         // 32-bit sort keys when every column index fits beside the slot index
-        if ((long long)h->n <= (1LL << (32 - LOG2TS)) && !h->noPack32)
-            return launch_row_wave_impl<LOG2TS, true, true>(h, queue, qn, CpOrCnt);
-        return launch_row_wave_impl<LOG2TS, true, false>(h, queue, qn, CpOrCnt);
+        const bool pack32 = (long long)h->n <= (1LL << (32 - LOG2TS)) && !h->noPack32;
+        if (pack32) {
+            if (smallB) return launch_row_wave_impl<LOG2TS, true, true, true>(h, queue, qn, CpOrCnt);
+            return launch_row_wave_impl<LOG2TS, true, true, false>(h, queue, qn, CpOrCnt);
+        }
+        if (smallB) return launch_row_wave_impl<LOG2TS, true, false, true>(h, queue, qn, CpOrCnt);
+        return launch_row_wave_impl<LOG2TS, true, false, false>(h, queue, qn, CpOrCnt);
     } else {
-        return launch_row_wave_impl<LOG2TS, false, false>(h, queue, qn, CpOrCnt);
+        if (smallB) return launch_row_wave_impl<LOG2TS, false, false, true>(h, queue, qn, CpOrCnt);
+        return launch_row_wave_impl<LOG2TS, false, false, false>(h, queue, qn, CpOrCnt);
     }
 }
 
@@ -992,6 +1000,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }

@@ -154,6 +154,8 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "lds_bitmap"      0: keep the long-row bitmap in HBM even when the matrix has <= 2^20 columns
  *   "lds_bitmap_min_log2"  numeric workgroup bins with tables of at least 2^v slots go to the LDS bitmap
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
+ *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
+ *                     nnz(B) < 2^29)
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)

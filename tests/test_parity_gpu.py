@@ -165,6 +165,15 @@ def test_quarter_wave_rows(oracle, nA, lenB, dup):
     _check(oracle, m, k, n, (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx), options={"no_pack32": 1})
 
 
+def test_b_addressing_paths(oracle):
+    """colIndB / valB loads: 32-bit byte offsets (nnz(B) < 2^29, default) and the general 64-bit path."""
+    m, rp, col, val = poisson_case("poisson27pt", 10, 10, 10)
+    A = (rp, col, val)
+    Cp, Cj, Cx, _ = _check(oracle, m, m, m, A, A)
+    Cp2, Cj2, Cx2, _ = _check(oracle, m, m, m, A, A, options={"small_b": 0})
+    assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
+
+
 def test_sort_key_width_paths(oracle):
     """32-bit packed sort keys vs the 64-bit fallback must agree (wave and quarter-wave kernels)."""
     m, rp, col, val = poisson_case("poisson27pt", 14, 14, 14)
