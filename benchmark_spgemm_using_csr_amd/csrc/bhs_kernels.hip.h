@@ -80,6 +80,9 @@ __device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA)
     return (b == 1) ? 2 : b;        // 0 < v <= upper[2] that did not qualify for the quad bin
 }
 
+// s_waitcnt immediate (gfx9 encoding): vmcnt(0), expcnt and lgkmcnt left at their maxima (no wait)
+constexpr int kWaitVm0 = 0x0F70;
+
 __device__ __forceinline__ unsigned hash_col(int col, int log2ts)
 {
     return ((unsigned)col * 2654435761u) >> (32 - log2ts);
@@ -1326,21 +1329,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     value_t avC = 0.0, av1 = 0.0;
     if (lane < dC.z - dC.y) { cC = Aj[dC.y + lane]; if (NUM) avC = Ax[dC.y + lane]; }
     if (lane < d1.z - d1.y) { c1 = Aj[d1.y + lane]; if (NUM) av1 = Ax[d1.y + lane]; }
-    int b0C = 0, lenC = 0;
-    if (lane < dC.z - dC.y) { int2 be; __builtin_memcpy(&be, Bp + cC, 8); b0C = be.x; lenC = be.y - be.x; }
+    // B row extents travel through the pipeline as the raw (begin, end) pair: forming the length where the
+    // gather is issued puts an s_waitcnt vmcnt(0) right behind it, i.e. one exposed round trip per row
+    int2 beC = make_int2(0, 0);
+    if (lane < dC.z - dC.y) __builtin_memcpy(&beC, Bp + cC, 8);
 
 #if BHS_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tPrev = __builtin_readcyclecounter();
 #endif
+    // The prologue's loads are complete before the loop is entered.  Without this the compiler's wait-count
+    // analysis merges "pending since the prologue" into the loop header and guards the first use of every
+    // rotated register with vmcnt(0/1) -- which, the counter being in-order, waits for the prefetches the
+    // iteration has just issued.
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);
     for (int it = 0; it < nIt; ++it) {
         // ---- prefetch for the rows behind this one
         const int4 d3 = load_desc(it + 3);
         int c2 = 0;
         value_t av2 = 0.0;
         if (lane < d2.z - d2.y) { c2 = Aj[d2.y + lane]; if (NUM) av2 = Ax[d2.y + lane]; }
-        int b01 = 0, len1 = 0;
-        if (lane < d1.z - d1.y) { int2 be; __builtin_memcpy(&be, Bp + c1, 8); b01 = be.x; len1 = be.y - be.x; }   // one 8-byte gather
+        int2 be1 = make_int2(0, 0);
+        if (lane < d1.z - d1.y) __builtin_memcpy(&be1, Bp + c1, 8);   // one 8-byte gather, consumed by the next row
 
         const int row = dC.x, a0 = dC.y, a1 = dC.z;
         // ---- clear the table
@@ -1375,7 +1385,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         if (multi) load_a(a0 + 64 + lane, cA, avA);
         for (int ca = a0; ca < a1; ca += 64) {
             // ---- one A entry per lane: B row extent, flat product offsets
-            int b0 = b0C, len = lenC;
+            int b0 = beC.x, len = beC.y - beC.x;
             value_t av = avC;
             if (multi) {
                 if (ca == a0) {
@@ -1397,6 +1407,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                     b0 = be.x;
                     len = be.y - be.x;
                 }
+                __builtin_amdgcn_s_waitcnt(kWaitVm0);         // nothing of this (rare) path stays pending at the join
             }
             const int incl = wave_incl_scan_dpp(len);
             const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -1533,6 +1544,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
                         }
                     }
                 }
+                // Every load of the window has been consumed by now, but under conditions the compiler cannot
+                // match up with the ones they were issued under (u < nb vs g < nb): left alone it guards the
+                // loop header with vmcnt(0) against writes into "possibly pending" registers, and on the first
+                // window that wait lands on the row prefetches issued a moment ago.  Free at run time.
+                __builtin_amdgcn_s_waitcnt(kWaitVm0);
             }
             if (multi && ca == a0) {                          // first chunk done: its successor's extents (entries loaded at row start)
                 gather_b(ca + 64 + lane, cA);
@@ -1542,11 +1558,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         }
         wave_sync();
         BHS_TICK(3);
+        // ---- rotate the pipeline HERE, not behind the stores of C: the moves need the prefetched registers, and
+        // a wait placed after the stores would be a vmcnt(0) that also waits for the stores to be acknowledged.
+        // At this point every load older than the last window's is back, so the moves cost nothing.
+        const int outW = dC.w;
+        dC = d1; d1 = d2; d2 = d3;
+        avC = av1; av1 = av2;
+        c1 = c2;
+        beC = be1;
+        // (pinned: otherwise the select inside load_desc and the moves sink to the loop latch, behind the stores)
+        asm volatile("" : "+v"(d2.x), "+v"(d2.y), "+v"(d2.z), "+v"(d2.w), "+v"(c1), "+v"(beC.x), "+v"(beC.y));
+        if (NUM) asm volatile("" : "+v"(av1));
         if (!NUM) {
             myNew = wave_sum_dpp(myNew);
             if (lane == 0) cntOut[row] = myNew;
         } else {
-            const long long outBase = dC.w;
+            const long long outBase = outW;
             // ---- compact occupied slots -> packed sort keys
             int run = 0;
 #pragma unroll
@@ -1610,11 +1637,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         }
         wave_sync();
         BHS_TICK(5);
-        // ---- rotate the pipeline
-        dC = d1; d1 = d2; d2 = d3;
-        avC = av1; av1 = av2;
-        c1 = c2;
-        b0C = b01; lenC = len1;
     }
 #if BHS_PHASES
     if (NUM && lane == 0) {
@@ -1682,32 +1704,29 @@ __global__ __launch_bounds__(64) void k_row_quad(
             if (NUM) av_ = Ax[dd.y + l16];
         }
     };
-    auto load_b = [&](int c_, int& b0_, int& len_) {
-        b0_ = 0;
-        len_ = 0;
-        if (c_ >= 0) {
-            int2 be;
-            __builtin_memcpy(&be, Bp + c_, sizeof(be));
-            b0_ = be.x;
-            len_ = be.y - be.x;
-        }
+    auto load_b = [&](int c_, int2& be_) {                  // raw (begin, end): the length is formed where it is used
+        be_ = make_int2(0, 0);
+        if (c_ >= 0) __builtin_memcpy(&be_, Bp + c_, sizeof(be_));
     };
     const int g0 = gBeg + lb;
     int4 dC = load_desc(g0), d1 = load_desc(g0 + perX), d2 = load_desc(g0 + 2 * perX);
-    int cC, c1, b0C, lenC;
+    int cC, c1;
+    int2 beC;
     value_t avC, av1;
     load_a(dC, cC, avC);
     load_a(d1, c1, av1);
-    load_b(cC, b0C, lenC);
+    load_b(cC, beC);
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);                     // prologue loads complete (see k_row_wave)
     for (int grp = g0; grp < gEnd; grp += perX) {
         const int4 d = dC;                                     // this quarter's row (row < 0: idle quarter)
         const int4 d3 = load_desc(grp + 3 * perX);
-        int c2, b01, len1;
+        int c2;
+        int2 be1;
         value_t av2;
         load_a(d2, c2, av2);
-        load_b(c1, b01, len1);
+        load_b(c1, be1);
         // ---- one A entry per lane of the quarter
-        const int b0 = b0C, len = lenC;
+        const int b0 = beC.x, len = beC.y - beC.x;
         const value_t av = avC;
         // ---- clear the four tables (64 lanes x 4 slots = 256 slots)
         *reinterpret_cast<int4*>(&sm.keys[0][lane * 4]) = make_int4(kEmpty, kEmpty, kEmpty, kEmpty);
@@ -1789,8 +1808,16 @@ __global__ __launch_bounds__(64) void k_row_quad(
                     if (NUM) unsafeAtomicAdd(&sm.vals[g][hh[u]], (acc_t)avq[u] * (acc_t)bxq[u]);
                 }
             }
+            __builtin_amdgcn_s_waitcnt(kWaitVm0);             // the window's loads are consumed (see k_row_wave)
         }
         wave_sync();
+        // ---- rotate the pipeline ahead of the stores of C (see k_row_wave)
+        dC = d1; d1 = d2; d2 = d3;
+        avC = av1; av1 = av2;
+        c1 = c2;
+        beC = be1;
+        asm volatile("" : "+v"(d2.x), "+v"(d2.y), "+v"(d2.z), "+v"(d2.w), "+v"(c1), "+v"(beC.x), "+v"(beC.y));
+        if (NUM) asm volatile("" : "+v"(av1));
         if (!NUM) {
             // per-quarter sum of myNew: DPP row reduction, lane 15 of the row holds it
             unsigned r = (unsigned)myNew;
@@ -1856,11 +1883,6 @@ __global__ __launch_bounds__(64) void k_row_quad(
             }
         }
         wave_sync();
-        // ---- rotate the pipeline
-        dC = d1; d1 = d2; d2 = d3;
-        avC = av1; av1 = av2;
-        c1 = c2;
-        b0C = b01; lenC = len1;
     }
 }
 
