@@ -139,6 +139,14 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    // compressed pattern of B for the symbolic pass (k_compress_b): 0 never (default), 1 when the data has <= 60 %
+    // as many (block, mask) pairs as entries, 2 always (needs sorted B rows either way).  Off by default: on
+    // MI355X the symbolic wave kernel is bound by its per-row work, not by its products, and 2.8x fewer inserts
+    // buy back less than the compression pass costs (poisson27pt 160^3: 10.46 ms with, 10.34 ms without).
+    int compressB = 0;
+    int cmpState = 0;                    // per data set: 0 undecided, 1 pays, -1 does not
+    bool cmpActive = false;              // this multiply's symbolic wave bins run on the compressed pattern
+    DevBuf cExt, cLen, cPair, symKey;    // per B row: pair extents, (entries, pairs); pairs; per A row: symbolic bin key
     hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
     bool wantHostRowPtr = false, rowPtrStaged = false;
     // options
@@ -161,6 +169,7 @@ namespace {
 enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S_NUM_START = 64,
        S_NUM_CURSOR = 80, S_TOTAL_CT = 96 /* 2 ints = u64 */, S_TOTAL_C = 98 /* 2 ints = i64 */,
        S_ERR = 100, S_TICKET = 101 /* dynamic row scheduler of the workgroup-per-row kernels */,
+       S_PAIRS = 102 /* 2 ints = u64: (block, mask) pairs of the compressed B */,
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
        S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
@@ -363,6 +372,57 @@ int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     }
 }
 
+template <int LOG2TS>
+int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
+{
+    constexpr int TS = 1 << LOG2TS;
+    auto kern = k_row_wave_csym<TS, LOG2TS>;
+    constexpr int WPB = kWavesPerBlock;
+    const size_t smem = sizeof(CsymSmem<TS>) * WPB;
+    static int perCU = 0;
+    if (!perCU) {
+        if (smem > 48 * 1024)
+            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nb = 0;
+        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WPB, smem));
+        perCU = std::max(1, std::min(nb, 32 / WPB));
+    }
+    if (h->verbose > 1) printf("  [symbolic/compressed TS=%d] occupancy API: %d workgroups/CU, smem %zu B\n", TS, perCU, smem);
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    int chunkLog2 = 0;
+    while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj,
+                       (const int2*)h->cExt.p, (const int2*)h->cPair.p, cnt);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+int launch_compress_b(bhs_handle* h)
+{
+    int G = 1 << h->logL;                       // lanes per row of B: its average length, 2..16
+    G = std::max(2, std::min(G, 16));
+    const int rowsPerBlock = 256 / G * 4;       // 4 rows in flight per lane group
+    long long grid = ((long long)h->k + rowsPerBlock - 1) / rowsPerBlock;
+    grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * 8));
+    int* small = (int*)h->small.p;
+#define BHS_CB(GG)                                                                                          \
+    case GG:                                                                                                \
+        hipLaunchKernelGGL(k_compress_b<GG>, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, h->dBp,   \
+                           h->dBj, (int2*)h->cExt.p, (int2*)h->cLen.p, (int2*)h->cPair.p,                                     \
+                           (unsigned long long*)(small + S_PAIRS));                                         \
+        break;
+    switch (G) {
+        BHS_CB(2) BHS_CB(4) BHS_CB(8) BHS_CB(16)
+        default: return BHS_ERR_INTERNAL;
+    }
+#undef BHS_CB
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
 template <bool NUM, bool PACK32>
 int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
@@ -406,6 +466,20 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
         return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
+    if constexpr (!NUM) {
+        if (h->cmpActive && c.block == 64 && !win && h->forcePath != 2) {
+            switch (lg) {
+                case 6: return launch_row_wave_csym<6>(h, queue, qn, CpOrCnt);
+                case 7: return launch_row_wave_csym<7>(h, queue, qn, CpOrCnt);
+                case 8: return launch_row_wave_csym<8>(h, queue, qn, CpOrCnt);
+                case 9: return launch_row_wave_csym<9>(h, queue, qn, CpOrCnt);
+                case 10: return launch_row_wave_csym<10>(h, queue, qn, CpOrCnt);
+                case 11: return launch_row_wave_csym<11>(h, queue, qn, CpOrCnt);
+                case 12: return launch_row_wave_csym<12>(h, queue, qn, CpOrCnt);
+                default: break;
+            }
+        }
+    }
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
     BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);
@@ -433,7 +507,7 @@ const char* kNumNames[kNumNumBins] = {"", "numeric_quad<64>", "numeric_wave<64>"
                                       "numeric_wave<512>", "numeric_wave<1024>",
                                       "numeric_wg<2048>", "numeric_wg<4096>", "numeric_wg<8192>", "numeric_long_rows"};
 
-int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
+int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
 {
     const int G = h->ubG;
     const int rowsPerBlock = 256 / G;
@@ -443,11 +517,18 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec)
     // cover many rows each, run fewer and longer blocks (poisson5pt 1024^2: 0.066 -> 0.048 ms)
     grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * (G <= 8 ? 4 : 32)));
     int* small = (int*)h->small.p;
-#define BHS_UB(GG)                                                                                   \
-    case GG:                                                                                         \
-        hipLaunchKernelGGL(k_upper_bound<GG>, dim3((unsigned)grid), dim3(256), 0, h->stream, h->m,   \
-                           h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,                     \
-                           (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec);    \
+#define BHS_UB(GG)                                                                                       \
+    case GG:                                                                                             \
+        if (cmp)                                                                                         \
+            hipLaunchKernelGGL((k_upper_bound<GG, true>), dim3((unsigned)grid), dim3(256), 0, h->stream, \
+                               h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
+                               (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
+                               (const int2*)h->cLen.p, (int*)h->symKey.p, keyMax);                       \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_upper_bound<GG, false>), dim3((unsigned)grid), dim3(256), 0, h->stream,\
+                               h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
+                               (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
+                               (const int2*)nullptr, (int*)nullptr, 0);                                  \
         break;
     switch (G) {
         BHS_UB(1) BHS_UB(2) BHS_UB(4) BHS_UB(8) BHS_UB(16) BHS_UB(32) BHS_UB(64)
@@ -531,8 +612,25 @@ int run_pipeline(bhs_handle* h)
     const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
+    h->cmpActive = false;
+    // (the undecided first multiply on a data set only measures the ratio: bins and symbolic pass stay plain)
+    const bool cmpRun = h->compressB && h->bSorted && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+                        (h->compressB == 2 || h->cmpState >= 0);
+    const bool cmpBins = cmpRun && (h->compressB == 2 || h->cmpState > 0);
+    if (cmpRun) {
+        BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)std::max(h->k, 1)));
+        BHS_TRY(ensure(h, h->cPair, sizeof(int2) * (size_t)std::max(h->nnzB, 1)));
+        BHS_TRY(ensure(h, h->cLen, sizeof(int2) * (size_t)std::max(h->k, 1)));
+        BHS_TRY(ensure(h, h->symKey, sizeof(int) * (size_t)m));
+        BHS_TRY(timed_begin(h, "compress_b", &ep));
+        BHS_TRY(launch_compress_b(h));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += h->k;
+    }
+    const int* symKeys = cmpBins ? (const int*)h->symKey.p : (const int*)h->ub.p;
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
-    BHS_TRY(launch_upper_bound(h, symSpec));
+    BHS_TRY(launch_upper_bound(h, symSpec, cmpBins, symSpec.upper[8]));
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches++;
     h->stats[ep->stat].rows += m;
@@ -547,13 +645,20 @@ int run_pipeline(bhs_handle* h)
     unsigned long long tot;
     memcpy(&tot, hs + S_TOTAL_CT, 8);
     h->nnzCt = (long long)tot;
+    if (cmpRun) {
+        unsigned long long pairs;
+        memcpy(&pairs, hs + S_PAIRS, 8);
+        if (h->cmpState == 0) h->cmpState = (double)pairs <= 0.6 * (double)h->nnzB ? 1 : -1;
+        h->cmpActive = cmpBins;
+        if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpActive ? "used" : "not used");
+    }
     memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
     BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
         long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
         BHS_TRY(timed_begin(h, "fill_queues", &ep));
         hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
-                           (const int*)h->ub.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
+                           symKeys, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
                            small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
                            (unsigned long long*)(small + S_SYM_SUMS));
         BHS_HIP(hipGetLastError());
@@ -706,6 +811,7 @@ int finish_set_data(bhs_handle* h)
     h->logL = lg;
     BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
     h->bSorted = 1;
+    h->cmpState = 0;
     if (h->nnzB > 1 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
@@ -717,6 +823,21 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
         h->bSorted = flag ? 0 : 1;
+    }
+    // compressed pattern of B: decide now whether it pays (the multiply itself re-runs the compression inside its
+    // timed region; this pass only yields the pair count)
+    if (h->compressB == 1 && h->bSorted && h->nnzB > 0 && h->k > 0) {
+        int* small = (int*)h->small.p;
+        BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)h->k));
+        BHS_TRY(ensure(h, h->cLen, sizeof(int2) * (size_t)h->k));
+        BHS_TRY(ensure(h, h->cPair, sizeof(int2) * (size_t)h->nnzB));
+        BHS_HIP(hipMemsetAsync(small + S_PAIRS, 0, 8, h->stream));
+        BHS_TRY(launch_compress_b(h));
+        unsigned long long pairs = 0;
+        BHS_HIP(hipMemcpyAsync(&pairs, small + S_PAIRS, 8, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        h->cmpState = (double)pairs <= 0.6 * (double)h->nnzB ? 1 : -1;
+        if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpState > 0 ? "used" : "not used");
     }
     if (h->useSpa) BHS_TRY(ensure_spa(h));
     h->hasData = true;
@@ -806,6 +927,10 @@ int bhs_destroy(bhs_handle* h)
     release(h->Cp);
     release(h->ub);
     release(h->queue);
+    release(h->cExt);
+    release(h->cPair);
+    release(h->cLen);
+    release(h->symKey);
     release(h->blockSum);
     release(h->small);
     release(h->spaRank);
@@ -1001,6 +1126,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }

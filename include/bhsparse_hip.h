@@ -156,6 +156,10 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
  *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
  *                     nnz(B) < 2^29)
+ *   "compress_b"      symbolic pass on the compressed pattern of B ((column >> 5, mask) pairs; rows binned by their
+ *                     pair count): 0 never (default: measured break-even at best on MI355X), 1 when the data has
+ *                     <= 60 % as many pairs as entries, 2 always.  Only for B with ascending rows.  Set it before
+ *                     bhs_set_data for mode 1 to be decided there.
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)

@@ -174,6 +174,45 @@ def test_b_addressing_paths(oracle):
     assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
 
 
+@pytest.mark.parametrize("case", ["p27", "p5", "p9", "random", "banded_long_rows", "rect_blocks"])
+def test_compressed_symbolic_pass(oracle, case):
+    """Symbolic pass on the compressed pattern of B ((column >> 5, mask) pairs): forced on, against the oracle
+    and against the plain pass; the default (auto) mode must agree as well."""
+    rng = np.random.default_rng(77)
+    if case == "p27":
+        m, rp, col, val = poisson_case("poisson27pt", 11, 9, 10)
+        A = B = (rp, col, val); k = n = m
+    elif case == "p5":
+        m, rp, col, val = poisson_case("poisson5pt", 40, 37)
+        A = B = (rp, col, val); k = n = m
+    elif case == "p9":
+        m, rp, col, val = poisson_case("poisson9pt", 33, 31)
+        A = B = (rp, col, val); k = n = m
+    elif case == "random":                      # no adjacent columns: compression does not pay, still correct
+        m, k, n = 300, 250, 4000
+        A = random_csr(m, k, 0.05, rng, empty_rows=(0, 9))
+        B = random_csr(k, n, 0.01, rng, empty_rows=(2,))
+    elif case == "banded_long_rows":            # A rows with > 64 entries (chunk loop), B rows of 70..90 adjacent columns
+        m, k, n = 200, 400, 3000
+        A = random_csr(m, k, 0.3, rng)
+        lens = rng.integers(70, 91, k)
+        starts = rng.integers(0, n - 100, k)
+        Bp = np.zeros(k + 1, np.int32); np.cumsum(lens, out=Bp[1:])
+        Bj = np.concatenate([np.arange(s0, s0 + l0) for s0, l0 in zip(starts, lens)]).astype(np.int32)
+        B = (Bp, Bj, rng.integers(1, 10, len(Bj)).astype(np.float64))
+    else:                                       # rectangular, blocks of 4 adjacent columns at random places
+        m, k, n = 500, 300, 100000
+        A = random_csr(m, k, 0.04, rng)
+        heads = [np.sort(rng.choice(n // 4, rng.integers(0, 12), replace=False)) * 4 for _ in range(k)]
+        Bj = np.concatenate([np.add.outer(h, np.arange(4)).ravel() for h in heads] + [np.empty(0, np.int64)]).astype(np.int32)
+        Bp = np.zeros(k + 1, np.int32); np.cumsum([4 * len(h) for h in heads], out=Bp[1:])
+        B = (Bp, Bj, rng.integers(1, 10, len(Bj)).astype(np.float64))
+    ref = _check(oracle, m, k, n, A, B, options={"compress_b": 0})
+    for mode in (2, 1):
+        got = _check(oracle, m, k, n, A, B, options={"compress_b": mode})
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+
+
 def test_sort_key_width_paths(oracle):
     """32-bit packed sort keys vs the 64-bit fallback must agree (wave and quarter-wave kernels)."""
     m, rp, col, val = poisson_case("poisson27pt", 14, 14, 14)
