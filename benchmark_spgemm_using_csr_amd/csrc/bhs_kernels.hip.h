@@ -67,14 +67,17 @@ constexpr int kMaxBins = 16;
 struct BinSpec {                    // bin b >= 2 holds rows with upper[b-1] < v <= upper[b]; bin 0: v == 0;
     int nbins;                      // bin 1 ("quad" bin): 0 < v <= quadMax and at most kQuadMaxA entries in the A row
     int quadMax;                    // 0 disables the quad bin
+    int laneMax, laneMaxA;          // lane bin (kLaneBin, k_row_lane): 0 < v <= laneMax and at most laneMaxA entries in the A row
     int upper[kMaxBins];            // upper[1] is 0: the size ladder starts at bin 2
 };
+constexpr int kLaneBin = kMaxBins - 1;   // outside every size ladder (ladders have at most 12 bins)
 constexpr int kQuadMaxA = 16;       // a 16-lane quarter wave holds one A entry per lane
 
 // qv: the quantity the quad bin's 64-slot quarter tables are sized by (products / entries).  It differs from v
 // only for symbolic bins keyed by the compressed pair count, where the quad kernel still walks plain products.
 __device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA, int qv)
 {
+    if (qv > 0 && qv <= s.laneMax && nA <= s.laneMaxA) return kLaneBin;
     if (qv > 0 && qv <= s.quadMax && nA <= kQuadMaxA) return 1;
     int b = 0;
 #pragma unroll
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
     }
     if (mySum) atomicAdd(&bsum, mySum);
     __syncthreads();
-    if (tid < spec.nbins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
+    if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
     if (tid == 0 && bsum) atomicAdd(total, bsum);
 }
 
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
             dd[r] = make_int4((int)row, a0, a1, outBase);
         }
         __syncthreads();
-        if (tid < spec.nbins && hist[tid]) base[tid] = binStart[tid] + atomicAdd(&binCursor[tid], hist[tid]);
+        if (tid < kMaxBins && hist[tid]) base[tid] = binStart[tid] + atomicAdd(&binCursor[tid], hist[tid]);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < kFillRounds; ++r)
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restric
     if ((tid & 63) == 0) wsum[tid >> 6] = s;
     __syncthreads();
     if (tid == 0) blockSum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (tid < spec.nbins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
+    if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
 }
 
 __global__ __launch_bounds__(1024) void k_scan_blocksums(int nb, long long* __restrict__ blockSum,
@@ -2171,6 +2174,129 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
         if (lane == 0) cntOut[row] = cnt;
         wave_sync();
     }
+}
+
+// ===========================================================================
+// Lane-per-row kernel for matrices whose rows are ALL tiny (stencils in their
+// natural ordering: poisson5pt has 5 entries per row, 25 products, 13 results).
+// The reference gives such rows a thread each and a heap in shared memory
+// (ESC_2heap_noncoalesced, bhsparse_cuda.h:520-722); here a lane merges the
+// <= K sorted B rows of its row directly: K heads (position, end, column, A
+// value, B value) live in registers, every step emits the smallest head column
+// with the sum of the heads that carry it and advances those heads -- no table,
+// no sort, no LDS, results leave in ascending order.  64 rows share every
+// instruction, so the per-row cost of the wave kernels (scan, marks, compaction,
+// sort: ~125 VALU instructions per row in k_row_quad) shrinks to the merge steps
+// themselves (~1 instruction per product and head).  Adjacent lanes hold adjacent
+// rows, whose B rows are adjacent in memory, so the per-lane loads coalesce for
+// banded matrices.  Needs strictly ascending B rows (checked at set_data time).
+//
+// Measured on MI355X (poisson5pt 1024^2 / poisson7pt 128^3 / poisson9pt 1024^2): the symbolic pass drops from
+// 0.081 / 0.476 / 0.273 ms (quarter-wave and wave kernels) to 0.034 / 0.14 / 0.12 ms.  The numeric pass does NOT
+// gain: a lane writes its row of C one entry per step, a 4- or 8-byte store at a stride of one row per lane, and
+// with 50 MB of rows in flight those partially written lines leave the L2 before they are complete (0.41 ms
+// against 0.18 ms for the quarter-wave kernel on poisson5pt; 0.09 ms with the stores removed).  The host therefore
+// uses it for the symbolic stage only (option "lane_numeric" routes the numeric stage here as well).
+// ===========================================================================
+// SMALLB: nnz(B) < 2^29, so byte offsets into colIndB / valB fit 32 bits and the loads take the scalar base +
+// 32-bit lane offset form: no 64-bit address pair per head (K = 6: 100 -> ~60 VGPRs, i.e. 8 waves per SIMD
+// instead of 4 for a kernel that lives on latency hiding).
+// E results are collected in registers and stored together, and the stores are issued BEFORE the loads that
+// advance the heads: the memory counter is in-order, so the wait for those loads also covers the stores -- issued
+// the other way round, every merge step waited for its own stores to be acknowledged (poisson5pt: 0.38 ms).
+#ifndef BHS_LANE_E
+#define BHS_LANE_E 1
+#endif
+// waves per SIMD asked of the register allocator (left alone it keeps both arms of every predicated load live:
+// 118 VGPRs for K = 6)
+constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 ? 6 : 5) : (K <= 6 ? 8 : K <= 8 ? 6 : K <= 10 ? 5 : 4); }
+
+template <int K, bool NUM, bool SMALLB>
+__global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4* __restrict__ desc, int qn,
+                                                  const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+                                                  const int* __restrict__ Bp, const int* __restrict__ Bj,
+                                                  const value_t* __restrict__ Bx, int* __restrict__ cntOut,
+                                                  int* __restrict__ Cj, value_t* __restrict__ Cx)
+{
+    constexpr int kEnd = 0x7fffffff;                       // exhausted head (column indices are < 2^31 - 1)
+    constexpr int E = NUM ? BHS_LANE_E : 1;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qn) return;
+    const int4 d = desc[q];
+    const int row = d.x, a0 = d.y, nA = d.z - d.y;
+    auto ld_col = [&](int p) {
+        if constexpr (SMALLB) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(Bj) + ((unsigned)p << 2));
+        else return Bj[p];
+    };
+    auto ld_val = [&](int p) {
+        if constexpr (SMALLB)
+            return *reinterpret_cast<const value_t*>(reinterpret_cast<const char*>(Bx) + (unsigned)p * (unsigned)sizeof(value_t));
+        else return Bx[p];
+    };
+    int pos[K], end[K], col[K];
+    acc_t av[K], bv[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        pos[j] = end[j] = 0;
+        av[j] = 0.0;
+        if (j < nA) {
+            const int c = Aj[a0 + j];
+            if (NUM) av[j] = (acc_t)Ax[a0 + j];
+            int2 be;
+            __builtin_memcpy(&be, Bp + c, sizeof(be));
+            pos[j] = be.x;
+            end[j] = be.y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        col[j] = kEnd;
+        bv[j] = 0.0;
+        if (pos[j] < end[j]) { col[j] = ld_col(pos[j]); if (NUM) bv[j] = (acc_t)ld_val(pos[j]); }
+    }
+    long long out = d.w;
+    int cnt = 0;
+    bool more = true;
+    while (more) {
+        int oc[E];
+        acc_t ov[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int mn = col[0];
+#pragma unroll
+            for (int j = 1; j < K; ++j) mn = min(mn, col[j]);
+            oc[e] = mn;
+            ov[e] = 0.0;
+            if (mn != kEnd) {
+                if (NUM) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) if (col[j] == mn) ov[e] += av[j] * bv[j];
+                }
+                if (NUM && e == E - 1) {                       // chunk complete: its stores go out ahead of the loads below
+#pragma unroll
+                    for (int x = 0; x < E; ++x) { Cj[out + x] = oc[x]; Cx[out + x] = (value_t)ov[x]; }
+                    out += E;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (col[j] == mn) {
+                        ++pos[j];
+                        col[j] = kEnd;
+                        if (pos[j] < end[j]) { col[j] = ld_col(pos[j]); if (NUM) bv[j] = (acc_t)ld_val(pos[j]); }
+                    }
+                }
+                ++cnt;
+            } else {
+                if (NUM) {                                      // row finished inside a chunk: store what the chunk holds
+#pragma unroll
+                    for (int x = 0; x < E; ++x) if (x < e) { Cj[out + x] = oc[x]; Cx[out + x] = (value_t)ov[x]; }
+                }
+                more = false;
+                break;
+            }
+        }
+    }
+    if (!NUM) cntOut[row] = cnt;
 }
 
 }  // namespace bhs

@@ -70,11 +70,16 @@ const KernelCfg kNumCfg[kNumNumBins] = {
     {10, 64, false}, {11, 256, false}, {12, 256, false}, {13, 512, false}, {13, 512, true}};
 constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a 64-slot quarter table admits
 
-BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad)
+constexpr int kLaneMaxK = 12;       // heads a lane keeps in registers (k_row_lane<K>: K = 4, 6, .., 12)
+constexpr int kLaneMax = kLaneMaxK * kLaneMaxK;   // products (symbolic) / entries (numeric) of a lane-bin row
+
+BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad, int laneK)
 {
     BinSpec s;
     memset(&s, 0, sizeof(s));
     s.nbins = nbins;
+    s.laneMax = laneK > 0 ? kLaneMax : 0;
+    s.laneMaxA = laneK;
     s.quadMax = (quad && maxLog2 >= 6) ? kQuadMax : 0;
     s.upper[0] = 0;
     s.upper[1] = 0;
@@ -139,6 +144,9 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
+    int laneNumeric = 0;                 // 1: numeric stage of lane-bin rows through k_row_lane too (measured slower: strided stores)
+    int maxRowA = 0;
     // compressed pattern of B for the symbolic pass (k_compress_b): 0 never (default), 1 when the data has <= 60 %
     // as many (block, mask) pairs as entries, 2 always (needs sorted B rows either way).  Off by default: on
     // MI355X the symbolic wave kernel is bound by its per-row work, not by its products, and 2.8x fewer inserts
@@ -454,6 +462,31 @@ int launch_row_quad(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 }
 
 template <bool NUM>
+int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCnt)
+{
+    const unsigned grid = (unsigned)(((long long)qn + 255) / 256);
+    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
+#define BHS_LANE(KK)                                                                                          \
+    case KK:                                                                                                  \
+        if (smallB)                                                                                           \
+            hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
+                               h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
+                               (value_t*)h->Cx.p);                                                            \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
+                               h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
+                               (value_t*)h->Cx.p);                                                            \
+        break;
+    switch (K) {
+        BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)
+        default: return BHS_ERR_INTERNAL;
+    }
+#undef BHS_LANE
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
@@ -608,8 +641,13 @@ int run_pipeline(bhs_handle* h)
     BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
 
     // ------------------------------------------------------------ stage 1
-    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0);
-    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0);
+    // lane bin (k_row_lane): matrices whose A rows are all tiny, B rows strictly ascending
+    int laneK = 0;
+    if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || h->maxRowA <= kLaneMaxK))
+        laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK);
+    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
+                                      h->laneNumeric ? laneK : 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     h->cmpActive = false;
@@ -671,6 +709,15 @@ int run_pipeline(bhs_handle* h)
     int symStat[kMaxBins], numStat[kMaxBins];
     for (int b = 0; b < kMaxBins; ++b) symStat[b] = numStat[b] = -1;
     BHS_TRY(fork_bins(h, symCount, kNumSymBins));
+    if (symCount[kLaneBin]) {
+        bin_stream(h, kLaneBin);
+        BHS_TRY(timed_begin(h, "symbolic_lane", &ep));
+        BHS_TRY(launch_row_lane<false>(h, laneK, (const int4*)h->queue.p + symStart[kLaneBin], symCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[kLaneBin];
+        symStat[kLaneBin] = ep->stat;
+    }
     for (int i = 1; i < kNumSymBins; ++i) {
         const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
         if (!symCount[b]) continue;
@@ -741,6 +788,15 @@ int run_pipeline(bhs_handle* h)
 
     // ------------------------------------------------------------ stage 4: numeric
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
+    if (numCount[kLaneBin]) {
+        bin_stream(h, kLaneBin);
+        BHS_TRY(timed_begin(h, "numeric_lane", &ep));
+        BHS_TRY(launch_row_lane<true>(h, laneK, (const int4*)h->queue.p + numStart[kLaneBin], numCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += numCount[kLaneBin];
+        numStat[kLaneBin] = ep->stat;
+    }
     for (int i = 1; i < kNumNumBins; ++i) {
         const int b = kNumNumBins - i;
         if (!numCount[b]) continue;
@@ -793,6 +849,7 @@ int finish_set_data(bhs_handle* h)
     const double avgB = h->k > 0 ? (double)h->nnzB / h->k : 1.0;
     BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
     int maxRowA = 0;
+    h->maxRowA = 0;
     if (h->m > 0) {
         int* small0 = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
@@ -804,6 +861,7 @@ int finish_set_data(bhs_handle* h)
     }
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
+    h->maxRowA = maxRowA;
     h->ubG = pow2_at_least(std::max(avgA, maxRowA / 32.0), 1, 64);
     int L = pow2_at_least(avgB, 1, 64);
     int lg = 0;
@@ -1126,6 +1184,8 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "lane_numeric")) { h->laneNumeric = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }

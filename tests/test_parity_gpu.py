@@ -161,8 +161,14 @@ def test_quarter_wave_rows(oracle, nA, lenB, dup):
     np.cumsum(lens, out=Ap[1:])
     Aj = np.concatenate([np.sort(rng.choice(k, L, replace=False)) for L in lens] + [np.empty(0, np.int64)]).astype(np.int32)
     Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
-    _check(oracle, m, k, n, (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx))
-    _check(oracle, m, k, n, (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx), options={"no_pack32": 1})
+    A, B = (Ap.astype(np.int32), Aj, Ax), (Bp.astype(np.int32), Bj, Bx)
+    r0 = _check(oracle, m, k, n, A, B, options={"lane_rows": 0})
+    _check(oracle, m, k, n, A, B, options={"lane_rows": 0, "no_pack32": 1})
+    # the same rows through the lane-per-row kernel (default for nA <= 12; forced otherwise, where rows with
+    # more than 12 entries stay with the quarter-wave kernel)
+    for mode in (1, 2):
+        r1 = _check(oracle, m, k, n, A, B, options={"lane_rows": mode, "lane_numeric": mode - 1})
+        assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
 
 
 def test_b_addressing_paths(oracle):
@@ -211,6 +217,44 @@ def test_compressed_symbolic_pass(oracle, case):
     for mode in (2, 1):
         got = _check(oracle, m, k, n, A, B, options={"compress_b": mode})
         assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+
+
+@pytest.mark.parametrize("case", ["p5", "p7", "p9", "tiny_random", "cancel", "unsorted_b"])
+def test_lane_per_row_kernel(oracle, case):
+    """k_row_lane (one row per lane, K-way merge of sorted B rows in registers) against the oracle and against
+    the table kernels; it must step aside for unsorted B."""
+    rng = np.random.default_rng(5)
+    kernels_wanted = True
+    if case in ("p5", "p7", "p9"):
+        dims = {"p5": ("poisson5pt", 37, 41, 1), "p7": ("poisson7pt", 9, 11, 8), "p9": ("poisson9pt", 23, 19, 1)}[case]
+        m, rp, col, val = poisson_case(*dims)
+        A = B = (rp, col, val); k = n = m
+    elif case == "tiny_random":                  # 0..12 entries per A row, B rows of 0..30 entries, empty rows in both
+        m, k, n = 777, 300, 2000
+        A = random_csr(m, k, 0.02, rng, empty_rows=(0, 5, 776), max_row=12)
+        B = random_csr(k, n, 0.008, rng, empty_rows=(1, 2), max_row=30)
+    elif case == "cancel":                       # exact cancellation keeps the structural zero
+        m = k = n = 3
+        A = (np.array([0, 2, 2, 3], np.int32), np.array([0, 1, 2], np.int32), np.array([1.0, -1.0, 2.0]))
+        B = (np.array([0, 2, 4, 5], np.int32), np.array([0, 2, 0, 1, 1], np.int32), np.array([3.0, 1.0, 3.0, 5.0, 7.0]))
+    else:
+        m, k, n = 200, 100, 500
+        A = random_csr(m, k, 0.05, rng, max_row=8)
+        Bp, Bj, Bx = random_csr(k, n, 0.02, rng)
+        Bj = Bj.copy()
+        for j in range(k):
+            Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][::-1]
+        B = (Bp, Bj, Bx)
+        kernels_wanted = False
+    ref = _check(oracle, m, k, n, A, B, options={"lane_rows": 0})
+    for mode, num in ((1, 0), (2, 0), (1, 1), (2, 1)):
+        got = _check(oracle, m, k, n, A, B, options={"lane_rows": mode, "lane_numeric": num})
+        assert all(np.array_equal(x, y) for x, y in zip(ref[:3], got[:3]))
+        names = {s["name"] for s in got[3]["kernels"] if s["launches"]}
+        assert ("symbolic_lane" in names) == kernels_wanted, names
+        assert ("numeric_lane" in names) == (kernels_wanted and num == 1), names
+    if case == "cancel":
+        assert ref[0].tolist() == [0, 3, 3, 4] and ref[2][0] == 0.0
 
 
 def test_sort_key_width_paths(oracle):
