@@ -45,6 +45,7 @@ SYMBOLS = {
     "bhs_get_C": (_i, [_vp, _vp, _vp]),
     "bhs_get_rowptrC": (_i, [_vp, _vp]),
     "bhs_get_C_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "bhs_csr_sort_indices_device": (_i, [_vp, _i, _vp, _vp, _vp]),
     "bhs_get_kernel_stats": (_i, [_vp, C.POINTER(KernelStat), _i]),
     "bhs_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "bhs_strerror": (C.c_char_p, [_i]),

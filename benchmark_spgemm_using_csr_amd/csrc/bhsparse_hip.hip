@@ -144,6 +144,7 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
     int laneNumeric = 0;                 // 1: numeric stage of lane-bin rows through k_row_lane too (measured slower: strided stores)
     int maxRowA = 0;
@@ -154,6 +155,7 @@ struct bhs_handle {
     int compressB = 0;
     int cmpState = 0;                    // per data set: 0 undecided, 1 pays, -1 does not
     bool cmpActive = false;              // this multiply's symbolic wave bins run on the compressed pattern
+    DevBuf sortList, sortCnt, sortK, sortV;   // bhs_csr_sort_indices_device: long-row list, its counter, scratch keys / values
     DevBuf cExt, cLen, cPair, symKey;    // per B row: pair extents, (entries, pairs); pairs; per A row: symbolic bin key
     hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
     bool wantHostRowPtr = false, rowPtrStaged = false;
@@ -842,6 +844,39 @@ int run_pipeline(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
+// per-row sort of a device CSR by column, in place (bhs_csr_sort_indices_device; also applied to unsorted B)
+int sort_rows_device(bhs_handle* h, int n_row, const int* d_rowPtr, int* d_colInd, value_t* d_val)
+{
+    BHS_TRY(ensure(h, h->sortCnt, 16));
+    BHS_TRY(ensure(h, h->sortList, sizeof(int) * (size_t)n_row));
+    int* cnt = (int*)h->sortCnt.p;                      // [0] long rows, [1] longest row
+    BHS_HIP(hipMemsetAsync(cnt, 0, 16, h->stream));
+    const long long gmr = std::min<long long>(((long long)n_row + 255) / 256, (long long)h->numCU * 8);
+    hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, n_row, d_rowPtr, cnt + 1);
+    BHS_HIP(hipGetLastError());
+    int host[2] = {0, 0};
+    int nnz = 0;
+    BHS_HIP(hipMemcpyAsync(host, cnt, 8, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipMemcpyAsync(&nnz, d_rowPtr + n_row, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    if (host[1] > kSortLdsMax) {                        // rows beyond the LDS buffer sort in HBM scratch
+        BHS_TRY(ensure(h, h->sortK, sizeof(unsigned long long) * (size_t)std::max(nnz, 1)));
+        BHS_TRY(ensure(h, h->sortV, sizeof(value_t) * (size_t)std::max(nnz, 1)));
+    }
+    const long long gw = std::min<long long>(((long long)n_row + 3) / 4, (long long)h->numCU * 32);
+    hipLaunchKernelGGL(k_sort_rows_wave, dim3((unsigned)std::max<long long>(gw, 1)), dim3(256), 0, h->stream, n_row,
+                       d_rowPtr, d_colInd, (value_t*)d_val, (int*)h->sortList.p, cnt);
+    BHS_HIP(hipGetLastError());
+    if (host[1] > 1024) {
+        hipLaunchKernelGGL(k_sort_rows_block, dim3((unsigned)(h->numCU * 2)), dim3(256), 0, h->stream, d_rowPtr, d_colInd,
+                           (value_t*)d_val, (const int*)h->sortList.p, (const int*)cnt,
+                           (unsigned long long*)h->sortK.p, (value_t*)h->sortV.p);
+        BHS_HIP(hipGetLastError());
+    }
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    return BHS_SUCCESS;
+}
+
 int finish_set_data(bhs_handle* h)
 {
     // derived launch parameters
@@ -881,6 +916,27 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
         h->bSorted = flag ? 0 : 1;
+        if (!h->bSorted && h->sortB) {
+            // Unsorted rows of B: sort them once here (the reference's driver does this on the host before
+            // initData, main.cu:62-64) so that the multiply can take the kernels that want ascending rows.
+            // Borrowed device arrays are never written: the sort runs on a private copy.
+            if (!h->ownAB) {
+                BHS_TRY(ensure(h, h->ownB[1], sizeof(int) * (size_t)h->nnzB));
+                BHS_TRY(ensure(h, h->ownB[2], sizeof(value_t) * (size_t)h->nnzB));
+                BHS_HIP(hipMemcpyAsync(h->ownB[1].p, h->dBj, sizeof(int) * (size_t)h->nnzB, hipMemcpyDeviceToDevice, h->stream));
+                BHS_HIP(hipMemcpyAsync(h->ownB[2].p, h->dBx, sizeof(value_t) * (size_t)h->nnzB, hipMemcpyDeviceToDevice, h->stream));
+                h->dBj = (const int*)h->ownB[1].p;
+                h->dBx = (const value_t*)h->ownB[2].p;
+            }
+            BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
+            BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj,
+                               small + S_SORTED);
+            BHS_HIP(hipGetLastError());
+            BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            BHS_HIP(hipStreamSynchronize(h->stream));
+            h->bSorted = flag ? 0 : 1;          // (duplicate columns inside a row still count as "not ascending")
+        }
     }
     // compressed pattern of B: decide now whether it pays (the multiply itself re-runs the compression inside its
     // timed region; this pass only yields the pair count)
@@ -987,6 +1043,10 @@ int bhs_destroy(bhs_handle* h)
     release(h->queue);
     release(h->cExt);
     release(h->cPair);
+    release(h->sortList);
+    release(h->sortCnt);
+    release(h->sortK);
+    release(h->sortV);
     release(h->cLen);
     release(h->symKey);
     release(h->blockSum);
@@ -1151,6 +1211,14 @@ int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC
     return BHS_SUCCESS;
 }
 
+int bhs_csr_sort_indices_device(bhs_handle* h, int n_row, const int* d_rowPtr, int* d_colInd, bhs_value_t* d_val)
+{
+    if (!h || n_row < 0 || (n_row > 0 && (!d_rowPtr || !d_colInd || !d_val))) return BHS_ERR_INVALID_ARG;
+    if (n_row == 0) return BHS_SUCCESS;
+    BHS_HIP(hipSetDevice(h->device));
+    return sort_rows_device(h, n_row, d_rowPtr, d_colInd, (value_t*)d_val);
+}
+
 int bhs_get_kernel_stats(bhs_handle* h, bhs_kernel_stat* out, int cap)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
@@ -1184,6 +1252,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }

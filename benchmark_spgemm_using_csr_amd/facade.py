@@ -165,6 +165,13 @@ class bhsparse(object):
             raise BhsparseError("bhs_get_C_device", err)
         return tuple(int(x.value or 0) for x in p)
 
+    def csr_sort_indices_device(self, n_row, d_rowPtr, d_colInd, d_val):
+        """In-place, stable per-row sort by column of a device-resident CSR matrix
+        (ref_spgemm::csr_sort_indices, SpGEMM_cuda/ref_spgemm.h:37-62, on the GPU)."""
+        if self._h is None:
+            return _lib.BHS_ERR_NOT_READY
+        return self._lib.bhs_csr_sort_indices_device(self._h, n_row, _ptr(d_rowPtr), _ptr(d_colInd), _ptr(d_val))
+
     def get_rowptrC(self, out=None):
         out = np.empty(self._m + 1, np.int32) if out is None else out
         err = self._lib.bhs_get_rowptrC(self._h, _ptr(out))

@@ -127,6 +127,16 @@ BHS_API int bhs_get_rowptrC(bhs_handle *h, int *csrRowPtrC /* m+1 */);
 BHS_API int bhs_get_C_device(bhs_handle *h, const int **d_rowPtrC, const int **d_colIndC,
                              const bhs_value_t **d_valC);
 
+/* ---- input preparation ----------------------------------------------------
+ * Per-row sort of a DEVICE-resident CSR matrix by column index, in place and
+ * stable: ref_spgemm::csr_sort_indices (SpGEMM_cuda/ref_spgemm.h:37-62), which
+ * the reference's driver runs on the host over every Matrix Market input before
+ * the multiply (main.cu:62-64).  Rows already in order are left untouched.
+ * Synchronous.  (bhs_set_data / bhs_set_data_device accept unsorted rows as they
+ * are; sorted rows of B let the multiply take its fastest kernels.)            */
+BHS_API int bhs_csr_sort_indices_device(bhs_handle *h, int n_row, const int *d_rowPtr, int *d_colInd,
+                                        bhs_value_t *d_val);
+
 /* ---- measurement ----------------------------------------------------------
  * Per-kernel-family device times of the LAST bhs_spgemm, measured with
  * hipEvents on the stream the kernels were launched on (what bench.py reports
@@ -156,6 +166,9 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
  *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
  *                     nnz(B) < 2^29)
+ *   "sort_b"          1 (default): rows of B that are not ascending are sorted at bhs_set_data[_device] time (device
+ *                     pointers are borrowed and never written: the sort runs on a private copy); 0: multiply them as
+ *                     they are (general kernels only).  Set it before bhs_set_data.
  *   "lane_rows"       lane-per-row symbolic kernel (k_row_lane: one row per lane, K-way merge of the sorted B rows in
  *                     registers) for rows with <= 12 entries and <= 144 products: 0 never, 1 (default) when EVERY row of
  *                     A has <= 12 entries (stencils), 2 for any matrix.  Needs B with strictly ascending rows.

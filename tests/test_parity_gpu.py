@@ -246,15 +246,57 @@ def test_lane_per_row_kernel(oracle, case):
             Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][::-1]
         B = (Bp, Bj, Bx)
         kernels_wanted = False
+    sb = 0 if case == "unsorted_b" else 1          # (left unsorted, B keeps the lane kernel out)
     ref = _check(oracle, m, k, n, A, B, options={"lane_rows": 0})
     for mode, num in ((1, 0), (2, 0), (1, 1), (2, 1)):
-        got = _check(oracle, m, k, n, A, B, options={"lane_rows": mode, "lane_numeric": num})
+        got = _check(oracle, m, k, n, A, B, options={"lane_rows": mode, "lane_numeric": num, "sort_b": sb})
         assert all(np.array_equal(x, y) for x, y in zip(ref[:3], got[:3]))
         names = {s["name"] for s in got[3]["kernels"] if s["launches"]}
         assert ("symbolic_lane" in names) == kernels_wanted, names
         assert ("numeric_lane" in names) == (kernels_wanted and num == 1), names
     if case == "cancel":
         assert ref[0].tolist() == [0, 3, 3, 4] and ref[2][0] == 0.0
+
+
+@pytest.mark.parametrize("lens", [[0, 1, 2, 64, 65, 128, 129, 300, 512, 513, 1024], [1025, 3, 4096, 4097, 0, 9000, 70],
+                                  [5] * 3000])
+@pytest.mark.parametrize("f32", [False, True])
+def test_device_row_sort(oracle, lens, f32):
+    """bhs_csr_sort_indices_device against the host csr_sort_indices restatement (ref_spgemm.h:37-62): stable,
+    in place, every row-length class (register sort, LDS network, HBM scratch), duplicates kept in input order."""
+    import torch
+    rng = np.random.default_rng(len(lens))
+    lens = np.array(lens)
+    rp = np.zeros(len(lens) + 1, np.int32)
+    np.cumsum(lens, out=rp[1:])
+    n = 20000
+    col = np.concatenate([rng.integers(0, n, L) if i % 3 == 0 else rng.permutation(n)[:L] for i, L in enumerate(lens)]
+                         + [np.empty(0, np.int64)]).astype(np.int32)
+    col[rp[3]:rp[4]] = np.sort(col[rp[3]:rp[4]])                 # one row already in order
+    val = np.arange(len(col), dtype=np.float64) + 0.5              # distinct: shows where every entry came from
+    ecol, eval_ = col.copy(), val.copy()
+    for i in range(len(lens)):
+        o = np.argsort(col[rp[i]:rp[i + 1]], kind="stable")
+        ecol[rp[i]:rp[i + 1]] = col[rp[i]:rp[i + 1]][o]
+        eval_[rp[i]:rp[i + 1]] = val[rp[i]:rp[i + 1]][o]
+    oc, ov = col.copy(), val.copy()
+    oracle.csr_sort_indices(rp, oc, ov)
+    assert np.array_equal(oc, ecol) and np.array_equal(ov, eval_)
+    dt = np.float32 if f32 else np.float64
+    dev = torch.device("cuda", 0)
+    d_rp, d_col = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    d_val = torch.from_numpy(val.astype(dt)).to(dev)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse(value_dtype=dt)
+    assert bh.initPlatform(plats) == 0
+    assert bh.csr_sort_indices_device(len(lens), d_rp, d_col, d_val) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_col.cpu().numpy(), ecol)
+    assert np.array_equal(d_val.cpu().numpy(), eval_.astype(dt))
+    assert bh.csr_sort_indices_device(len(lens), d_rp, d_col, d_val) == 0      # idempotent
+    assert np.array_equal(d_col.cpu().numpy(), ecol)
+    assert bh.freePlatform() == 0
 
 
 def test_sort_key_width_paths(oracle):
@@ -317,8 +359,26 @@ def test_unsorted_B_rows_still_correct(oracle):
         p = rng.permutation(Bp[j + 1] - Bp[j])
         Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][p]
         Bx[Bp[j]:Bp[j + 1]] = Bx[Bp[j]:Bp[j + 1]][p]
-    _check(oracle, 300, 200, 5000, A, (Bp, Bj, Bx))
-    _check(oracle, 300, 200, 5000, A, (Bp, Bj, Bx), options={"max_table_log2": 6})
+    r0 = _check(oracle, 300, 200, 5000, A, (Bp, Bj, Bx), options={"sort_b": 0})     # multiplied as they are
+    _check(oracle, 300, 200, 5000, A, (Bp, Bj, Bx), options={"sort_b": 0, "max_table_log2": 6})
+    r1 = _check(oracle, 300, 200, 5000, A, (Bp, Bj, Bx))                             # default: sorted at set_data time
+    assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
+    # device-pointer API: the caller's arrays are borrowed and must come back untouched
+    import torch
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (A[0], A[1], A[2], Bp, Bj, Bx)]
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.initData_device(300, 200, 5000, len(A[1]), t[2], t[0], t[1], len(Bj), t[5], t[3], t[4]) == 0
+    assert bh.spgemm() == 0
+    assert bh.get_nnzC() == r0[3]["nnzC"] and np.array_equal(bh.get_rowptrC(), r0[0])
+    Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+    assert bh.get_C(Cj, Cx) == 0
+    assert np.array_equal(Cj, r0[1]) and np.array_equal(Cx, r0[2])
+    assert np.array_equal(t[4].cpu().numpy(), Bj) and np.array_equal(t[5].cpu().numpy(), Bx)
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
 @pytest.mark.parametrize("cap", [6, 8, 10])
