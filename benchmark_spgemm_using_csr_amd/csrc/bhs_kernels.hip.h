@@ -1698,7 +1698,7 @@ struct QuadSmem {
 
 template <bool NUM, bool PACK32>
 __global__ __launch_bounds__(64) void k_row_quad(
-    const int4* __restrict__ desc, int qn,
+    const int4* __restrict__ desc, int qn, const int* __restrict__ Ap,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
@@ -1721,7 +1721,11 @@ __global__ __launch_bounds__(64) void k_row_quad(
     // global round trips of a row never sit on the critical path.
     auto load_desc = [&](int grp_) {
         int4 r = make_int4(-1, 0, 0, 0);
-        if (grp_ < gEnd && grp_ * 4 + g < qn) r = desc[grp_ * 4 + g];
+        if (grp_ < gEnd && grp_ * 4 + g < qn) {
+            const int q = grp_ * 4 + g;
+            if (desc) r = desc[q];
+            else r = make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);   // direct: no queue, entry q is row q (see k_row_lane)
+        }
         return r;
     };
     auto load_a = [&](const int4& dd, int& c_, value_t& av_) {
@@ -2213,6 +2217,7 @@ constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 
 
 template <int K, bool NUM, bool SMALLB>
 __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4* __restrict__ desc, int qn,
+                                                  const int* __restrict__ Ap,
                                                   const int* __restrict__ Aj, const value_t* __restrict__ Ax,
                                                   const int* __restrict__ Bp, const int* __restrict__ Bj,
                                                   const value_t* __restrict__ Bx, int* __restrict__ cntOut,
@@ -2222,7 +2227,9 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
     constexpr int E = NUM ? BHS_LANE_E : 1;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= qn) return;
-    const int4 d = desc[q];
+    // desc == nullptr ("direct"): every row of the matrix is in this bin, so the queue was never built and entry q
+    // is row q (its descriptor comes from rowPtrA and, for the numeric pass, rowPtrC in cntOut)
+    const int4 d = desc ? desc[q] : make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);
     const int row = d.x, a0 = d.y, nA = d.z - d.y;
     auto ld_col = [&](int p) {
         if constexpr (SMALLB) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(Bj) + ((unsigned)p << 2));

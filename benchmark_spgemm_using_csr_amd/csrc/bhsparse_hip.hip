@@ -144,6 +144,7 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
     int laneNumeric = 0;                 // 1: numeric stage of lane-bin rows through k_row_lane too (measured slower: strided stores)
@@ -446,7 +447,7 @@ int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->ls, queue, qn, h->dAj, h->dAx, h->dBp, h->dBj,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->ls, queue, qn, h->dAp, h->dAj, h->dAx, h->dBp, h->dBj,
                        h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -472,11 +473,11 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
     case KK:                                                                                                  \
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
-                               h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
+                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
                                (value_t*)h->Cx.p);                                                            \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
-                               h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
+                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
                                (value_t*)h->Cx.p);                                                            \
         break;
     switch (K) {
@@ -692,6 +693,11 @@ int run_pipeline(bhs_handle* h)
         h->cmpActive = cmpBins;
         if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpActive ? "used" : "not used");
     }
+    // "Direct" stages: when EVERY row of the matrix sits in the lane bin or the quad bin (stencils: poisson5pt,
+    // 7pt, 9pt), that bin's queue would list the rows 0..m-1 in order -- the fill pass is skipped and the kernel
+    // derives its descriptors from rowPtrA (and rowPtrC) itself.
+    const bool symDirect = h->directBins && (symCount[kLaneBin] == m || symCount[1] == m);
+    if (!symDirect) {
     memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
     BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
@@ -705,6 +711,8 @@ int run_pipeline(bhs_handle* h)
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
     }
+    }
+    const int4* symQueue = symDirect ? nullptr : (const int4*)h->queue.p;
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
 
     // ------------------------------------------------------------ stage 2: symbolic
@@ -714,7 +722,7 @@ int run_pipeline(bhs_handle* h)
     if (symCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
         BHS_TRY(timed_begin(h, "symbolic_lane", &ep));
-        BHS_TRY(launch_row_lane<false>(h, laneK, (const int4*)h->queue.p + symStart[kLaneBin], symCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(launch_row_lane<false>(h, laneK, symQueue ? symQueue + symStart[kLaneBin] : nullptr, symCount[kLaneBin], (int*)h->Cp.p));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += symCount[kLaneBin];
@@ -725,7 +733,7 @@ int run_pipeline(bhs_handle* h)
         if (!symCount[b]) continue;
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kSymNames[b], &ep));
-        int rc = dispatch_bin<false>(h, kSymCfg[b], (const int4*)h->queue.p + symStart[b], symCount[b], (int*)h->Cp.p);
+        int rc = dispatch_bin<false>(h, kSymCfg[b], symQueue ? symQueue + symStart[b] : nullptr, symCount[b], (int*)h->Cp.p);
         if (rc) { h->ls = h->stream; return rc; }
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
@@ -761,6 +769,8 @@ int run_pipeline(bhs_handle* h)
     }
     BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
     BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
+    const bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    if (!numDirect) {
     memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
     BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
     {
@@ -774,6 +784,8 @@ int run_pipeline(bhs_handle* h)
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
     }
+    }
+    const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
     BHS_HIP(hipEventRecord(h->ev[3], h->stream));
     h->rowPtrStaged = false;
     if (h->wantHostRowPtr) {
@@ -793,7 +805,7 @@ int run_pipeline(bhs_handle* h)
     if (numCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
         BHS_TRY(timed_begin(h, "numeric_lane", &ep));
-        BHS_TRY(launch_row_lane<true>(h, laneK, (const int4*)h->queue.p + numStart[kLaneBin], numCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(launch_row_lane<true>(h, laneK, numQueue ? numQueue + numStart[kLaneBin] : nullptr, numCount[kLaneBin], (int*)h->Cp.p));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += numCount[kLaneBin];
@@ -804,7 +816,7 @@ int run_pipeline(bhs_handle* h)
         if (!numCount[b]) continue;
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
-        int rc = dispatch_bin<true>(h, kNumCfg[b], (const int4*)h->queue.p + numStart[b], numCount[b], (int*)h->Cp.p);
+        int rc = dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[b] : nullptr, numCount[b], (int*)h->Cp.p);
         if (rc) { h->ls = h->stream; return rc; }
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
@@ -820,11 +832,13 @@ int run_pipeline(bhs_handle* h)
         unsigned long long v[3];
         if (symStat[b] >= 0) {
             memcpy(v, hs + S_SYM_SUMS + 6 * b, sizeof(v));
+            if (symDirect) { v[0] = (unsigned long long)h->nnzCt; v[2] = (unsigned long long)h->nnzA; }   // no fill pass counted them
             StatRec& r = h->stats[symStat[b]];
             r.products += (int64_t)v[0]; r.nnzA_rows += (int64_t)v[2];
         }
         if (numStat[b] >= 0) {
             memcpy(v, hs + S_NUM_SUMS + 6 * b, sizeof(v));
+            if (numDirect) { v[0] = (unsigned long long)h->nnzCt; v[1] = (unsigned long long)h->nnzC; v[2] = (unsigned long long)h->nnzA; }
             StatRec& r = h->stats[numStat[b]];
             r.products += (int64_t)v[0]; r.nnz_out += (int64_t)v[1]; r.nnzA_rows += (int64_t)v[2];
         }
@@ -1252,6 +1266,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = value != 0; return BHS_SUCCESS; }

@@ -166,6 +166,8 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
  *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
  *                     nnz(B) < 2^29)
+ *   "direct_bins"     1 (default): a stage whose rows ALL sit in the lane bin or the quad bin (stencils) skips the
+ *                     queue-fill pass; the kernel derives row q's descriptor from rowPtrA / rowPtrC
  *   "sort_b"          1 (default): rows of B that are not ascending are sorted at bhs_set_data[_device] time (device
  *                     pointers are borrowed and never written: the sort runs on a private copy); 0: multiply them as
  *                     they are (general kernels only).  Set it before bhs_set_data.

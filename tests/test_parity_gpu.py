@@ -299,6 +299,26 @@ def test_device_row_sort(oracle, lens, f32):
     assert bh.freePlatform() == 0
 
 
+@pytest.mark.parametrize("stencil,dims", [("poisson5pt", (33, 29, 1)), ("poisson7pt", (8, 9, 7)), ("poisson9pt", (21, 18, 1))])
+def test_direct_stages_without_queue(oracle, stencil, dims):
+    """All rows in the lane bin (symbolic) and in the quad bin (numeric): both stages run without their queue
+    (no fill_queues launch); forcing the queues back must give the same C."""
+    m, rp, col, val = poisson_case(stencil, *dims)
+    A = (rp, col, val)
+    r1 = _check(oracle, m, m, m, A, A)
+    names = {s["name"] for s in r1[3]["kernels"] if s["launches"]}
+    assert "fill_queues" not in names and "symbolic_lane" in names and "numeric_quad<64>" in names, names
+    rows = {s["name"]: (s["rows"], s["products"], s["nnz_out"]) for s in r1[3]["kernels"]}
+    assert rows["numeric_quad<64>"] == (m, r1[3]["nnzCt"], r1[3]["nnzC"])
+    r0 = _check(oracle, m, m, m, A, A, options={"direct_bins": 0})
+    assert "fill_queues" in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
+    assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
+    r2 = _check(oracle, m, m, m, A, A, options={"lane_rows": 0})                  # symbolic and numeric both direct on the quad kernel
+    r3 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 1})               # ... and both on the lane kernel
+    for r in (r2, r3):
+        assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r[:3]))
+
+
 def test_sort_key_width_paths(oracle):
     """32-bit packed sort keys vs the 64-bit fallback must agree (wave and quarter-wave kernels)."""
     m, rp, col, val = poisson_case("poisson27pt", 14, 14, 14)
