@@ -2196,24 +2196,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
 // banded matrices.  Needs strictly ascending B rows (checked at set_data time).
 //
 // Measured on MI355X (poisson5pt 1024^2 / poisson7pt 128^3 / poisson9pt 1024^2): the symbolic pass drops from
-// 0.081 / 0.476 / 0.273 ms (quarter-wave and wave kernels) to 0.034 / 0.14 / 0.12 ms.  The numeric pass does NOT
-// gain: a lane writes its row of C one entry per step, a 4- or 8-byte store at a stride of one row per lane, and
-// with 50 MB of rows in flight those partially written lines leave the L2 before they are complete (0.41 ms
-// against 0.18 ms for the quarter-wave kernel on poisson5pt; 0.09 ms with the stores removed).  The host therefore
-// uses it for the symbolic stage only (option "lane_numeric" routes the numeric stage here as well).
+// 0.081 / 0.476 / 0.273 ms (quarter-wave and wave kernels) to 0.030 / 0.12 / 0.10 ms.  The numeric pass gains only
+// while K <= 6 (poisson5pt: 0.187 -> 0.122 ms; 7pt and 9pt lose: two more loads per advancing head, 8 and 10 heads
+// in registers), and only with its stores staged through LDS (see S below); the host routes the numeric stage
+// here for K <= 6 (option "lane_numeric").
 // ===========================================================================
 // SMALLB: nnz(B) < 2^29, so byte offsets into colIndB / valB fit 32 bits and the loads take the scalar base +
-// 32-bit lane offset form: no 64-bit address pair per head (K = 6: 100 -> ~60 VGPRs, i.e. 8 waves per SIMD
-// instead of 4 for a kernel that lives on latency hiding).
-// E results are collected in registers and stored together, and the stores are issued BEFORE the loads that
-// advance the heads: the memory counter is in-order, so the wait for those loads also covers the stores -- issued
-// the other way round, every merge step waited for its own stores to be acknowledged (poisson5pt: 0.38 ms).
-#ifndef BHS_LANE_E
-#define BHS_LANE_E 1
+// 32-bit lane offset form: no 64-bit address pair per head.
+#ifndef BHS_LANE_S
+#define BHS_LANE_S 16
 #endif
 // waves per SIMD asked of the register allocator (left alone it keeps both arms of every predicated load live:
-// 118 VGPRs for K = 6)
-constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 ? 6 : 5) : (K <= 6 ? 8 : K <= 8 ? 6 : K <= 10 ? 5 : 4); }
+// 118 VGPRs for K = 6); the numeric pass is bounded by its LDS staging buffers (S = 16: 52 KB per workgroup)
+constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 ? 6 : 5) : (BHS_LANE_S == 16 ? 3 : BHS_LANE_S == 8 ? (K <= 10 ? 5 : 4) : (K <= 10 ? 7 : 4)); }
 
 template <int K, bool NUM, bool SMALLB>
 __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4* __restrict__ desc, int qn,
@@ -2224,12 +2219,23 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
                                                   int* __restrict__ Cj, value_t* __restrict__ Cx)
 {
     constexpr int kEnd = 0x7fffffff;                       // exhausted head (column indices are < 2^31 - 1)
-    constexpr int E = NUM ? BHS_LANE_E : 1;
+    // numeric pass: S results per row are staged in LDS (row-major, stride S + 1) and then written by S lanes per
+    // row, so that C receives runs of up to S consecutive entries instead of one entry per lane at a stride of a
+    // whole row (those 4-byte stores left the L2 as partially written lines: 0.41 ms on poisson5pt, 0.09 ms
+    // without the stores).  Longer runs beat occupancy: S = 4 / 8 / 16 -> 0.23 / 0.15 / 0.12 ms on poisson5pt
+    // (7 / 5 / 3 waves per SIMD; 13 results per row, so S = 16 writes every row in one piece).
+    constexpr int S = BHS_LANE_S, SP = S + 1, RPP = 64 / S;   // RPP rows per flush pass, S lanes each
+    __shared__ int sCol[NUM ? 4 : 1][NUM ? 64 * SP : 1];
+    __shared__ value_t sVal[NUM ? 4 : 1][NUM ? 64 * SP : 1];
+    __shared__ int sN[NUM ? 4 : 1][NUM ? 64 : 1];
+    __shared__ int sOut[NUM ? 4 : 1][NUM ? 64 : 1];
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= qn) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bool more = q < qn;
     // desc == nullptr ("direct"): every row of the matrix is in this bin, so the queue was never built and entry q
     // is row q (its descriptor comes from rowPtrA and, for the numeric pass, rowPtrC in cntOut)
-    const int4 d = desc ? desc[q] : make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);
+    int4 d = make_int4(0, 0, 0, 0);
+    if (more) d = desc ? desc[q] : make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);
     const int row = d.x, a0 = d.y, nA = d.z - d.y;
     auto ld_col = [&](int p) {
         if constexpr (SMALLB) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(Bj) + ((unsigned)p << 2));
@@ -2261,49 +2267,62 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
         bv[j] = 0.0;
         if (pos[j] < end[j]) { col[j] = ld_col(pos[j]); if (NUM) bv[j] = (acc_t)ld_val(pos[j]); }
     }
-    long long out = d.w;
-    int cnt = 0;
-    bool more = true;
-    while (more) {
-        int oc[E];
-        acc_t ov[E];
+    // one merge step: smallest head column, sum of the heads that carry it, those heads advance
+    auto step = [&](int& mn, acc_t& sum) {
+        mn = col[0];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int mn = col[0];
+        for (int j = 1; j < K; ++j) mn = min(mn, col[j]);
+        sum = 0.0;
+        if (mn == kEnd) return false;
 #pragma unroll
-            for (int j = 1; j < K; ++j) mn = min(mn, col[j]);
-            oc[e] = mn;
-            ov[e] = 0.0;
-            if (mn != kEnd) {
-                if (NUM) {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) if (col[j] == mn) ov[e] += av[j] * bv[j];
-                }
-                if (NUM && e == E - 1) {                       // chunk complete: its stores go out ahead of the loads below
-#pragma unroll
-                    for (int x = 0; x < E; ++x) { Cj[out + x] = oc[x]; Cx[out + x] = (value_t)ov[x]; }
-                    out += E;
-                }
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    if (col[j] == mn) {
-                        ++pos[j];
-                        col[j] = kEnd;
-                        if (pos[j] < end[j]) { col[j] = ld_col(pos[j]); if (NUM) bv[j] = (acc_t)ld_val(pos[j]); }
-                    }
-                }
-                ++cnt;
-            } else {
-                if (NUM) {                                      // row finished inside a chunk: store what the chunk holds
-#pragma unroll
-                    for (int x = 0; x < E; ++x) if (x < e) { Cj[out + x] = oc[x]; Cx[out + x] = (value_t)ov[x]; }
-                }
-                more = false;
-                break;
+        for (int j = 0; j < K; ++j) {
+            if (col[j] == mn) {
+                if (NUM) sum += av[j] * bv[j];
+                ++pos[j];
+                col[j] = kEnd;
+                if (pos[j] < end[j]) { col[j] = ld_col(pos[j]); if (NUM) bv[j] = (acc_t)ld_val(pos[j]); }
             }
         }
+        return true;
+    };
+    if constexpr (!NUM) {
+        int cnt = 0, mn;
+        acc_t sum;
+        while (more) { more = step(mn, sum); cnt += more ? 1 : 0; }
+        if (q < qn) cntOut[row] = cnt;
+    } else {
+        int out = d.w;                                      // (nnz(C) < 2^31)
+        while (__any(more)) {
+            int nst = 0;
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                if (more) {
+                    int mn;
+                    acc_t sum;
+                    more = step(mn, sum);
+                    if (more) {
+                        sCol[w][lane * SP + e] = mn;
+                        sVal[w][lane * SP + e] = (value_t)sum;
+                        ++nst;
+                    }
+                }
+            }
+            sN[w][lane] = nst;
+            sOut[w][lane] = out;
+            out += nst;
+            wave_sync();
+#pragma unroll
+            for (int pass = 0; pass < S; ++pass) {
+                const int r = pass * RPP + lane / S, e = lane % S;
+                if (e < sN[w][r]) {
+                    const long long o = (long long)sOut[w][r] + e;
+                    Cj[o] = sCol[w][r * SP + e];
+                    Cx[o] = sVal[w][r * SP + e];
+                }
+            }
+            wave_sync();
+        }
     }
-    if (!NUM) cntOut[row] = cnt;
 }
 
 // ===========================================================================

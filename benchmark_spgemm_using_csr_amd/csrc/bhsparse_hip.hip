@@ -147,7 +147,7 @@ struct bhs_handle {
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
-    int laneNumeric = 0;                 // 1: numeric stage of lane-bin rows through k_row_lane too (measured slower: strided stores)
+    int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 6 (where it wins)
     int maxRowA = 0;
     // compressed pattern of B for the symbolic pass (k_compress_b): 0 never (default), 1 when the data has <= 60 %
     // as many (block, mask) pairs as entries, 2 always (needs sorted B rows either way).  Off by default: on
@@ -650,7 +650,7 @@ int run_pipeline(bhs_handle* h)
         laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
     const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK);
     const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
-                                      h->laneNumeric ? laneK : 0);
+                                      (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 6)) ? laneK : 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     h->cmpActive = false;
@@ -1269,7 +1269,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
-    if (!strcmp(key, "lane_numeric")) { h->laneNumeric = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }

@@ -307,15 +307,17 @@ def test_direct_stages_without_queue(oracle, stencil, dims):
     A = (rp, col, val)
     r1 = _check(oracle, m, m, m, A, A)
     names = {s["name"] for s in r1[3]["kernels"] if s["launches"]}
-    assert "fill_queues" not in names and "symbolic_lane" in names and "numeric_quad<64>" in names, names
+    numk = "numeric_lane" if stencil == "poisson5pt" else "numeric_quad<64>"      # lane numeric only while K <= 6
+    assert "fill_queues" not in names and "symbolic_lane" in names and numk in names, names
     rows = {s["name"]: (s["rows"], s["products"], s["nnz_out"]) for s in r1[3]["kernels"]}
-    assert rows["numeric_quad<64>"] == (m, r1[3]["nnzCt"], r1[3]["nnzC"])
+    assert rows[numk] == (m, r1[3]["nnzCt"], r1[3]["nnzC"])
     r0 = _check(oracle, m, m, m, A, A, options={"direct_bins": 0})
     assert "fill_queues" in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
     assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
     r2 = _check(oracle, m, m, m, A, A, options={"lane_rows": 0})                  # symbolic and numeric both direct on the quad kernel
     r3 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 1})               # ... and both on the lane kernel
-    for r in (r2, r3):
+    r4 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 0})
+    for r in (r2, r3, r4):
         assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r[:3]))
 
 
