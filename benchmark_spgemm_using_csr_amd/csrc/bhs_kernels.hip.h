@@ -2216,8 +2216,11 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
                                                   const int* __restrict__ Aj, const value_t* __restrict__ Ax,
                                                   const int* __restrict__ Bp, const int* __restrict__ Bj,
                                                   const value_t* __restrict__ Bx, int* __restrict__ cntOut,
-                                                  int* __restrict__ Cj, value_t* __restrict__ Cx)
+                                                  int* __restrict__ Cj, value_t* __restrict__ Cx,
+                                                  int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots)
 {
+    // ubOut != nullptr (symbolic pass of a "lane-first" multiply, where no upper-bound pass ran): the row's product
+    // count is written to ubOut and added into one of 64 counters (ctSlots; the host sums them)
     constexpr int kEnd = 0x7fffffff;                       // exhausted head (column indices are < 2^31 - 1)
     // numeric pass: S results per row are staged in LDS (row-major, stride S + 1) and then written by S lanes per
     // row, so that C receives runs of up to S consecutive entries instead of one entry per lane at a stride of a
@@ -2286,10 +2289,27 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
         return true;
     };
     if constexpr (!NUM) {
+        long long prods = 0;
+        if (ubOut) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) prods += end[j] - pos[j];
+        }
         int cnt = 0, mn;
         acc_t sum;
         while (more) { more = step(mn, sum); cnt += more ? 1 : 0; }
         if (q < qn) cntOut[row] = cnt;
+        if (ubOut) {
+            __shared__ unsigned long long bsum;
+            if (threadIdx.x == 0) bsum = 0;
+            __syncthreads();
+            if (q < qn) ubOut[row] = prods > 0x7fffffffLL ? 0x7fffffff : (int)prods;
+            unsigned long long t = (unsigned long long)prods;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0 && t) atomicAdd(&bsum, t);
+            __syncthreads();
+            if (threadIdx.x == 0 && bsum) atomicAdd(&ctSlots[blockIdx.x & 63], bsum);
+        }
     } else {
         int out = d.w;                                      // (nnz(C) < 2^31)
         while (__any(more)) {

@@ -144,6 +144,8 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
+    int maxRowB = 0;
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
@@ -185,7 +187,9 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_NUM_SUMS = 104 + 96,
        S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
        S_SORTED = 300, S_MAXROW = 301,
-       S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */, S_SMALL_INTS = 320 };
+       S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
+       S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
+       S_SMALL_INTS = 448 };
 
 int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
 {
@@ -465,7 +469,8 @@ int launch_row_quad(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 }
 
 template <bool NUM>
-int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCnt)
+int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCnt, int* ubOut = nullptr,
+                    unsigned long long* ctSlots = nullptr)
 {
     const unsigned grid = (unsigned)(((long long)qn + 255) / 256);
     const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
@@ -474,11 +479,11 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p);                                                            \
+                               (value_t*)h->Cx.p, ubOut, ctSlots);                                            \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p);                                                            \
+                               (value_t*)h->Cx.p, ubOut, ctSlots);                                            \
         break;
     switch (K) {
         BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)
@@ -670,6 +675,20 @@ int run_pipeline(bhs_handle* h)
         h->stats[ep->stat].rows += h->k;
     }
     const int* symKeys = cmpBins ? (const int*)h->symKey.p : (const int*)h->ub.p;
+    // "Lane-first": every row of A has <= laneK entries and every row of B is short, so every row can go through
+    // the lane-per-row symbolic kernel whatever its product count (the kernel has no table to overflow).  The
+    // upper-bound pass, its host round trip and the symbolic queue all disappear; the lane kernel writes ub[] and
+    // the product total on the side.
+    const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64;
+    int symCount[kMaxBins], symStart[kMaxBins + 1];
+    if (laneFirst) {
+        BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
+        for (int b = 0; b < kMaxBins; ++b) { symCount[b] = 0; symStart[b] = 0; }
+        symStart[kMaxBins] = 0;
+        symCount[kLaneBin] = m;
+    }
+    bool symDirect = laneFirst;
+    if (!laneFirst) {
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
     BHS_TRY(launch_upper_bound(h, symSpec, cmpBins, symSpec.upper[8]));
     BHS_TRY(timed_end(h, ep));
@@ -677,7 +696,6 @@ int run_pipeline(bhs_handle* h)
     h->stats[ep->stat].rows += m;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
-    int symCount[kMaxBins], symStart[kMaxBins + 1];
     symStart[0] = 0;
     for (int b = 0; b < kMaxBins; ++b) {
         symCount[b] = hs[S_SYM_COUNT + b];
@@ -696,7 +714,7 @@ int run_pipeline(bhs_handle* h)
     // "Direct" stages: when EVERY row of the matrix sits in the lane bin or the quad bin (stencils: poisson5pt,
     // 7pt, 9pt), that bin's queue would list the rows 0..m-1 in order -- the fill pass is skipped and the kernel
     // derives its descriptors from rowPtrA (and rowPtrC) itself.
-    const bool symDirect = h->directBins && (symCount[kLaneBin] == m || symCount[1] == m);
+    symDirect = h->directBins && (symCount[kLaneBin] == m || symCount[1] == m);
     if (!symDirect) {
     memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
     BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
@@ -712,6 +730,7 @@ int run_pipeline(bhs_handle* h)
         h->stats[ep->stat].launches++;
     }
     }
+    }   // !laneFirst
     const int4* symQueue = symDirect ? nullptr : (const int4*)h->queue.p;
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
 
@@ -722,7 +741,9 @@ int run_pipeline(bhs_handle* h)
     if (symCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
         BHS_TRY(timed_begin(h, "symbolic_lane", &ep));
-        BHS_TRY(launch_row_lane<false>(h, laneK, symQueue ? symQueue + symStart[kLaneBin] : nullptr, symCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(launch_row_lane<false>(h, laneK, symQueue ? symQueue + symStart[kLaneBin] : nullptr, symCount[kLaneBin], (int*)h->Cp.p,
+                                       laneFirst ? (int*)h->ub.p : nullptr,
+                                       laneFirst ? (unsigned long long*)(small + S_CT_SLOTS) : nullptr));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += symCount[kLaneBin];
@@ -756,6 +777,11 @@ int run_pipeline(bhs_handle* h)
     h->stats[ep->stat].launches += 3;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
+    if (laneFirst) {                                     // product count: the lane kernel's 64 partial sums
+        unsigned long long t = 0, v;
+        for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
+        h->nnzCt = (long long)t;
+    }
     long long nnzC;
     memcpy(&nnzC, hs + S_TOTAL_C, 8);
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
@@ -911,6 +937,16 @@ int finish_set_data(bhs_handle* h)
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
     h->maxRowA = maxRowA;
+    h->maxRowB = 0;
+    if (h->k > 0) {
+        int* small0 = (int*)h->small.p;
+        BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
+        const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 8);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_MAXROW);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(&h->maxRowB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+    }
     h->ubG = pow2_at_least(std::max(avgA, maxRowA / 32.0), 1, 64);
     int L = pow2_at_least(avgB, 1, 64);
     int lg = 0;
@@ -1266,6 +1302,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "lane_first")) { h->laneFirst = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }

@@ -166,6 +166,9 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
  *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
  *                     nnz(B) < 2^29)
+ *   "lane_first"      1 (default): when every row of A has <= 12 entries and every row of B <= 64 (stencils), the
+ *                     upper-bound pass and its host round trip are skipped; the lane-per-row symbolic kernel handles
+ *                     every row and counts the products on the side
  *   "direct_bins"     1 (default): a stage whose rows ALL sit in the lane bin or the quad bin (stencils) skips the
  *                     queue-fill pass; the kernel derives row q's descriptor from rowPtrA / rowPtrC
  *   "sort_b"          1 (default): rows of B that are not ascending are sorted at bhs_set_data[_device] time (device

@@ -317,7 +317,10 @@ def test_direct_stages_without_queue(oracle, stencil, dims):
     r2 = _check(oracle, m, m, m, A, A, options={"lane_rows": 0})                  # symbolic and numeric both direct on the quad kernel
     r3 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 1})               # ... and both on the lane kernel
     r4 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 0})
-    for r in (r2, r3, r4):
+    assert "upper_bound" not in names                                              # lane-first: no upper-bound pass either
+    r5 = _check(oracle, m, m, m, A, A, options={"lane_first": 0})
+    assert "upper_bound" in {s["name"] for s in r5[3]["kernels"] if s["launches"]}
+    for r in (r2, r3, r4, r5):
         assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r[:3]))
 
 
