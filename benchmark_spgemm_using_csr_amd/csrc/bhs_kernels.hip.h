@@ -2196,10 +2196,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
 // banded matrices.  Needs strictly ascending B rows (checked at set_data time).
 //
 // Measured on MI355X (poisson5pt 1024^2 / poisson7pt 128^3 / poisson9pt 1024^2): the symbolic pass drops from
-// 0.081 / 0.476 / 0.273 ms (quarter-wave and wave kernels) to 0.030 / 0.12 / 0.10 ms.  The numeric pass gains only
-// while K <= 6 (poisson5pt: 0.187 -> 0.122 ms; 7pt and 9pt lose: two more loads per advancing head, 8 and 10 heads
-// in registers), and only with its stores staged through LDS (see S below); the host routes the numeric stage
-// here for K <= 6 (option "lane_numeric").
+// 0.081 / 0.476 / 0.273 ms (quarter-wave and wave kernels) to 0.030 / 0.12 / 0.10 ms.  The numeric pass gains
+// while K <= 8 (poisson5pt 0.187 -> 0.116 ms, 7pt 0.66 -> 0.51 ms; 9pt loses, 0.36 -> 0.42 ms: two more loads per
+// advancing head and 10 heads in registers), and only with its stores staged through LDS (see S below); the host
+// routes the numeric stage here for K <= 8 (option "lane_numeric").
 // ===========================================================================
 // SMALLB: nnz(B) < 2^29, so byte offsets into colIndB / valB fit 32 bits and the loads take the scalar base +
 // 32-bit lane offset form: no 64-bit address pair per head.

@@ -149,7 +149,7 @@ struct bhs_handle {
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
-    int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 6 (where it wins)
+    int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 8 (where it wins)
     int maxRowA = 0;
     // compressed pattern of B for the symbolic pass (k_compress_b): 0 never (default), 1 when the data has <= 60 %
     // as many (block, mask) pairs as entries, 2 always (needs sorted B rows either way).  Off by default: on
@@ -655,7 +655,7 @@ int run_pipeline(bhs_handle* h)
         laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
     const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK);
     const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
-                                      (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 6)) ? laneK : 0);
+                                      (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 8)) ? laneK : 0);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     h->cmpActive = false;

@@ -178,7 +178,7 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     registers) for rows with <= 12 entries and <= 144 products: 0 never, 1 (default) when EVERY row of
  *                     A has <= 12 entries (stencils), 2 for any matrix.  Needs B with strictly ascending rows.
  *   "lane_numeric"    the numeric stage of those rows goes through k_row_lane as well: 0 never, 1 always, 2 (default)
- *                     when no row of A has more than 6 entries (poisson5pt; measured slower beyond)
+ *                     when no row of A has more than 8 entries (poisson5pt, 7pt; measured slower beyond)
  *   "compress_b"      symbolic pass on the compressed pattern of B ((column >> 5, mask) pairs; rows binned by their
  *                     pair count): 0 never (default: measured break-even at best on MI355X), 1 when the data has
  *                     <= 60 % as many pairs as entries, 2 always.  Only for B with ascending rows.  Set it before

@@ -307,7 +307,7 @@ def test_direct_stages_without_queue(oracle, stencil, dims):
     A = (rp, col, val)
     r1 = _check(oracle, m, m, m, A, A)
     names = {s["name"] for s in r1[3]["kernels"] if s["launches"]}
-    numk = "numeric_lane" if stencil == "poisson5pt" else "numeric_quad<64>"      # lane numeric only while K <= 6
+    numk = "numeric_quad<64>" if stencil == "poisson9pt" else "numeric_lane"      # lane numeric only while K <= 8
     assert "fill_queues" not in names and "symbolic_lane" in names and numk in names, names
     rows = {s["name"]: (s["rows"], s["products"], s["nnz_out"]) for s in r1[3]["kernels"]}
     assert rows[numk] == (m, r1[3]["nnzCt"], r1[3]["nnzC"])
