@@ -1302,8 +1302,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     const int4* __restrict__ desc, int qn, int chunkLog2,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx,
+    const int* __restrict__ Ap, int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots)
 {
+    // desc == nullptr ("wave-first" symbolic pass: maxRow(A) x maxRow(B) fits this table for EVERY row, so no
+    // upper-bound pass ran and no queue exists): queue entry q is row q, its descriptor comes from rowPtrA, and the
+    // row's product count goes to ubOut[row] and into one of 64 spread counters (ctSlots), which is all the
+    // upper-bound pass would have delivered.
     // measurement-only ablation mask, compile time (tools/build_variants.sh builds variants with -DBHS_ABL=..):
     // 1 no value atomics, 2 no sort, 4 no inserts, 8 no stores, 16 no colIndB load, 32 no valB load, 64 no sAv read
     constexpr int abl = NUM ? BHS_ABL : BHS_ABL_SYM;
@@ -1344,10 +1349,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     asm volatile("" : "+v"(vzero));
     auto load_desc = [&](int it_) {
         const bool has = it_ < nIt;
-        int4 r = desc[q_of(has ? it_ : 0) + vzero];
+        int4 r;
+        if (desc) r = desc[q_of(has ? it_ : 0) + vzero];
+        else {
+            const int q = q_of(has ? it_ : 0) + vzero;
+            int2 aa;
+            __builtin_memcpy(&aa, Ap + q, 8);
+            r = make_int4(q, aa.x, aa.y, 0);
+        }
         if (!has) r = make_int4(-1, 0, 0, 0);
         return r;
     };
+    unsigned long long prodSum = 0;                       // wave-first: products of this wave's rows
 
     // ---- software pipeline over rows: descriptor (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
     if (nIt == 0) return;                                // (wave-uniform; there is no barrier in this kernel)
@@ -1395,6 +1408,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
         }
         int myNew = 0;
+        int rowProducts = 0;
         // Rows with more than 64 A entries (power-law matrices: hundreds of short B rows per row) walk them in
         // chunks of 64.  In the larger-table instantiations, where such rows live, the chunks are pipelined
         // like the rows are: the B extents of chunk i+1 and the A entries of chunk i+2 are in flight while
@@ -1440,6 +1454,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             }
             const int incl = wave_incl_scan_dpp(len);
             const int total = __builtin_amdgcn_readlane(incl, 63);
+            rowProducts += total;
             const int last = incl - 1;                      // flat index of this entry's last product
             const unsigned long long nz = __ballot(len > 0);
             const int jc = mbcnt64(nz);                      // compacted index among non-empty entries
@@ -1601,6 +1616,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         if (!NUM) {
             myNew = wave_sum_dpp(myNew);
             if (lane == 0) cntOut[row] = myNew;
+            if (ubOut) {
+                if (lane == 0) ubOut[row] = rowProducts;
+                prodSum += (unsigned long long)rowProducts;
+            }
         } else {
             const long long outBase = outW;
             // ---- compact occupied slots -> packed sort keys
@@ -1667,6 +1686,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         wave_sync();
         BHS_TICK(5);
     }
+    if (!NUM && ubOut && lane == 0 && prodSum) atomicAdd(&ctSlots[blockIdx.x & 63], prodSum);
 #if BHS_PHASES
     if (NUM && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);

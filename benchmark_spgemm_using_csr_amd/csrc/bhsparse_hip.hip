@@ -144,6 +144,8 @@ struct bhs_handle {
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
     bool binsForked = false;
     int allowSmallB = 1;
+    int waveFirst = 1;                   // same idea for rows bounded by maxRow(A) x maxRow(B) <= a wave table
+    double avgRowA = 1.0, avgRowB = 1.0;
     int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
     int maxRowB = 0;
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
@@ -361,8 +363,11 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     // XCD chunk: BHS_XCD_CHUNK entries for long queues; short queues get >= 8 chunks per XCD
     int chunkLog2 = 0;
     while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
+    const bool wf = !NUM && queue == nullptr;             // wave-first symbolic pass: rows straight from rowPtrA
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj, h->dAx,
-                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
+                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p, h->dAp,
+                       wf ? (int*)h->ub.p : (int*)nullptr,
+                       wf ? (unsigned long long*)((int*)h->small.p + S_CT_SLOTS) : (unsigned long long*)nullptr);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -680,15 +685,26 @@ int run_pipeline(bhs_handle* h)
     // upper-bound pass, its host round trip and the symbolic queue all disappear; the lane kernel writes ub[] and
     // the product total on the side.
     const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64;
+    // "Wave-first": maxRow(A) x maxRow(B) bounds every row's product count; when that bound fits a wave-per-row
+    // table and is not far above the average row (stencils, FEM meshes: poisson27pt 27 x 27 = 729 for every interior
+    // row), every row can run the symbolic wave kernel of that one table size -- again without upper-bound pass,
+    // host round trip or queue; the kernel delivers ub[] and the product total.
+    int wfBin = 0;
+    if (!laneFirst && h->waveFirst && h->directBins && !cmpRun && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+        const long long bound = (long long)h->maxRowA * h->maxRowB;
+        if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
+            for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
+    }
+    const bool noUpperBound = laneFirst || wfBin > 0;
     int symCount[kMaxBins], symStart[kMaxBins + 1];
-    if (laneFirst) {
+    if (noUpperBound) {
         BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
         for (int b = 0; b < kMaxBins; ++b) { symCount[b] = 0; symStart[b] = 0; }
         symStart[kMaxBins] = 0;
-        symCount[kLaneBin] = m;
+        symCount[laneFirst ? kLaneBin : wfBin] = m;
     }
-    bool symDirect = laneFirst;
-    if (!laneFirst) {
+    bool symDirect = noUpperBound;
+    if (!noUpperBound) {
     BHS_TRY(timed_begin(h, "upper_bound", &ep));
     BHS_TRY(launch_upper_bound(h, symSpec, cmpBins, symSpec.upper[8]));
     BHS_TRY(timed_end(h, ep));
@@ -730,7 +746,7 @@ int run_pipeline(bhs_handle* h)
         h->stats[ep->stat].launches++;
     }
     }
-    }   // !laneFirst
+    }   // !noUpperBound
     const int4* symQueue = symDirect ? nullptr : (const int4*)h->queue.p;
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
 
@@ -777,7 +793,7 @@ int run_pipeline(bhs_handle* h)
     h->stats[ep->stat].launches += 3;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
-    if (laneFirst) {                                     // product count: the lane kernel's 64 partial sums
+    if (noUpperBound) {                                  // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
         for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
         h->nnzCt = (long long)t;
@@ -937,6 +953,8 @@ int finish_set_data(bhs_handle* h)
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
     h->maxRowA = maxRowA;
+    h->avgRowA = avgA;
+    h->avgRowB = avgB;
     h->maxRowB = 0;
     if (h->k > 0) {
         int* small0 = (int*)h->small.p;
@@ -1302,6 +1320,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "wave_first")) { h->waveFirst = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_first")) { h->laneFirst = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }

@@ -169,6 +169,9 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "lane_first"      1 (default): when every row of A has <= 12 entries and every row of B <= 64 (stencils), the
  *                     upper-bound pass and its host round trip are skipped; the lane-per-row symbolic kernel handles
  *                     every row and counts the products on the side
+ *   "wave_first"      1 (default): when maxRow(A) x maxRow(B) fits a wave-per-row table and is within 4x of the average
+ *                     row's product count (poisson27pt: 27 x 27), every row runs the symbolic wave kernel of that table
+ *                     size straight from rowPtrA -- no upper-bound pass, host round trip or queue
  *   "direct_bins"     1 (default): a stage whose rows ALL sit in the lane bin or the quad bin (stencils) skips the
  *                     queue-fill pass; the kernel derives row q's descriptor from rowPtrA / rowPtrC
  *   "sort_b"          1 (default): rows of B that are not ascending are sorted at bhs_set_data[_device] time (device

@@ -318,10 +318,46 @@ def test_direct_stages_without_queue(oracle, stencil, dims):
     r3 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 1})               # ... and both on the lane kernel
     r4 = _check(oracle, m, m, m, A, A, options={"lane_numeric": 0})
     assert "upper_bound" not in names                                              # lane-first: no upper-bound pass either
-    r5 = _check(oracle, m, m, m, A, A, options={"lane_first": 0})
+    r5 = _check(oracle, m, m, m, A, A, options={"lane_first": 0, "wave_first": 0})
     assert "upper_bound" in {s["name"] for s in r5[3]["kernels"] if s["launches"]}
-    for r in (r2, r3, r4, r5):
+    r6 = _check(oracle, m, m, m, A, A, options={"lane_first": 0})                  # falls to the wave-first symbolic pass
+    n6 = {s["name"] for s in r6[3]["kernels"] if s["launches"]}
+    assert "upper_bound" not in n6 and any(x.startswith("symbolic_wave") for x in n6), n6
+    for r in (r2, r3, r4, r5, r6):
         assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r[:3]))
+
+
+def test_wave_first_symbolic_pass(oracle):
+    """maxRow(A) x maxRow(B) fits a wave table (poisson27pt: 729 <= 768): no upper-bound pass, no symbolic queue;
+    the symbolic kernel supplies ub[] and the product total.  Rows with > 64 entries in A, empty rows and a bound
+    that does not fit must all still agree with the plain pipeline."""
+    rng = np.random.default_rng(3)
+    m, rp, col, val = poisson_case("poisson27pt", 9, 8, 10)
+    A = (rp, col, val)
+    r1 = _check(oracle, m, m, m, A, A)
+    n1 = {s["name"]: s for s in r1[3]["kernels"] if s["launches"]}
+    assert "upper_bound" not in n1 and "symbolic_wave<1024>" in n1, sorted(n1)
+    assert n1["symbolic_wave<1024>"]["rows"] == m and n1["symbolic_wave<1024>"]["products"] == r1[3]["nnzCt"]
+    r0 = _check(oracle, m, m, m, A, A, options={"wave_first": 0})
+    assert "upper_bound" in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
+    assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
+    # A rows of up to 100 entries (chunk loop), B rows of <= 20: bound 2000 -> the 4096-slot table
+    mm, kk, nn = 300, 400, 3000
+    A2 = random_csr(mm, kk, 0.2, rng, empty_rows=(0, 17, 299), max_row=100)
+    B2 = random_csr(kk, nn, 0.005, rng, empty_rows=(3,), max_row=20)
+    a1 = _check(oracle, mm, kk, nn, A2, B2)
+    a0 = _check(oracle, mm, kk, nn, A2, B2, options={"wave_first": 0})
+    assert "upper_bound" not in {s["name"] for s in a1[3]["kernels"] if s["launches"]}
+    assert all(np.array_equal(x, y) for x, y in zip(a0[:3], a1[:3]))
+    # one long row of A breaks the bound: plain pipeline
+    A3 = random_csr(mm, kk, 0.05, rng)
+    A3[1][:] = np.sort(A3[1].reshape(-1)) if False else A3[1]
+    lens = np.diff(A3[0]); lens[5] = 390
+    rp3 = np.zeros(mm + 1, np.int32); np.cumsum(lens, out=rp3[1:])
+    col3 = np.concatenate([np.sort(rng.choice(kk, L, replace=False)) for L in lens]).astype(np.int32)
+    A3 = (rp3, col3, rng.integers(1, 10, len(col3)).astype(np.float64))
+    b1 = _check(oracle, mm, kk, nn, A3, B2)
+    assert "upper_bound" in {s["name"] for s in b1[3]["kernels"] if s["launches"]}
 
 
 def test_sort_key_width_paths(oracle):
