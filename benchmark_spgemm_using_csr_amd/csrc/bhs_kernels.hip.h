@@ -343,10 +343,13 @@ constexpr int kScanTile = 256 * kScanItems;     // per block
 __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restrict__ cnt,
                                                      const int* __restrict__ Ap,
                                                      long long* __restrict__ blockSum,
-                                                     int* __restrict__ binCount, BinSpec spec)
+                                                     int* __restrict__ binCount, BinSpec spec,
+                                                     int* __restrict__ maxCnt)
 {
     __shared__ int hist[kMaxBins];
     __shared__ long long wsum[4];
+    __shared__ int wmax[4];
+    int mx = 0;
     const int tid = threadIdx.x;
     if (tid < kMaxBins) hist[tid] = 0;
     __syncthreads();
@@ -358,15 +361,19 @@ __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restric
         if (idx < m) {
             const int v = cnt[idx];
             s += v;
+            mx = max(mx, v);
             const int b = bin_of(spec, v, Ap[idx + 1] - Ap[idx]);
             if (b > 0) atomicAdd(&hist[b], 1);
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
+    if ((tid & 63) == 0) { wsum[tid >> 6] = s; wmax[tid >> 6] = mx; }
     __syncthreads();
-    if (tid == 0) blockSum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) {
+        blockSum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        atomicMax(maxCnt, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));   // longest row of C (numeric-first test)
+    }
     if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
 }
 
@@ -1355,7 +1362,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
             const int q = q_of(has ? it_ : 0) + vzero;
             int2 aa;
             __builtin_memcpy(&aa, Ap + q, 8);
-            r = make_int4(q, aa.x, aa.y, 0);
+            r = make_int4(q, aa.x, aa.y, NUM ? cntOut[q] : 0);    // (numeric pass: cntOut is rowPtrC)
         }
         if (!has) r = make_int4(-1, 0, 0, 0);
         return r;

@@ -187,7 +187,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_PAIRS = 102 /* 2 ints = u64: (block, mask) pairs of the compressed B */,
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
-       S_ZERO_END = 104 + 192,   /* everything below is zeroed at the start of every spgemm */
+       S_MAXCNT = 104 + 192 /* longest row of C */,
+       S_ZERO_END = 104 + 194,   /* everything below is zeroed at the start of every spgemm */
        S_SORTED = 300, S_MAXROW = 301,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
@@ -783,7 +784,7 @@ int run_pipeline(bhs_handle* h)
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
-                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec);
+                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
                        (long long*)h->blockSum.p, (long long*)(small + S_TOTAL_C));
     hipLaunchKernelGGL(k_scan_apply, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (int*)h->Cp.p,
@@ -811,7 +812,21 @@ int run_pipeline(bhs_handle* h)
     }
     BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
     BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
-    const bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
+    // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
+    // queue, and the few short boundary rows no longer pay for kernels of their own.
+    if (!numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+        const int maxCnt = hs[S_MAXCNT];
+        int nb = 0;
+        for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
+        if (nb && maxCnt > 0 && (double)nnzC / m * 4.0 >= (double)numSpec.upper[nb]) {
+            for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
+            numStart[kMaxBins] = 0;
+            numCount[nb] = m;
+            numDirect = true;
+        }
+    }
     if (!numDirect) {
     memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
     BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
