@@ -1323,7 +1323,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     using packed_t = typename Smem::packed_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int WPB = kWavesPerBlock;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index is wave-uniform by construction: saying so (readfirstlane) moves the whole queue-index arithmetic
+    // of the row pipeline to the scalar unit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Smem& sm = reinterpret_cast<Smem*>(smem_raw)[wave];
     constexpr int MAXB = NUM ? kMaxBNum : kMaxBSym;
     constexpr int GRP = (MAXB % 4 == 0) ? 4 : (MAXB % 3 == 0 ? 3 : 2);                   // probes in flight per insert group
@@ -1401,6 +1403,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
         int2 be1 = make_int2(0, 0);
         if (lane < d1.z - d1.y) __builtin_memcpy(&be1, Bp + c1, 8);   // one 8-byte gather, consumed by the next row
 
+        // (making the descriptor fields scalars as well -- readfirstlane -- was measured SLOWER: the reads need a
+        // wait the compiler can only place conservatively, on top of the fresh prefetches)
         const int row = dC.x, a0 = dC.y, a1 = dC.z;
         // ---- clear the table
 #pragma unroll
@@ -2059,7 +2063,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int WPB = kWavesPerBlock;
     constexpr int MAXB = kMaxBCsym, GRP = 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Smem& sm = reinterpret_cast<Smem*>(smem_raw)[wave];
     const unsigned long long* __restrict__ cPair64 = reinterpret_cast<const unsigned long long*>(cPair);
 
