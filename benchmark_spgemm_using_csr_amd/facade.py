@@ -105,6 +105,13 @@ class bhsparse(object):
         self._m = m
         self._rowptrC = None
         self._keep = (d_valA, d_rowPtrA, d_colIndA, d_valB, d_rowPtrB, d_colIndB)
+        # The library reads these arrays on ITS stream, starting inside this call (row-length and sortedness
+        # scans).  torch tensors may still be being written by kernels queued on torch's stream: wait for them.
+        # (Without this a multiply could read half-written row pointers: observed as a memory fault or a hang
+        # when freshly generated inputs landed in recycled memory.)
+        if any(hasattr(t, "is_cuda") and t.is_cuda for t in self._keep):
+            import torch
+            torch.cuda.synchronize(self._keep[1].device if hasattr(self._keep[1], "device") else None)
         return self._lib.bhs_set_data_device(self._h, m, k, n, nnzA, _ptr(d_valA), _ptr(d_rowPtrA),
                                              _ptr(d_colIndA), nnzB, _ptr(d_valB), _ptr(d_rowPtrB),
                                              _ptr(d_colIndB))
@@ -170,6 +177,9 @@ class bhsparse(object):
         (ref_spgemm::csr_sort_indices, SpGEMM_cuda/ref_spgemm.h:37-62, on the GPU)."""
         if self._h is None:
             return _lib.BHS_ERR_NOT_READY
+        if any(hasattr(t, "is_cuda") and t.is_cuda for t in (d_rowPtr, d_colInd, d_val)):
+            import torch
+            torch.cuda.synchronize()                       # the library works on its own stream (see initData_device)
         return self._lib.bhs_csr_sort_indices_device(self._h, n_row, _ptr(d_rowPtr), _ptr(d_colInd), _ptr(d_val))
 
     def get_rowptrC(self, out=None):

@@ -82,7 +82,10 @@ BHS_API int bhs_set_data(bhs_handle *h, int m, int k, int n,
 /* Same, but the six arrays are DEVICE pointers on the handle's device (borrowed
  * until bhs_free_data; never written).  This is the entry the benchmark uses so
  * that inputs are HBM-resident when the timed region starts, and the entry a
- * multi-GPU host uses to hand each rank its row block of A with B replicated. */
+ * multi-GPU host uses to hand each rank its row block of A with B replicated.
+ * The library works on its own stream and starts reading the arrays inside this
+ * call: they must be COMPLETE (producer kernels / copies on other streams
+ * synchronised) before it is made, and stay unchanged until bhs_free_data.     */
 BHS_API int bhs_set_data_device(bhs_handle *h, int m, int k, int n,
                                 int nnzA, const bhs_value_t *d_valA, const int *d_rowPtrA, const int *d_colIndA,
                                 int nnzB, const bhs_value_t *d_valB, const int *d_rowPtrB, const int *d_colIndB);
