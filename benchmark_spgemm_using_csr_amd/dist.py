@@ -95,6 +95,12 @@ def allgatherv_csr(m_total, local_rowptr, local_col, local_val, group=None, out=
     _all_gatherv([(val, local_val[:nnz_local], nnzs, nnz_off), (col, local_col[:nnz_local], nnzs, nnz_off),
                   (rowptr, rebased, rows, row_off)], group)
     rowptr[m_total] = nnz_total
+    # On RCCL, Work.wait() only orders torch's current stream behind the transfers (and the local copy is an
+    # ordinary asynchronous kernel): the HOST goes on.  The blocks being sent live in the library's C buffers,
+    # which the next bhs_spgemm -- on the library's own stream -- overwrites, so everything queued here must be
+    # over before this function returns.
+    if col.is_cuda:
+        torch.cuda.current_stream(dev).synchronize()
     return rowptr, col, val, {"rows": rows, "nnz": nnzs}
 
 
