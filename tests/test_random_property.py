@@ -45,13 +45,27 @@ def test_oracle_matches_scipy_on_positive_values(oracle, seed, m, k, n, dA, dB, 
     assert oracle.nnzCt(Ap, Aj, Bp) == int(sum(Bp[j + 1] - Bp[j] for j in Aj))
 
 
+# option sets that route rows through the alternative kernels / pipeline shapes (include/bhsparse_hip.h)
+OPTION_SETS = [{}, {}, {"lane_rows": 2, "lane_numeric": 1}, {"lane_rows": 0}, {"compress_b": 2},
+               {"wave_first": 0, "lane_first": 0}, {"direct_bins": 0}, {"concurrent_bins": 1},
+               {"lane_rows": 2, "lane_numeric": 0, "small_b": 0}, {"sort_b": 0}]
+
+
 @pytest.mark.gpu
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
-@given(signed=st.booleans(), **CASE)
-def test_hip_matches_oracle(oracle, seed, m, k, n, dA, dB, skew, signed):
+@settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
+@given(signed=st.booleans(), opts=st.sampled_from(OPTION_SETS), shuffle_b=st.booleans(), tiny=st.booleans(), **CASE)
+def test_hip_matches_oracle(oracle, seed, m, k, n, dA, dB, skew, signed, opts, shuffle_b, tiny):
     from benchmark_spgemm_using_csr_amd.facade import spgemm_csr
+    if tiny:                                                    # rows of a few entries: lane-first / wave-first territory
+        dA, dB, skew = min(dA, 6.0 / max(k, 1)), min(dB, 8.0 / max(n, 1)), 0
     (Ap, Aj, Ax), (Bp, Bj, Bx) = _random_pair(seed, m, k, n, dA, dB, skew, signed)
-    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    if shuffle_b:                                               # unsorted rows of B (sorted by the library, or not: sort_b)
+        rng = np.random.default_rng(seed ^ 0x5bd1)
+        for j in range(k):
+            p = rng.permutation(Bp[j + 1] - Bp[j])
+            Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][p]
+            Bx[Bp[j]:Bp[j + 1]] = Bx[Bp[j]:Bp[j + 1]][p]
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=opts)
     ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
     res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)       # integer-valued inputs: bit-exact, zeros kept
     assert res["ok"], res
