@@ -1101,8 +1101,14 @@ __device__ __forceinline__ void wave_sync()
 #ifndef BHS_MAXB_NUM
 #define BHS_MAXB_NUM 6
 #endif
-constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM;
-constexpr int kMaxB = kMaxBSym > kMaxBNum ? kMaxBSym : kMaxBNum;   // sizes the LDS mark words
+constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = 12;
+constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // sizes the LDS mark words
+// Every window of a row costs one exposed memory round trip (~3 us on a loaded chip).  Rows of the 256-slot numeric
+// tables have two windows of 6 batches and live on occupancy (5 waves per SIMD); rows of the larger tables have
+// thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
+// and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
+constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
+constexpr int wave_min_waves(int TS, bool NUM) { return NUM && TS >= 512 ? 4 : 5; }
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
 // otherwise (col << 32 | slot) in 64 bits.
@@ -1305,7 +1311,7 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const acc_t
 
 // SMALLB: nnz(B) < 2^29, byte offsets into colIndB / valB fit 32 bits
 template <int TS, int LOG2TS, bool NUM, bool PACK32, bool SMALLB>
-__global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
+__global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void k_row_wave(
     const int4* __restrict__ desc, int qn, int chunkLog2,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
@@ -1327,7 +1333,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave(
     // of the row pipeline to the scalar unit
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     Smem& sm = reinterpret_cast<Smem*>(smem_raw)[wave];
-    constexpr int MAXB = NUM ? kMaxBNum : kMaxBSym;
+    constexpr int MAXB = wave_window_batches(TS, NUM);
     constexpr int GRP = (MAXB % 4 == 0) ? 4 : (MAXB % 3 == 0 ? 3 : 2);                   // probes in flight per insert group
 
     // XCD-aware persistent schedule (gridDim.x is a multiple of 8; block b runs on XCD b % 8, tools/xcc_probe.hip).

@@ -153,11 +153,13 @@ struct bhs_handle {
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
     int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 8 (where it wins)
     int maxRowA = 0;
-    // compressed pattern of B for the symbolic pass (k_compress_b): 0 never (default), 1 when the data has <= 60 %
-    // as many (block, mask) pairs as entries, 2 always (needs sorted B rows either way).  Off by default: on
-    // MI355X the symbolic wave kernel is bound by its per-row work, not by its products, and 2.8x fewer inserts
-    // buy back less than the compression pass costs (poisson27pt 160^3: 10.46 ms with, 10.34 ms without).
-    int compressB = 0;
+    // compressed pattern of B for the symbolic pass (k_compress_b): 0 never, 1 (default) when it moves rows out of
+    // the workgroup-per-row symbolic kernels -- the average row has more than 1536 products (beyond the 2048-slot
+    // wave table) and the data has <= 60 % as many (block, mask) pairs as entries --, 2 always (needs sorted B rows
+    // either way).  Where the plain pass already runs the wave kernels it does not pay: that kernel is bound by its
+    // per-row work, and 2.8x fewer inserts buy back less than the compression costs (poisson27pt 160^3: 10.46 ms
+    // with, 10.34 ms without).  A 3-dof FEM-like matrix (81 entries per row, 6561 products) goes from 12.5 to 5.9 ms.
+    int compressB = 1;
     int cmpState = 0;                    // per data set: 0 undecided, 1 pays, -1 does not
     bool cmpActive = false;              // this multiply's symbolic wave bins run on the compressed pattern
     DevBuf sortList, sortCnt, sortK, sortV;   // bhs_csr_sort_indices_device: long-row list, its counter, scratch keys / values
@@ -1023,7 +1025,8 @@ int finish_set_data(bhs_handle* h)
     }
     // compressed pattern of B: decide now whether it pays (the multiply itself re-runs the compression inside its
     // timed region; this pass only yields the pair count)
-    if (h->compressB == 1 && h->bSorted && h->nnzB > 0 && h->k > 0) {
+    if (h->compressB == 1 && (avgA * avgB <= 1536.0 || !h->bSorted)) h->cmpState = -1;
+    else if (h->compressB == 1 && h->nnzB > 0 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)h->k));
         BHS_TRY(ensure(h, h->cLen, sizeof(int2) * (size_t)h->k));

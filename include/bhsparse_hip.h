@@ -186,9 +186,10 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "lane_numeric"    the numeric stage of those rows goes through k_row_lane as well: 0 never, 1 always, 2 (default)
  *                     when no row of A has more than 8 entries (poisson5pt, 7pt; measured slower beyond)
  *   "compress_b"      symbolic pass on the compressed pattern of B ((column >> 5, mask) pairs; rows binned by their
- *                     pair count): 0 never (default: measured break-even at best on MI355X), 1 when the data has
- *                     <= 60 % as many pairs as entries, 2 always.  Only for B with ascending rows.  Set it before
- *                     bhs_set_data for mode 1 to be decided there.
+ *                     pair count): 0 never, 1 (default) when the average row has more than 1536 products and the data
+ *                     has <= 60 % as many pairs as entries (FEM-like inputs: keeps rows out of the workgroup-per-row
+ *                     symbolic kernels), 2 always.  Only for B with ascending rows.  Set it before bhs_set_data for
+ *                     mode 1 to be decided there.
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)

@@ -360,6 +360,29 @@ def test_wave_first_symbolic_pass(oracle):
     assert "upper_bound" in {s["name"] for s in b1[3]["kernels"] if s["launches"]}
 
 
+def test_compression_is_automatic_for_heavy_clustered_rows(oracle):
+    """3-dof FEM-like pattern (poisson27pt (x) ones(3,3): 81 entries per row, 6561 products, columns in runs of 3):
+    the default options compress B's pattern so that the symbolic pass stays in the wave kernels; poisson27pt itself
+    (729 products per row) must NOT be compressed."""
+    import scipy.sparse as sp
+    from benchmark_spgemm_using_csr_amd import gallery
+    rp, col = gallery.poisson_csr("poisson27pt", 6, 5, 6)
+    P = sp.csr_matrix((np.ones(len(col)), col, rp), shape=(len(rp) - 1,) * 2)
+    A3 = sp.kron(P, np.ones((3, 3)), format="csr")
+    A3.sort_indices()
+    m = A3.shape[0]
+    A = (A3.indptr.astype(np.int32), A3.indices.astype(np.int32), gallery.fill_values(A3.nnz))
+    r1 = _check(oracle, m, m, m, A, A)
+    n1 = {s["name"] for s in r1[3]["kernels"] if s["launches"]}
+    assert "compress_b" in n1 and not any(x.startswith("symbolic_wg") for x in n1), n1
+    r0 = _check(oracle, m, m, m, A, A, options={"compress_b": 0})
+    assert "compress_b" not in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
+    assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
+    mm, rp, col, val = poisson_case("poisson27pt", 7, 7, 7)
+    r2 = _check(oracle, mm, mm, mm, (rp, col, val), (rp, col, val))
+    assert "compress_b" not in {s["name"] for s in r2[3]["kernels"] if s["launches"]}
+
+
 def test_sort_key_width_paths(oracle):
     """32-bit packed sort keys vs the 64-bit fallback must agree (wave and quarter-wave kernels)."""
     m, rp, col, val = poisson_case("poisson27pt", 14, 14, 14)
