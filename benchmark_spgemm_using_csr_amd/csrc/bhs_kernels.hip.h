@@ -1101,14 +1101,20 @@ __device__ __forceinline__ void wave_sync()
 #ifndef BHS_MAXB_NUM
 #define BHS_MAXB_NUM 6
 #endif
-constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = 12;
+#ifndef BHS_MAXB_LONG
+#define BHS_MAXB_LONG 12
+#endif
+#ifndef BHS_LONG_WAVES
+#define BHS_LONG_WAVES 4
+#endif
+constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = BHS_MAXB_LONG;
 constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // sizes the LDS mark words
 // Every window of a row costs one exposed memory round trip (~3 us on a loaded chip).  Rows of the 256-slot numeric
 // tables have two windows of 6 batches and live on occupancy (5 waves per SIMD); rows of the larger tables have
 // thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
 // and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
 constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
-constexpr int wave_min_waves(int TS, bool NUM) { return NUM && TS >= 512 ? 4 : 5; }
+constexpr int wave_min_waves(int TS, bool NUM) { return !NUM || TS < 512 ? 5 : (TS >= 1024 ? 3 : BHS_LONG_WAVES); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
 // otherwise (col << 32 | slot) in 64 bits.
