@@ -1072,6 +1072,9 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
 #ifndef BHS_DEFER_MUL
 #define BHS_DEFER_MUL 1
 #endif
+#ifndef BHS_UNIFORM
+#define BHS_UNIFORM 1
+#endif
 // ask the register allocator for >= 5 waves per SIMD (<= 96 VGPRs).  With the deferred multiply the window
 // holds 6 x (col, valB, av) in registers; 6 waves (80 VGPRs) spill, measured 3.80 vs 3.49 ms.
 #ifndef BHS_WAVE_ATTR
@@ -1127,6 +1130,7 @@ struct WaveSmem {
     value_t sAv[NUM ? 64 : 1];
     int sBase[64];
     alignas(8) unsigned marks[2 * kMaxB];   // read as 64-bit words
+    unsigned magic[BHS_UNIFORM ? 64 : 1];   // ceil(2^32 / L), L = 1..64: product index -> A entry when all B rows have L entries
 };
 
 template <typename T>
@@ -1385,6 +1389,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
 
     // ---- software pipeline over rows: descriptor (i+3) -> A entries (i+2) -> B extents (i+1) -> work (i)
     if (nIt == 0) return;                                // (wave-uniform; there is no barrier in this kernel)
+    if (BHS_UNIFORM && NUM && TS <= 256) sm.magic[lane] = 0xffffffffu / (unsigned)(lane + 1) + 1u;
     int4 dC = load_desc(0);
     int4 d1 = load_desc(1);
     int4 d2 = load_desc(2);
@@ -1487,13 +1492,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                 if (NUM) sm.sAv[jc] = av;
             }
             int done = 0;                                    // entries completed before the window
+            // Uniform chunk (BHS_UNIFORM): every B row it touches has the same number L of entries (stencil
+            // interiors, block matrices).  Product p then belongs to entry p / L -- one v_mul_hi with
+            // ceil(2^32 / L), exact for p * L < 2^32 -- and the mark words, their two LDS round trips per window
+            // and the mbcnt / popcount per batch are not needed.  Numeric pass only: same-box A/B on poisson27pt 128^3,
+            // three runs each: numeric 3.33 -> 3.26 ms, symbolic 1.385 -> 1.40 ms (the branch costs it more than the
+            // marks did).
+            const int L0 = __builtin_amdgcn_readfirstlane(len);
+            const int nAc = a1 - ca < 64 ? a1 - ca : 64;
+            constexpr bool kUni = BHS_UNIFORM && NUM && TS <= 256;   // (compiled out of the large-table kernels: its branches cost the 12-batch windows 8 %)
+            const bool uni = kUni && L0 >= 2 && L0 <= 64 && __ballot(lane < nAc && len != L0) == 0ull;
+            unsigned magic = 0;
+            if (uni) { wave_sync(); magic = sm.magic[BHS_UNIFORM ? L0 - 1 : 0]; }
             BHS_TICK(0);
             for (int w0 = 0; w0 < total; w0 += 64 * MAXB) {
                 const int nb = (total - w0 + 63) >> 6;       // batches in this window (wave-uniform)
-                if (lane < 2 * MAXB) sm.marks[lane] = 0;
-                wave_sync();
-                const int rel = last - w0;
-                if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
+                if (!uni) {
+                    if (lane < 2 * MAXB) sm.marks[lane] = 0;
+                    wave_sync();
+                    const int rel = last - w0;
+                    if (len > 0 && rel >= 0 && rel < 64 * MAXB) atomicOr(&sm.marks[rel >> 5], 1u << (rel & 31));
+                }
                 wave_sync();
                 int col[MAXB];
                 acc_t pv[MAXB];
@@ -1514,10 +1533,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                     pv[u] = 0.0;
 #endif
                     if (u < nb) {
-                        const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
                         const int p = w0 + u * 64 + lane;
-                        const int j = cum + mbcnt64(mk);
-                        cum += __popcll(mk);
+                        int j;
+                        if (uni) j = (int)__umulhi((unsigned)p, magic);
+                        else {
+                            const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(&sm.marks[2 * u]);
+                            j = cum + mbcnt64(mk);
+                            cum += __popcll(mk);
+                        }
                         if (p < total) {
                             if constexpr (SMALLB && BHS_DEFER_MUL == 1 && !(NUM ? BHS_ABL : BHS_ABL_SYM)) {
                                 // nnz(B) < 2^29: byte offsets fit 32 bits, so the loads use SGPR base + 32-bit VGPR
