@@ -97,7 +97,9 @@ def main():
     bh = facade.bhsparse()
     err = bh.initPlatform(plats, device=local_rank)
     assert err == 0, facade._lib.strerror(err)
+    t_setup = time.perf_counter()
     err = bh.initData_device(r1 - r0, m, m, nnzA, Ax, Ap, Aj, nnzB, Bx, Bp, Bj)
+    setup_ms = (time.perf_counter() - t_setup) * 1e3     # bhs_set_data_device: row-length and sortedness scans (host-synchronous)
     assert err == 0, facade._lib.strerror(err)
 
     gather_out = [None]
@@ -128,10 +130,12 @@ def main():
     kstats = {}
     stage = np.zeros(4)
     t_compute = 0.0
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tc = time.perf_counter()
         full = step()
+        step_ms.append((time.perf_counter() - tc) * 1e3)
         for s in bh.kernel_stats():
             d = kstats.setdefault(s["name"], {"ms": 0.0, "launches": 0, "rows": 0, "products": 0, "nnz_out": 0,
                                               "nnzA_rows": 0, "steps": 0})
@@ -140,7 +144,6 @@ def main():
                 d[kk] = s[kk]
         stage += np.array(bh.stage_ms)
         t_compute += bh.time_ms
-        del tc
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -187,17 +190,23 @@ def main():
         else:
             alg = 4 * nnzA + 8 * (r1 - r0) + 4 * (m + 1)
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes (tools/prof.sh -> tools/hbm_traffic.py): used only when the
+        # file was produced by THIS build of the device sources, otherwise null (a stale constant is worse than none)
+        traffic, traffic_build = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.workload if world == 1 else "", {}).get(kname)
+                tj = json.load(open(tf))
+                traffic_build = tj.get("build")
+                if traffic_build == facade._lib.source_digest():
+                    traffic = tj.get(args.workload if world == 1 else "", {}).get(kname)
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 5),
-                "launches_timed": ks["launches"]}
+                "launches_timed": ks["launches"], "build": facade._lib.source_digest(),
+                "traffic_from_build": traffic_build}
     # whole-pipeline compulsory-bytes model: read A, read B, write C once
     bytes_alg_total = (4 * (r1 - r0 + 1) + 12 * nnzA) + (4 * (m + 1) + 12 * nnzB) + (4 * (r1 - r0 + 1) + 12 * bh.nnzC)
     pipeline_frac = bytes_alg_total / (np.sum(stage) / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -245,6 +254,28 @@ def main():
         if not chk["ok"]:
             cpu["mismatch"] = chk
 
+    # ---- second headline: the same multiply with every launch shortcut that rests on per-dataset row bounds
+    # switched off (no lane-first / wave-first / numeric-first: upper-bound pass, host round trip and queues as for
+    # an arbitrary matrix).  The shortcuts are verified on the device inside the timed multiply (a refuted bound
+    # re-runs the general pipeline), but their choice comes from bhs_set_data's scans -- `setup_ms` -- so both
+    # figures are printed.
+    general = None
+    if world == 1:
+        for key in ("wave_first", "lane_first", "direct_bins"):
+            assert bh.set_option(key, 0) == 0
+        for _ in range(2):
+            assert bh.spgemm() == 0
+        torch.cuda.synchronize()
+        tg = []
+        for _ in range(max(3, args.steps // 2)):
+            tq = time.perf_counter()
+            assert bh.spgemm() == 0
+            tg.append((time.perf_counter() - tq) * 1e3)
+        general = {"options": "wave_first=0 lane_first=0 direct_bins=0", "ms_median": round(float(np.median(tg)), 4),
+                   "ms_min": round(float(np.min(tg)), 4), "gflops_median": round(2.0 * bh.nnzCt / (float(np.median(tg)) * 1e6), 2)}
+        for key in ("wave_first", "lane_first", "direct_bins"):
+            assert bh.set_option(key, 1) == 0
+
     # ---- the other single-GPU configurations of BASELINE.json, short runs, reported beside the headline
     extra = None
     if world == 1 and not args.no_extra and args.workload == "p27_weak":
@@ -283,6 +314,8 @@ def main():
                    "m": m, "nnzA_total": nnzB, "nnzCt": nnzCt_total, "nnzC": nnzC_total,
                    "parallelism": "rowblock%d+allgatherv" % world if world > 1 else "single",
                    "values": "1+lcg%9 seed 20140519", "gather_in_step": bool((world > 1 or force_gather) and not args.no_gather)},
+        "ms_min": round(float(np.min(step_ms)), 4), "ms_median": round(float(np.median(step_ms)), 4),
+        "setup_ms": round(setup_ms, 4), "general_path": general,
         "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
         "stage_ms": [round(float(x) / args.steps, 4) for x in stage],

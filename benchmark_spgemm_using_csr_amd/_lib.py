@@ -58,9 +58,24 @@ _lib = None
 _libs = {}
 
 
+SOURCES = ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_rank.hip.h", "bhs_wave.hip.h", "bhs_dist.hip.h")
+
+
+def source_digest():
+    """Short hash of the device sources: keys measurements (profiles/hbm_traffic.json) to the build they came from."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in SOURCES:
+        path = os.path.join(CSRC, f)
+        if os.path.exists(path):
+            hsh.update(f.encode())
+            hsh.update(open(path, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile libbhsparse_hip.so and libbhsparse_hip_f32.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_wave.hip.h")] + [HEADER]
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))] + [HEADER]
     outs = [os.path.join(CSRC, "libbhsparse_hip.so"), SO_PATH_F32]
     stale = any(not os.path.exists(o) or any(os.path.getmtime(s) > os.path.getmtime(o) for s in srcs) for o in outs)
     if force or stale:

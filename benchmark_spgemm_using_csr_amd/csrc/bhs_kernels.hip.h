@@ -429,32 +429,39 @@ __global__ __launch_bounds__(256) void k_scan_apply(int m, int* __restrict__ cnt
     }
 }
 
-// longest row of a CSR matrix (chooses the lanes-per-row of k_upper_bound for skewed inputs)
+// longest row of a CSR matrix (chooses the lanes-per-row of k_upper_bound for skewed inputs).  One same-address
+// atomic per BLOCK: with one per wave (8192 of them on a 2 M-row matrix) the kernel took 98 us for 8 MB, all of
+// it atomics queueing on one L2 word.
 __global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ Ap, int* __restrict__ out)
 {
+    __shared__ int wmax[4];
     int mx = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256)
         mx = max(mx, Ap[i + 1] - Ap[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (mx) atomicMax(out, mx);
+    }
 }
 
-// B-row sortedness check (reference precondition for EM_mergepath,
-// bhsparse_cuda.h:1902ff; here only the column-window path relies on it).
-__global__ __launch_bounds__(256) void k_check_sorted(int k, const int* __restrict__ Bp,
+// B-row sortedness check (reference precondition for EM_mergepath, bhsparse_cuda.h:1902ff; here the lane kernels,
+// the compressed symbolic pass and the column-window path rely on strictly ascending rows).  G = 2^logG lanes per
+// row walk it with coalesced loads; neighbours are compared inside a row only, so no search for row boundaries
+// (the element-parallel version with a binary search at every row end took 0.93 ms on poisson27pt 128^3).
+__global__ __launch_bounds__(256) void k_check_sorted(int k, int logG, const int* __restrict__ Bp,
                                                       const int* __restrict__ Bj, int* __restrict__ flag)
 {
-    const long long nnz = Bp[k];
+    const int G = 1 << logG, g = threadIdx.x & (G - 1), rpb = 256 >> logG;
     int bad = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i + 1 < nnz; i += (long long)gridDim.x * 256)
-        if (Bj[i] >= Bj[i + 1]) {
-            // unsorted only if i and i+1 are in the same row: find via binary search of i+1 in Bp
-            int lo = 0, hi = k;                     // largest r with Bp[r] <= i+1
-            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (Bp[mid] <= i + 1) lo = mid; else hi = mid - 1; }
-            if (Bp[lo] != i + 1) bad = 1;           // i+1 is not the first entry of its row
-        }
-    if (bad) atomicOr(flag, 1);
+    for (long long r = (long long)blockIdx.x * rpb + (threadIdx.x >> logG); r < k; r += (long long)gridDim.x * rpb) {
+        const int a0 = Bp[r], a1 = Bp[r + 1];
+        for (int e = a0 + g; e + 1 < a1; e += G) bad |= Bj[e] >= Bj[e + 1] ? 1 : 0;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -838,7 +845,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
                 const int pos = __hip_atomic_load(&rank[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                                 __popc(word & ((1u << (c & 31)) - 1u));
                 if (BHS_ABL & 1024) { if (pos < 0) Cx[base] = sAv[l] * Bx[idx]; }
-                else unsafeAtomicAdd(&Cx[base + pos], (value_t)(sAv[l] * Bx[idx]));
+                else unsafeAtomicAdd(&Cx[base + pos], (value_t)((acc_t)sAv[l] * (acc_t)Bx[idx]));
             });
             __syncthreads();
             BHS_TICK_SPA(11);
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                     const unsigned mask = t < k ? 0xffffffffu : (t == k ? (1u << (c & 31)) - 1u : 0u);
                     pos += __popc(g[t] & mask);
                 }
-                const value_t v = Ax[e] * Bx[idx];
+                const value_t v = (value_t)((acc_t)Ax[e] * (acc_t)Bx[idx]);   // product formed in acc_t, narrowed once
                 if ((dup[c >> 9] >> ((c >> 4) & 31)) & 1u) unsafeAtomicAdd(&Cx[base + pos], v);
                 else Cx[base + pos] = v;                       // the only product of this column
             });
@@ -1326,7 +1333,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx,
-    const int* __restrict__ Ap, int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots)
+    const int* __restrict__ Ap, int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots,
+    int* __restrict__ errFlag)
 {
     // desc == nullptr ("wave-first" symbolic pass: maxRow(A) x maxRow(B) fits this table for EVERY row, so no
     // upper-bound pass ran and no queue exists): queue entry q is row q, its descriptor comes from rowPtrA, and the
@@ -1615,12 +1623,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                                 }
 #endif
                                 if (!ok) {                           // collision: linear probing
+                                    // bounded: the host's binning keeps every table under 75 % full, but borrowed
+                                    // arrays may change under us -- a full table must end in S_ERR, not in a hang
                                     unsigned h = hh[v];
+                                    int left = TS;
                                     for (;;) {
                                         h = (h + 1) & (TS - 1);
                                         const int c2 = atomicCAS(&sm.keys[h], kEmpty, cv);
                                         if (c2 == kEmpty) { ++myNew; break; }
                                         if (c2 == cv) break;
+                                        if (--left == 0) { atomicOr(errFlag, 1); break; }
                                     }
                                     hh[v] = h;
                                 }
@@ -1663,7 +1675,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
             myNew = wave_sum_dpp(myNew);
             if (lane == 0) cntOut[row] = myNew;
             if (ubOut) {
-                if (lane == 0) ubOut[row] = rowProducts;
+                // wave-first: the host launched this table size on the strength of the row bounds it saw at
+                // bhs_set_data time; the multiply itself checks them -- a row that could have overfilled the table
+                // raises bit 1 of the error word and the host repeats the multiply through the general pipeline
+                if (lane == 0) { ubOut[row] = rowProducts; if (rowProducts > TS - TS / 4) atomicOr(errFlag, 2); }
                 prodSum += (unsigned long long)rowProducts;
             }
         } else {
@@ -1767,7 +1782,7 @@ __global__ __launch_bounds__(64) void k_row_quad(
     const int4* __restrict__ desc, int qn, const int* __restrict__ Ap,
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx)
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ errFlag)
 {
     using Smem = QuadSmem<NUM, PACK32>;
     using packed_t = typename Smem::packed_t;
@@ -1896,11 +1911,13 @@ __global__ __launch_bounds__(64) void k_row_quad(
                     if (cur[u] == kEmpty) { ++myNew; ok = true; }
                     if (!ok) {
                         unsigned h = hh[u];
+                        int left = TS;                        // bounded probing (see k_row_wave)
                         for (;;) {
                             h = (h + 1) & (TS - 1);
                             const int c2 = atomicCAS(&sm.keys[g][h], kEmpty, cv);
                             if (c2 == kEmpty) { ++myNew; break; }
                             if (c2 == cv) break;
+                            if (--left == 0) { atomicOr(errFlag, 1); break; }
                         }
                         hh[u] = h;
                     }
@@ -2092,7 +2109,8 @@ struct CsymSmem {
 template <int TS, int LOG2TS>
 __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_csym(
     const int4* __restrict__ desc, int qn, int chunkLog2, const int* __restrict__ Aj,
-    const int2* __restrict__ cExt, const int2* __restrict__ cPair, int* __restrict__ cntOut)
+    const int2* __restrict__ cExt, const int2* __restrict__ cPair, int* __restrict__ cntOut,
+    int* __restrict__ errFlag)
 {
     using Smem = CsymSmem<TS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2210,10 +2228,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
                             if (cv != kEmpty) {
                                 if (cur[v] != kEmpty && cur[v] != cv) {        // collision: linear probing
                                     unsigned h = hh[v];
+                                    int left = TS;             // bounded probing (see k_row_wave)
                                     for (;;) {
                                         h = (h + 1) & (TS - 1);
                                         const int c2 = atomicCAS(&sm.keys[h], kEmpty, cv);
                                         if (c2 == kEmpty || c2 == cv) break;
+                                        if (--left == 0) { atomicOr(errFlag, 1); break; }
                                     }
                                     hh[v] = h;
                                 }
@@ -2283,7 +2303,8 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
                                                   const int* __restrict__ Bp, const int* __restrict__ Bj,
                                                   const value_t* __restrict__ Bx, int* __restrict__ cntOut,
                                                   int* __restrict__ Cj, value_t* __restrict__ Cx,
-                                                  int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots)
+                                                  int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots,
+                                                  int* __restrict__ errFlag)
 {
     // ubOut != nullptr (symbolic pass of a "lane-first" multiply, where no upper-bound pass ran): the row's product
     // count is written to ubOut and added into one of 64 counters (ctSlots; the host sums them)
@@ -2306,6 +2327,9 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
     int4 d = make_int4(0, 0, 0, 0);
     if (more) d = desc ? desc[q] : make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);
     const int row = d.x, a0 = d.y, nA = d.z - d.y;
+    // lane-first / direct launches rest on the longest row of A seen at bhs_set_data time: verified here (bit 1 of the
+    // error word sends the host back through the general pipeline)
+    if (!desc && more && nA > K) atomicOr(errFlag, 2);
     auto ld_col = [&](int p) {
         if constexpr (SMALLB) return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(Bj) + ((unsigned)p << 2));
         else return Bj[p];

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 using namespace bhs;
@@ -148,6 +149,7 @@ struct bhs_handle {
     double avgRowA = 1.0, avgRowB = 1.0;
     int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
     int maxRowB = 0;
+    bool specFailed = false;             // a lane-first / wave-first launch met a row beyond the bounds seen at set_data time
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
@@ -178,6 +180,10 @@ struct bhs_handle {
     size_t evUsed = 0;
     std::vector<StatRec> stats;
     double stageMs[4] = {0, 0, 0, 0};
+    // per-handle (hence per-device) launch cache: resident workgroups per CU of every kernel instantiation, filled
+    // by kernel_occupancy(), which also raises the dynamic-LDS limit of kernels that need more than 48 KB.  Both
+    // are properties of (kernel, device): a process-wide static would hand a second device the first one's answers.
+    std::unordered_map<const void*, int> occ;
 };
 
 namespace {
@@ -224,6 +230,22 @@ void release(DevBuf& b)
     b.cap = 0;
 }
 
+// resident workgroups per CU of `kern` on this handle's device (>= 1), cached per handle; kernels with more than
+// 48 KB of dynamic LDS get their limit raised here, once per handle
+int kernel_occupancy(bhs_handle* h, const void* kern, int block, size_t smem, int* out)
+{
+    auto it = h->occ.find(kern);
+    if (it != h->occ.end()) { *out = it->second; return BHS_SUCCESS; }
+    if (smem > 48 * 1024)
+        BHS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int nb = 0;
+    BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, block, smem));
+    nb = std::max(1, nb);
+    h->occ.emplace(kern, nb);
+    *out = nb;
+    return BHS_SUCCESS;
+}
+
 int stat_index(bhs_handle* h, const char* name)
 {
     for (size_t i = 0; i < h->stats.size(); ++i)
@@ -262,15 +284,8 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     constexpr int TS = 1 << LOG2TS;
     auto kern = k_row_block<TS, LOG2TS, BLOCK, NUM>;
     const size_t smem = sizeof(BlockSmem<TS, BLOCK, NUM>);
-    static int perCU = 0;
-    if (!perCU) {
-        if (smem > 48 * 1024)
-            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        int nb = 0;
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BLOCK, smem));
-        perCU = std::max(1, nb);
-    }
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), BLOCK, smem, &perCU));
     long long grid = std::max<long long>(1, std::min<long long>((long long)qn, (long long)h->numCU * perCU));
     BHS_HIP(hipMemsetAsync((int*)h->small.p + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->ls, queue, qn, h->n, h->bSorted, h->dAj,
@@ -297,7 +312,7 @@ int ensure_spa(bhs_handle* h)
         BHS_TRY(ensure(h, h->spaRank, (size_t)slots * nWords * sizeof(int)));      // rank words
         BHS_TRY(ensure(h, h->spaBits, (size_t)slots * nWords * sizeof(unsigned)));
     }
-    BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->ls));
+    BHS_HIP(hipMemsetAsync(h->spaBits.p, 0, (size_t)slots * nWords * sizeof(unsigned), h->stream));
     h->spaSlots = (int)slots;
     h->spaCols = h->n;
     h->spaDirty = false;
@@ -326,12 +341,9 @@ template <bool NUM>
 int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     auto kern = k_row_bitmap_lds<NUM>;
-    static bool attrSet = false;
-    if (!attrSet) {
-        BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bitmap_smem<NUM>(kLdsBitmapCols / 32)));
-        attrSet = true;
-    }
+    int perCUunused = 1;     // (one workgroup per CU by design; the call raises the dynamic-LDS limit for this device)
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), kLdsBitmapBlock,
+                             lds_bitmap_smem<NUM>(kLdsBitmapCols / 32), &perCUunused));
     const int nWords = (int)((((long long)std::max(h->n, 1) + 31) / 32 + 1023) / 1024 * 1024);
     const long long grid = std::max<long long>(1, std::min<long long>(qn, h->numCU));
     int* small = (int*)h->small.p;
@@ -350,15 +362,9 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     auto kern = k_row_wave<TS, LOG2TS, NUM, PACK32, SMALLB>;
     constexpr int WPB = kWavesPerBlock;
     const size_t smem = sizeof(WaveSmem<TS, NUM, PACK32>) * WPB;
-    static int perCU = 0;
-    if (!perCU) {
-        if (smem > 48 * 1024)
-            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        int nb = 0;   // resident 64-lane workgroups per CU: registers, LDS and the 32-wave cap all count
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WPB, smem));
-        perCU = std::max(1, std::min(nb, 32 / WPB));
-    }
+    int perCU = 1;    // resident 64-lane workgroups per CU: registers, LDS and the 32-wave cap all count
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * WPB, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32 / WPB));
     if (h->verbose > 1) printf("  [%s TS=%d] occupancy API: %d workgroups/CU, smem %zu B\n", NUM ? "numeric" : "symbolic", TS, perCU, smem);
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
@@ -370,7 +376,8 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj, h->dAx,
                        h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p, h->dAp,
                        wf ? (int*)h->ub.p : (int*)nullptr,
-                       wf ? (unsigned long long*)((int*)h->small.p + S_CT_SLOTS) : (unsigned long long*)nullptr);
+                       wf ? (unsigned long long*)((int*)h->small.p + S_CT_SLOTS) : (unsigned long long*)nullptr,
+                       (int*)h->small.p + S_ERR);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -402,15 +409,9 @@ int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
     auto kern = k_row_wave_csym<TS, LOG2TS>;
     constexpr int WPB = kWavesPerBlock;
     const size_t smem = sizeof(CsymSmem<TS>) * WPB;
-    static int perCU = 0;
-    if (!perCU) {
-        if (smem > 48 * 1024)
-            BHS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        int nb = 0;
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * WPB, smem));
-        perCU = std::max(1, std::min(nb, 32 / WPB));
-    }
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * WPB, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32 / WPB));
     if (h->verbose > 1) printf("  [symbolic/compressed TS=%d] occupancy API: %d workgroups/CU, smem %zu B\n", TS, perCU, smem);
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
@@ -418,7 +419,7 @@ int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
     int chunkLog2 = 0;
     while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj,
-                       (const int2*)h->cExt.p, (const int2*)h->cPair.p, cnt);
+                       (const int2*)h->cExt.p, (const int2*)h->cPair.p, cnt, (int*)h->small.p + S_ERR);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -450,17 +451,14 @@ template <bool NUM, bool PACK32>
 int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
     auto kern = k_row_quad<NUM, PACK32>;
-    static int perCU = 0;
-    if (!perCU) {
-        int nb = 0;
-        BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, 0));
-        perCU = std::max(1, std::min(nb, 32));
-    }
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, 0, &perCU));
+    perCU = std::min(perCU, 32);
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->ls, queue, qn, h->dAp, h->dAj, h->dAx, h->dBp, h->dBj,
-                       h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p);
+                       h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p, (int*)h->small.p + S_ERR);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -487,11 +485,11 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p, ubOut, ctSlots);                                            \
+                               (value_t*)h->Cx.p, ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p, ubOut, ctSlots);                                            \
+                               (value_t*)h->Cx.p, ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
         break;
     switch (K) {
         BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)
@@ -630,7 +628,7 @@ int join_bins(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
-int run_pipeline(bhs_handle* h)
+int run_pipeline_impl(bhs_handle* h)
 {
     h->ls = h->stream;
     const int m = h->m;
@@ -642,6 +640,7 @@ int run_pipeline(bhs_handle* h)
     h->nnzC = 0;
     h->nnzCt = 0;
     h->hasC = false;
+    h->rowPtrStaged = false;          // (an empty product returns early: the previous multiply's staging must not be read)
 
     BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
     if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
@@ -687,13 +686,14 @@ int run_pipeline(bhs_handle* h)
     // the lane-per-row symbolic kernel whatever its product count (the kernel has no table to overflow).  The
     // upper-bound pass, its host round trip and the symbolic queue all disappear; the lane kernel writes ub[] and
     // the product total on the side.
-    const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64;
+    const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64 &&
+                           !h->specFailed;
     // "Wave-first": maxRow(A) x maxRow(B) bounds every row's product count; when that bound fits a wave-per-row
     // table and is not far above the average row (stencils, FEM meshes: poisson27pt 27 x 27 = 729 for every interior
     // row), every row can run the symbolic wave kernel of that one table size -- again without upper-bound pass,
     // host round trip or queue; the kernel delivers ub[] and the product total.
     int wfBin = 0;
-    if (!laneFirst && h->waveFirst && h->directBins && !cmpRun && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+    if (!laneFirst && h->waveFirst && h->directBins && !cmpRun && h->forcePath == 0 && h->maxTableLog2 >= 15 && !h->specFailed) {
         const long long bound = (long long)h->maxRowA * h->maxRowB;
         if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
             for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
@@ -803,6 +803,15 @@ int run_pipeline(bhs_handle* h)
     }
     long long nnzC;
     memcpy(&nnzC, hs + S_TOTAL_C, 8);
+    if (hs[S_ERR] & 2) {
+        // The lane-first / wave-first launch was chosen from the row bounds seen at bhs_set_data time and the
+        // kernels found a row beyond them (borrowed arrays changed since): this multiply starts over on the
+        // general pipeline, which assumes nothing, and the data set stays there.
+        if (!noUpperBound || h->specFailed) return BHS_ERR_INTERNAL;
+        h->specFailed = true;
+        if (h->verbose > 1) printf("  [speculative direct launch refuted on the device: general pipeline]\n");
+        return run_pipeline_impl(h);
+    }
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
     if (nnzC > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
     h->nnzC = nnzC;
@@ -917,6 +926,26 @@ int run_pipeline(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
+// Every exit of the pipeline leaves the handle quiescent: an error taken while the bins of a stage are forked
+// onto the side streams would otherwise leave kernels queued there -- still writing Cp / Cj / the counters while
+// the next bhs_spgemm starts on `stream` -- and stale launch state (ls, ticket slot) behind.
+int run_pipeline(bhs_handle* h)
+{
+    const int rc = run_pipeline_impl(h);
+    if (rc != BHS_SUCCESS) {
+        for (int i = 0; i < bhs_handle::kBinStreams; ++i)
+            if (h->binStream[i]) (void)hipStreamSynchronize(h->binStream[i]);
+        if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
+        h->ls = h->stream;
+        h->ticketSlot = S_TICKET;
+        h->binsForked = false;
+        h->rowPtrStaged = false;
+    }
+    return rc;
+}
+
 // per-row sort of a device CSR by column, in place (bhs_csr_sort_indices_device; also applied to unsorted B)
 int sort_rows_device(bhs_handle* h, int n_row, const int* d_rowPtr, int* d_colInd, value_t* d_val)
 {
@@ -924,7 +953,7 @@ int sort_rows_device(bhs_handle* h, int n_row, const int* d_rowPtr, int* d_colIn
     BHS_TRY(ensure(h, h->sortList, sizeof(int) * (size_t)n_row));
     int* cnt = (int*)h->sortCnt.p;                      // [0] long rows, [1] longest row
     BHS_HIP(hipMemsetAsync(cnt, 0, 16, h->stream));
-    const long long gmr = std::min<long long>(((long long)n_row + 255) / 256, (long long)h->numCU * 8);
+    const long long gmr = std::min<long long>(((long long)n_row + 255) / 256, (long long)h->numCU * 2);
     hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, n_row, d_rowPtr, cnt + 1);
     BHS_HIP(hipGetLastError());
     int host[2] = {0, 0};
@@ -961,7 +990,7 @@ int finish_set_data(bhs_handle* h)
     if (h->m > 0) {
         int* small0 = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
-        const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 8);
+        const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 2);
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_MAXROW);
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(&maxRowA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -976,7 +1005,7 @@ int finish_set_data(bhs_handle* h)
     if (h->k > 0) {
         int* small0 = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
-        const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 8);
+        const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 2);
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_MAXROW);
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(&h->maxRowB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -990,11 +1019,14 @@ int finish_set_data(bhs_handle* h)
     BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
     h->bSorted = 1;
     h->cmpState = 0;
+    h->specFailed = false;
     if (h->nnzB > 1 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
-        long long grid = std::min<long long>(((long long)h->nnzB + 255) / 256, (long long)h->numCU * 16);
-        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj,
+        const int logG = std::min(h->logL, 6);                  // lanes per row of B: its average length
+        long long grid = std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16);
+        grid = std::max<long long>(grid, 1);
+        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
                            small + S_SORTED);
         BHS_HIP(hipGetLastError());
         int flag = 0;
@@ -1015,7 +1047,7 @@ int finish_set_data(bhs_handle* h)
             }
             BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
             BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj,
+            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
                                small + S_SORTED);
             BHS_HIP(hipGetLastError());
             BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -111,3 +111,92 @@ def test_driver_symmetric_and_pattern_mtx(driver, tmp_path):
     p.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n% c\n5 5 6\n1 1\n2 1\n3 2\n5 1\n4 4\n5 5\n")
     out = _run(driver, "-hip", "-spgemm", str(p))
     assert "A: ( 5 by 5, nnz = 9 )" in out and "ColIndC/csrValC PASS!" in out
+
+
+@pytest.mark.gpu
+def test_driver_two_different_rectangular_files(driver, tmp_path, oracle):
+    """The CLI's two-file form (main.cu:56-60, 285-293) with A != B and rectangular shapes: A is 6 x 9 (general,
+    real), B is 9 x 4 (general, integer); the driver multiplies, checks against the CPU oracle and prints the counts."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+
+    def write(path, rows, cols, dens, field):
+        mask = rng.random((rows, cols)) < dens
+        mask[0, :] = False                                   # an empty row
+        r, c = np.nonzero(mask)
+        perm = rng.permutation(len(r))                       # unsorted coordinate order
+        with open(path, "w") as f:
+            f.write("%%%%MatrixMarket matrix coordinate %s general\n%% test\n%d %d %d\n" % (field, rows, cols, len(r)))
+            for i in perm:
+                v = rng.integers(1, 10)
+                f.write("%d %d %s\n" % (r[i] + 1, c[i] + 1, str(int(v)) if field == "integer" else "%.1f" % v))
+        return mask
+    a = tmp_path / "a.mtx"; b = tmp_path / "b.mtx"
+    ma = write(a, 6, 9, 0.5, "real")
+    mb = write(b, 9, 4, 0.5, "integer")
+    out = _run(driver, "-hip", "-spgemm", str(a), str(b))
+    assert " A: ( 6 by 9, nnz = %d )" % ma.sum() in out and " B: ( 9 by 4, nnz = %d )" % mb.sum() in out
+    assert "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out
+    nnzct = int((ma.sum(axis=0) * mb.sum(axis=1)).sum())
+    nnzc = int(((ma.astype(int) @ mb.astype(int)) > 0).sum())
+    assert '"nnzCt": %d, "nnzC": %d, "pass": true' % (nnzct, nnzc) in out
+    # mismatched inner dimensions are refused like any other driver error
+    p = subprocess.run([driver, "-hip", "-spgemm", str(b), str(b)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "dimension mismatch" in p.stdout
+
+
+def test_host_code_under_address_and_ub_sanitizers(tmp_path, oracle):
+    """the host side (C++ facade headers, Matrix Market reader, gallery, csr_sort, the CPU oracle) built
+    with -fsanitize=address,undefined and exercised on the CPU: parse files, sort rows, run the oracle, compare.
+    (GPU sanitizers are not available on the pool; the device library is not part of this build.)"""
+    import numpy as np
+    src = tmp_path / "san.cpp"
+    src.write_text(r'''
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "%(root)s/benchmark_spgemm_using_csr_amd/host/common.h"
+#include "%(root)s/benchmark_spgemm_using_csr_amd/host/csr_sort.h"
+#include "%(root)s/benchmark_spgemm_using_csr_amd/host/gallery.h"
+#include "%(root)s/benchmark_spgemm_using_csr_amd/host/mtx_reader.h"
+extern "C" {
+#include "%(root)s/oracle/ref_spgemm_oracle.h"
+}
+int main(int argc, char** argv) {
+    CsrHost A, B;
+    std::string msg;
+    if (read_matrix_market(argv[1], A, &msg)) { printf("%%s\n", msg.c_str()); return 2; }
+    gallery_poisson("poisson27pt", 5, 4, 3, B);
+    if (read_matrix_market(argv[2], B, &msg) == 0) return 3;      // a broken file must be refused, not crash
+    gallery_poisson("poisson9pt", 7, 6, 1, B);
+    csr_sort_indices<int, double>(A.num_rows, A.row_offsets.data(), A.column_indices.data(), A.values.data());
+    const int m = A.num_rows;
+    std::vector<int64_t> Cp(m + 1);
+    const int64_t ct = oracle_nnzCt(m, A.row_offsets.data(), A.column_indices.data(), A.row_offsets.data(), nullptr);
+    const int64_t nnzC = oracle_spgemm_symbolic(m, A.num_cols, A.num_cols, A.row_offsets.data(), A.column_indices.data(),
+                                                A.row_offsets.data(), A.column_indices.data(), Cp.data(), 2);
+    std::vector<int> Cj(nnzC);
+    std::vector<double> Cx(nnzC);
+    oracle_spgemm_numeric(m, A.num_cols, A.num_cols, A.row_offsets.data(), A.column_indices.data(), A.values.data(),
+                          A.row_offsets.data(), A.column_indices.data(), A.values.data(), Cp.data(), Cj.data(), Cx.data(), 2);
+    std::vector<int> Cp32(Cp.begin(), Cp.end());
+    int64_t res[8] = {0};
+    oracle_compare(m, nnzC, Cp.data(), Cj.data(), Cx.data(), nnzC, Cp32.data(), Cj.data(), Cx.data(), 1e-6, res);
+    uint64_t dg[4];
+    oracle_digest(m, Cp.data(), Cj.data(), Cx.data(), dg);
+    printf("nnzCt=%%lld nnzC=%%lld\n", (long long)ct, (long long)nnzC);
+    return 0;
+}''' % {"root": ROOT})
+    exe = tmp_path / "san"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp",
+           "-o", str(exe), str(src), "-x", "c", os.path.join(ROOT, "oracle", "ref_spgemm_oracle.c"), "-lm"]
+    subprocess.check_call(cmd)
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n3 3 5\n1 1 1.0\n9 9 2.0\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
+    p = subprocess.run([str(exe), os.path.join(GOLDEN, "cage4.mtx"), str(bad)], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "nnzCt=269 nnzC=81" in p.stdout

@@ -130,3 +130,19 @@ def test_poisson_row_blocks_concatenate():
     for name, dims in (("poisson5pt", (7, 9, 1)), ("poisson9pt", (8, 5, 1)), ("poisson7pt", (4, 5, 6))):
         rp, col = gallery.poisson_csr(name, *dims)
         assert (len(rp) - 1, len(col)) == gallery.poisson_closed_form(name, *dims)
+
+
+def test_webbase_standin_matches_published_shape():
+    """configs[3] stand-in (the SuiteSparse file is not in the image): same dimensions as Williams/webbase-1M
+    (m = n = 1 000 005, nnz = 3 105 536, longest row ~4.7 k) within a few per cent, power-law row lengths."""
+    from benchmark_spgemm_using_csr_amd import gallery
+    rp, col = gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
+    lens = np.diff(rp)
+    assert len(rp) - 1 == 1000005
+    assert abs(int(rp[-1]) - 3105536) <= 0.04 * 3105536            # duplicates removed: slightly below target
+    assert 4600 <= lens.max() <= 4700 and 4600 <= np.sort(lens)[-8] <= 4700   # 8 hub rows of ~4.7 k (webbase: 4700)
+    assert (lens <= 3).mean() > 0.7                                 # most rows are tiny (webbase: ~70 % with <= 3)
+    assert (lens > 100).sum() < 5000                                # a thin tail carries the long rows
+    d = np.diff(col.astype(np.int64))
+    starts = np.zeros(len(col), bool); starts[rp[1:-1][rp[1:-1] < len(col)]] = True
+    assert np.all((d > 0) | starts[1:])                             # rows sorted, duplicate-free

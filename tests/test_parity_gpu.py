@@ -602,8 +602,11 @@ def test_float_value_type_build(oracle, case):
     if case in ("p27", "p5", "hub"):
         assert np.array_equal(Cx.astype(np.float64), ref[2])          # small integers: exact
     else:
-        scale = np.maximum(np.abs(ref[2]), 1e-3)
-        assert np.max(np.abs(Cx.astype(np.float64) - ref[2]) / scale) < 50 * F32_TOL
+        # fp64 accumulation of exact products of float inputs, ONE rounding to float at the end: the error of an
+        # entry is at most half a float ulp of its own magnitude (2^-24 relative) -- no growth with the number of
+        # products and no cancellation term.  (Long-row bins that add in float would not meet this.)
+        err = np.abs(Cx.astype(np.float64) - ref[2])
+        assert np.all(err <= np.abs(ref[2]) * (2.0 ** -24 * 1.0001) + 1e-300), float(np.max(err / np.maximum(np.abs(ref[2]), 1e-300)))
     check_csr_invariants(m, n, Cp, Cj)
 
 
@@ -643,3 +646,95 @@ def test_errors_are_codes_not_exceptions():
     assert bh.initData(2, 2, 2, 0, np.empty(0), bad, np.empty(0, np.int32), 0, np.empty(0),
                        np.zeros(3, np.int32), np.empty(0, np.int32), None) == bhmod._lib.BHS_ERR_INVALID_ARG
     assert bh.freePlatform() == 0
+
+
+def test_empty_multiply_after_nonempty_on_one_handle():
+    """the empty-product early exit must not hand out the PREVIOUS multiply's staged rowPtrC.
+    One handle: a non-empty multiply through the host-pointer API (rowPtrC staged in pinned memory), then an
+    empty one with more rows; the C-ABI's rowPtrC_out must come back all zero."""
+    m1, rp, col, val = poisson_case("poisson27pt", 8, 8, 8)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    Cp1 = np.zeros(m1 + 1, np.int32)
+    assert bh.initData(m1, m1, m1, len(col), val, rp, col, len(col), val, rp, col, Cp1) == 0
+    assert bh.spgemm() == 0 and Cp1[-1] == bh.get_nnzC() > 0
+    # empty A with MORE rows than before (the stale staging buffer would also be too short), B unchanged
+    m2 = 3 * m1
+    rp0 = np.zeros(m2 + 1, np.int32)
+    Cp2 = np.full(m2 + 1, -7, np.int32)
+    assert bh.initData(m2, m1, m1, 0, np.empty(0), rp0, np.empty(0, np.int32), len(col), val, rp, col, Cp2) == 0
+    assert bh.spgemm() == 0
+    assert bh.get_nnzC() == 0 and bh.nnzCt == 0
+    assert not Cp2.any()
+    # and back to a non-empty product on the same handle
+    assert bh.initData(m1, m1, m1, len(col), val, rp, col, len(col), val, rp, col, Cp1) == 0
+    Cp1[:] = -1
+    assert bh.spgemm() == 0 and Cp1[0] == 0 and Cp1[-1] == bh.get_nnzC() > 0
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+def test_empty_multiply_after_nonempty_device_inputs():
+    """Same hazard through bhs_set_data_device + bhs_spgemm(rowPtrC_out) called directly on the C-ABI."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    m1, rp, col, val = poisson_case("poisson5pt", 30, 30)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Bp, Bj, Bx = t(rp), t(col), t(val)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.initData_device(m1, m1, m1, len(col), Bx, Bp, Bj, len(col), Bx, Bp, Bj) == 0
+    out1 = np.full(m1 + 1, -1, np.int32)
+    nnzCt, nnzC = C.c_int64(0), C.c_int(0)
+    assert bh._lib.bhs_spgemm(bh._h, out1.ctypes.data_as(C.c_void_p), C.byref(nnzCt), C.byref(nnzC), None) == 0
+    assert out1[0] == 0 and out1[-1] == nnzC.value > 0
+    m2 = 5 * m1
+    Ap0 = torch.zeros(m2 + 1, dtype=torch.int32, device=dev)
+    e_i, e_v = torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.float64, device=dev)
+    assert bh.initData_device(m2, m1, m1, 0, e_v, Ap0, e_i, len(col), Bx, Bp, Bj) == 0
+    out2 = np.full(m2 + 1, -9, np.int32)
+    assert bh._lib.bhs_spgemm(bh._h, out2.ctypes.data_as(C.c_void_p), C.byref(nnzCt), C.byref(nnzC), None) == 0
+    assert nnzC.value == 0 and nnzCt.value == 0 and not out2.any()
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+@pytest.mark.parametrize("stencil,dims", [("poisson5pt", (40, 40, 1)), ("poisson27pt", (12, 12, 12))])
+def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
+    """Lane-first / wave-first launches are chosen from the row bounds seen at bhs_set_data time; the multiply
+    verifies them itself.  Borrowed device arrays are changed AFTER bhs_set_data_device so that one row of A is
+    far longer than the longest row seen then: the kernels must refute the speculation and the multiply must
+    still be right (general pipeline), on this call and the next."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m, rp, col, val = poisson_case(stencil, *dims)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Bp, Bj, Bx = t(rp), t(col), t(val)
+    Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
+    assert bh.spgemm() == 0
+    first = {s["name"] for s in bh.kernel_stats()}
+    assert "upper_bound" not in first            # the direct path ran
+    # row 5 of A swallows rows 5..11 (same arrays, same nnz): 7 rows' worth of entries in one row
+    rp2 = rp.copy()
+    rp2[6:12] = rp[12]
+    Ap.copy_(t(rp2))
+    torch.cuda.synchronize()
+    ref = oracle.spgemm(m, m, m, rp2, col, val, rp, col, val)
+    for _ in range(2):
+        assert bh.spgemm() == 0
+        assert "upper_bound" in {s["name"] for s in bh.kernel_stats()}       # general pipeline
+        Cp = bh.get_rowptrC()
+        nnzC = bh.get_nnzC()
+        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert bh.nnzCt == oracle.nnzCt(rp2, col, rp)
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
