@@ -510,9 +510,10 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     const int* __restrict__ ubArr,          // symbolic: per-row upper bound (first window guess)
     int* __restrict__ CpOrCnt, int* __restrict__ Cj, value_t* __restrict__ Cx,
-    int* __restrict__ errFlag, int* __restrict__ ticket)
+    int* __restrict__ errFlag, int* __restrict__ ticket, const int* __restrict__ qnPtr)
 {
     static_assert((1 << LOG2TS) == TS, "table size must be 2^LOG2TS");
+    if (qnPtr) qn = *qnPtr;               // queue filled on the device (overflow rows of k_sym_blocks): length read here
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Smem = BlockSmem<TS, BLOCK, NUM>;
     Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
         if (q >= qn) break;
         const int4 d = desc[q];
         const int row = d.x, a0 = d.y, a1 = d.z;
-        long long outBase = d.w;
+        long long outBase = NUM ? CpOrCnt[row] : 0;   // (numeric: CpOrCnt is rowPtrC; equals d.w where the queue carries it)
         int rowTotal = 0;                 // symbolic: unique count over all windows
         const long long need = NUM ? (long long)(CpOrCnt[row + 1] - CpOrCnt[row]) : (long long)ubArr[row];
         long long lo = 0, width = ncolsB;

@@ -14,6 +14,7 @@
 // rowPtrC (bhsparse_cuda.h:280, 289, 2787-2808).
 #include "../../include/bhsparse_hip.h"
 #include "bhs_kernels.hip.h"
+#include "bhs_rank.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -149,6 +150,10 @@ struct bhs_handle {
     double avgRowA = 1.0, avgRowB = 1.0;
     int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
     int maxRowB = 0;
+    int rankPath = 0;                    // pattern + rank kernels (bhs_rank.hip.h) for the matrices that qualify for wave-first: 0 off (default:
+                                         // measured slower than the hash kernels on poisson27pt), 1 on
+    int rankState = 0;                   // per data set: -1 after a multiply that sent too many rows to the overflow queue
+    DevBuf pat;                          // row patterns: kPatPairs x 8 bytes per row
     bool specFailed = false;             // a lane-first / wave-first launch met a row beyond the bounds seen at set_data time
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
@@ -197,7 +202,7 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_NUM_SUMS = 104 + 96,
        S_MAXCNT = 104 + 192 /* longest row of C */,
        S_ZERO_END = 104 + 194,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_MAXROW = 301,
+       S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* rows k_sym_blocks sent to the overflow queue */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
        S_SMALL_INTS = 448 };
@@ -279,7 +284,7 @@ int timed_end(bhs_handle* h, EventPair* p)
 }
 
 template <int LOG2TS, int BLOCK, bool NUM>
-int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, const int* qnPtr = nullptr)
 {
     constexpr int TS = 1 << LOG2TS;
     auto kern = k_row_block<TS, LOG2TS, BLOCK, NUM>;
@@ -290,7 +295,7 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     BHS_HIP(hipMemsetAsync((int*)h->small.p + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->ls, queue, qn, h->n, h->bSorted, h->dAj,
                        h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
-                       (int*)h->small.p + S_ERR, (int*)h->small.p + h->ticketSlot);
+                       (int*)h->small.p + S_ERR, (int*)h->small.p + h->ticketSlot, qnPtr);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -420,6 +425,65 @@ int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
     while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj,
                        (const int2*)h->cExt.p, (const int2*)h->cPair.p, cnt, (int*)h->small.p + S_ERR);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+// ---- pattern + rank kernels (bhs_rank.hip.h): every row straight from rowPtrA, XCD-aware persistent grid
+int rank_grid(bhs_handle* h, const void* kern, size_t smem, int qn, long long* grid, int* chunkLog2)
+{
+    constexpr int WPB = kWavesPerBlock;
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, kern, 64 * WPB, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32 / WPB));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    long long g = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
+    *grid = std::max<long long>(8, (g + 7) / 8 * 8);
+    int cl = 0;
+    while ((2 << cl) <= BHS_XCD_CHUNK && (128LL << cl) <= (long long)qn) ++cl;
+    *chunkLog2 = cl;
+    return BHS_SUCCESS;
+}
+
+int launch_sym_sorted(bhs_handle* h)
+{
+    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
+    const size_t smem = sizeof(SymSortSmem) * kWavesPerBlock;
+    int* small = (int*)h->small.p;
+    long long grid;
+    int cl;
+#define BHS_SYMS(SB)                                                                                              \
+    {                                                                                                             \
+        auto kern = k_sym_sorted<SB>;                                                                             \
+        BHS_TRY(rank_grid(h, reinterpret_cast<const void*>(kern), smem, h->m, &grid, &cl));                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), smem, h->ls, h->m, cl, h->dAp,  \
+                           h->dAj, h->dBp, h->dBj, (int*)h->Cp.p, (int*)h->ub.p,                                  \
+                           (unsigned long long*)(small + S_CT_SLOTS), (int*)h->pat.p, (int4*)h->queue.p,          \
+                           small + S_OVF);                                                                        \
+    }
+    if (smallB) BHS_SYMS(true) else BHS_SYMS(false)
+#undef BHS_SYMS
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <int RMAX>
+int launch_num_rank(bhs_handle* h)
+{
+    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
+    const size_t smem = sizeof(NumRankSmem<RMAX>) * kWavesPerBlock;
+    long long grid;
+    int cl;
+#define BHS_NUMR(SB)                                                                                              \
+    {                                                                                                             \
+        auto kern = k_num_rank<RMAX, SB>;                                                                         \
+        BHS_TRY(rank_grid(h, reinterpret_cast<const void*>(kern), smem, h->m, &grid, &cl));                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), smem, h->ls, h->m, cl, h->dAp,  \
+                           h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->Cp.p, (int*)h->Cj.p,            \
+                           (value_t*)h->Cx.p, (const int*)h->pat.p, (int*)h->small.p + S_ERR);                    \
+    }
+    if (smallB) BHS_NUMR(true) else BHS_NUMR(false)
+#undef BHS_NUMR
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -698,10 +762,16 @@ int run_pipeline_impl(bhs_handle* h)
         if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
             for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
     }
+    // The wave-first class (stencils, FEM meshes) takes the pattern + rank kernels: the symbolic pass hands every
+    // row's sorted column list to the numeric pass, which then needs no hash inserts, no compaction and no sort.
+    // (maxRowA is a hint: rows with more than 64 A entries go to the overflow queue on the device.)
+    const bool useRank = wfBin > 0 && h->rankPath && h->rankState >= 0 && h->maxRowA <= 64;
+    if (useRank) BHS_TRY(ensure(h, h->pat, sizeof(int) * (size_t)kPatStride * (size_t)m));
     const bool noUpperBound = laneFirst || wfBin > 0;
     int symCount[kMaxBins], symStart[kMaxBins + 1];
     if (noUpperBound) {
         BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
+        if (useRank) BHS_HIP(hipMemsetAsync(small + S_OVF, 0, sizeof(int), h->stream));
         for (int b = 0; b < kMaxBins; ++b) { symCount[b] = 0; symStart[b] = 0; }
         symStart[kMaxBins] = 0;
         symCount[laneFirst ? kLaneBin : wfBin] = m;
@@ -768,6 +838,23 @@ int run_pipeline_impl(bhs_handle* h)
         h->stats[ep->stat].rows += symCount[kLaneBin];
         symStat[kLaneBin] = ep->stat;
     }
+    if (useRank) {
+        BHS_TRY(timed_begin(h, "symbolic_sorted", &ep));
+        BHS_TRY(launch_sym_sorted(h));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += m;
+        symStat[wfBin] = ep->stat;
+        // rows the block table could not hold: workgroup-per-row hash kernel over the device-built queue (its
+        // length is read on the device; the launch is a persistent grid that leaves at once when the queue is empty)
+        h->ticketSlot = S_TICKETS + kMaxBins - 2;
+        BHS_TRY(timed_begin(h, "symbolic_overflow", &ep));
+        BHS_TRY((launch_row_block<15, 1024, false>(h, (const int4*)h->queue.p, h->numCU, (int*)h->Cp.p, small + S_OVF)));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->ticketSlot = S_TICKET;
+        symCount[wfBin] = 0;                                         // (done: the bin loop below has nothing left)
+    }
     for (int i = 1; i < kNumSymBins; ++i) {
         const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
         if (!symCount[b]) continue;
@@ -824,10 +911,19 @@ int run_pipeline_impl(bhs_handle* h)
     BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
     BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    int rankOvf = 0;
+    if (useRank) {
+        rankOvf = hs[S_OVF];
+        for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
+        numStart[kMaxBins] = 0;
+        numDirect = true;
+        // a data set that sends more than 2 % of its rows to the overflow queue is better served by the hash bins
+        if ((long long)rankOvf * 50 > (long long)m) h->rankState = -1;
+    }
     // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
     // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
     // queue, and the few short boundary rows no longer pay for kernels of their own.
-    if (!numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
         const int maxCnt = hs[S_MAXCNT];
         int nb = 0;
         for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
@@ -869,6 +965,24 @@ int run_pipeline_impl(bhs_handle* h)
     }
 
     // ------------------------------------------------------------ stage 4: numeric
+    if (useRank) {
+        BHS_TRY(timed_begin(h, "numeric_rank", &ep));
+        if (hs[S_MAXCNT] <= 128) BHS_TRY(launch_num_rank<128>(h));
+        else BHS_TRY(launch_num_rank<256>(h));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += m;
+        numStat[2] = ep->stat;
+        if (rankOvf > 0) {
+            h->ticketSlot = S_TICKETS + kMaxBins - 2;
+            BHS_TRY(timed_begin(h, "numeric_overflow", &ep));
+            BHS_TRY((launch_row_block<13, 512, true>(h, (const int4*)h->queue.p, rankOvf, (int*)h->Cp.p)));
+            BHS_TRY(timed_end(h, ep));
+            h->stats[ep->stat].launches++;
+            h->stats[ep->stat].rows += rankOvf;
+            h->ticketSlot = S_TICKET;
+        }
+    }
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
     if (numCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
@@ -1020,6 +1134,7 @@ int finish_set_data(bhs_handle* h)
     h->bSorted = 1;
     h->cmpState = 0;
     h->specFailed = false;
+    h->rankState = 0;
     if (h->nnzB > 1 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
@@ -1167,6 +1282,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->sortV);
     release(h->cLen);
     release(h->symKey);
+    release(h->pat);
     release(h->blockSum);
     release(h->small);
     release(h->spaRank);
@@ -1377,6 +1493,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "rank_path")) { h->rankPath = (int)value; h->rankState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }

@@ -26,8 +26,8 @@ def stat_name(k):
         return "%s_wave<%s>" % ("numeric" if mt.group(2) == "true" else "symbolic", mt.group(1))
     if "k_num_rank" in k:
         return "numeric_rank"
-    if "k_sym_blocks" in k:
-        return "symbolic_blocks"
+    if "k_sym_sorted" in k:
+        return "symbolic_sorted"
     mt = re.search(r"k_row_lane<(\d+), (true|false)", k)
     if mt:
         return "numeric_lane" if mt.group(2) == "true" else "symbolic_lane"

@@ -3,7 +3,7 @@
 import csv, sys, glob, collections, re
 root = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(root + "/pmc*/p_counter_collection.csv")):
+for f in sorted(glob.glob(root + "/pmc*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "bhs::" not in k: continue
