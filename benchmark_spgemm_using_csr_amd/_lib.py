@@ -41,6 +41,11 @@ SYMBOLS = {
     "bhs_free_data": (_i, [_vp]),
     "bhs_warmup": (_i, [_vp]),
     "bhs_spgemm": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(C.c_double)]),
+    "bhs_spgemm_symbolic": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i)]),
+    "bhs_set_output_device": (_i, [_vp, _vp, _vp, _i64]),
+    "bhs_spgemm_numeric": (_i, [_vp, _i, _i]),
+    "bhs_spgemm_finish": (_i, [_vp, C.POINTER(C.c_double)]),
+    "bhs_get_stream": (_i, [_vp, C.POINTER(_vp)]),
     "bhs_get_nnzC": (_i, [_vp, C.POINTER(_i)]),
     "bhs_get_C": (_i, [_vp, _vp, _vp]),
     "bhs_get_rowptrC": (_i, [_vp, _vp]),

@@ -1,0 +1,248 @@
+// bhs_dist.hip — libbhsparse_dist.so: row-block sharding of the SpGEMM hot path over the GPUs of one node and the
+// RCCL all-gatherv that assembles C (see include/bhsparse_dist.h).  Host C++ plus one trivial kernel; everything that
+// multiplies lives in libbhsparse_hip.so and is reached through its C-ABI only.
+#include "../../include/bhsparse_dist.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static_assert(sizeof(ncclUniqueId) == BHS_DIST_ID_BYTES, "id size");
+
+struct bhs_dist {
+    bhs_handle* h = nullptr;
+    int world = 1, rank = 0, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t hstream = nullptr;      // the handle's stream (borrowed)
+    hipStream_t cstream = nullptr;      // transfers: a stream of their own so that they overlap the numeric kernels
+    hipEvent_t evRange = nullptr, evDone = nullptr;
+    long long* dSizes = nullptr;        // device: world x kSizeSlots int64 (sizes exchange)
+    long long* hSizes = nullptr;        // pinned mirror
+    int* hCuts = nullptr;               // pinned: rowPtrC of this rank at the sub-block boundaries
+    double linkFloorMs = 0.0;
+};
+
+namespace {
+
+constexpr int kMaxSub = 16;
+constexpr int kSizeSlots = kMaxSub + 3;   // m_local, nnzCt, cut[0..S]
+
+#define DIST_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); return (int)BHS_ERR_LAUNCH; } } while (0)
+#define DIST_NCCL(call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { fprintf(stderr, "[bhsparse_dist] %s: %s\n", #call, ncclGetErrorString(r__)); return (int)BHS_ERR_LAUNCH; } } while (0)
+#define DIST_TRY(call) do { const int rc__ = (call); if (rc__ != BHS_SUCCESS) return rc__; } while (0)
+
+// rowPtrC of the rank's block, rebased by the entries of the ranks before it, into the block's place in the full array
+__global__ void k_rebase_rowptr(int n, const int* __restrict__ local, long long off, int* __restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (int)(local[i] + off);
+}
+
+__global__ void k_set_int(int* __restrict__ p, int v) { *p = v; }
+
+__global__ void k_gather_cuts(int S, int m_local, const int* __restrict__ rowPtr, long long* __restrict__ out)
+{
+    const int s = threadIdx.x;
+    if (s <= S) out[s] = rowPtr[(long long)m_local * s / S];
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int bhs_dist_unique_id(char id_out[BHS_DIST_ID_BYTES])
+{
+    if (!id_out) return BHS_ERR_INVALID_ARG;
+    ncclUniqueId id;
+    DIST_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return BHS_SUCCESS;
+}
+
+int bhs_dist_create(bhs_dist** out, bhs_handle* h, int world, int rank, const char id[BHS_DIST_ID_BYTES])
+{
+    if (!out || !h || !id || world < 1 || rank < 0 || rank >= world) return BHS_ERR_INVALID_ARG;
+    *out = nullptr;
+    bhs_dist* d = new (std::nothrow) bhs_dist();
+    if (!d) return BHS_ERR_ALLOC;
+    d->h = h;
+    d->world = world;
+    d->rank = rank;
+    void* s = nullptr;
+    if (bhs_get_stream(h, &s) != BHS_SUCCESS) { delete d; return BHS_ERR_INVALID_ARG; }
+    d->hstream = (hipStream_t)s;
+    if (hipGetDevice(&d->device) != hipSuccess) { delete d; return BHS_ERR_NO_DEVICE; }
+    ncclUniqueId nid;
+    memcpy(&nid, id, sizeof(nid));
+    if (ncclCommInitRank(&d->comm, world, nid, rank) != ncclSuccess) { delete d; return BHS_ERR_LAUNCH; }
+    if (hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d->evRange, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&d->dSizes, sizeof(long long) * kSizeSlots * (size_t)world) != hipSuccess ||
+        hipHostMalloc((void**)&d->hSizes, sizeof(long long) * kSizeSlots * (size_t)world, hipHostMallocDefault) != hipSuccess) {
+        bhs_dist_destroy(d);
+        return BHS_ERR_ALLOC;
+    }
+    *out = d;
+    return BHS_SUCCESS;
+}
+
+int bhs_dist_destroy(bhs_dist* d)
+{
+    if (!d) return BHS_ERR_INVALID_ARG;
+    if (d->cstream) (void)hipStreamSynchronize(d->cstream);
+    if (d->comm) (void)ncclCommDestroy(d->comm);
+    if (d->cstream) (void)hipStreamDestroy(d->cstream);
+    if (d->evRange) (void)hipEventDestroy(d->evRange);
+    if (d->evDone) (void)hipEventDestroy(d->evDone);
+    if (d->dSizes) (void)hipFree(d->dSizes);
+    if (d->hSizes) (void)hipHostFree(d->hSizes);
+    delete d;
+    return BHS_SUCCESS;
+}
+
+int bhs_dist_partition_rows(int m, const int* rowPtrA, const int* colIndA, const int* rowPtrB, int world, int* starts_out)
+{
+    if (m < 0 || world < 1 || !starts_out || (m > 0 && (!rowPtrA || !rowPtrB))) return BHS_ERR_INVALID_ARG;
+    // work of a row = its products + a constant for the row itself (rows without products still cost a visit)
+    std::vector<long long> pre((size_t)m + 1, 0);
+    for (int i = 0; i < m; ++i) {
+        long long w = 8;
+        for (int e = rowPtrA[i]; e < rowPtrA[i + 1]; ++e) {
+            const int c = colIndA[e];
+            w += rowPtrB[c + 1] - rowPtrB[c];
+        }
+        pre[(size_t)i + 1] = pre[i] + w;
+    }
+    const long long total = pre[m];
+    starts_out[0] = 0;
+    for (int r = 1; r < world; ++r) {
+        const long long target = total / world * r + (total % world) * r / world;
+        int lo = (int)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+        lo = std::max(lo, starts_out[r - 1]);
+        starts_out[r] = std::min(lo, m);
+    }
+    starts_out[world] = m;
+    return BHS_SUCCESS;
+}
+
+int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_blocks, int* d_rowPtrC, int* d_colIndC,
+                               bhs_value_t* d_valC, int64_t capacity, int64_t* nnzCt_total_out,
+                               int64_t* nnzC_total_out, double ms_out[3])
+{
+    if (!d || m_local < 0 || m_total < m_local || !d_rowPtrC || capacity < 0) return BHS_ERR_INVALID_ARG;
+    const int S = std::max(1, std::min(sub_blocks, kMaxSub));
+    const int W = d->world, me = d->rank;
+    DIST_HIP(hipSetDevice(d->device));
+    const double t0 = now_ms();
+    // the previous call's transfers read the arrays this multiply is about to overwrite
+    DIST_HIP(hipStreamWaitEvent(d->hstream, d->evDone, 0));
+
+    // ---- symbolic half: nnz(C) of the block and its rowPtrC are final afterwards
+    DIST_TRY(bhs_set_output_device(d->h, nullptr, nullptr, 0));
+    int64_t nnzCt = 0;
+    int nnzC = 0;
+    DIST_TRY(bhs_spgemm_symbolic(d->h, &nnzCt, &nnzC));
+    const int* lp = nullptr;
+    DIST_TRY(bhs_get_C_device(d->h, &lp, nullptr, nullptr));
+
+    // ---- sizes of every rank: rows, products, rowPtrC at the sub-block boundaries (one small all-gather)
+    long long* mine = d->dSizes + (size_t)me * kSizeSlots;
+    {
+        long long head[2] = {m_local, nnzCt};
+        memcpy(d->hSizes, head, sizeof(head));
+        DIST_HIP(hipMemcpyAsync(mine, d->hSizes, sizeof(head), hipMemcpyHostToDevice, d->hstream));
+        hipLaunchKernelGGL(k_gather_cuts, dim3(1), dim3(64), 0, d->hstream, S, m_local, lp, mine + 2);
+        DIST_HIP(hipGetLastError());
+    }
+    if (W > 1) DIST_NCCL(ncclAllGather(mine, d->dSizes, kSizeSlots, ncclInt64, d->comm, d->hstream));
+    DIST_HIP(hipMemcpyAsync(d->hSizes, d->dSizes, sizeof(long long) * kSizeSlots * (size_t)W, hipMemcpyDeviceToHost, d->hstream));
+    DIST_HIP(hipStreamSynchronize(d->hstream));
+    std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0);
+    long long ctTotal = 0;
+    for (int r = 0; r < W; ++r) {
+        const long long* sz = d->hSizes + (size_t)r * kSizeSlots;
+        rowOff[r + 1] = rowOff[r] + sz[0];
+        nnzOff[r + 1] = nnzOff[r] + sz[2 + S];          // cut[S] = nnz(C) of the block
+        ctTotal += sz[1];
+    }
+    if (rowOff[W] != m_total) return BHS_ERR_INVALID_ARG;
+    const long long total = nnzOff[W];
+    if (total > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
+    if (total > capacity || (total > 0 && (!d_colIndC || !d_valC))) return BHS_ERR_ALLOC;
+    // per-link floor: the largest block this rank receives over one link
+    long long worst = 0;
+    for (int r = 0; r < W; ++r)
+        if (r != me) worst = std::max(worst, (nnzOff[r + 1] - nnzOff[r]) * (long long)(sizeof(int) + sizeof(bhs_value_t)) +
+                                                 (rowOff[r + 1] - rowOff[r]) * (long long)sizeof(int));
+    d->linkFloorMs = (double)worst / 153.0e9 * 1e3;
+    const double t1 = now_ms();
+
+    // ---- this rank's block is produced in place: the numeric kernels write into the assembled arrays
+    DIST_TRY(bhs_set_output_device(d->h, d_colIndC ? d_colIndC + nnzOff[me] : nullptr,
+                                   d_valC ? d_valC + nnzOff[me] : nullptr, nnzOff[me + 1] - nnzOff[me]));
+    if (m_local > 0) {
+        const int grid = (int)std::min<long long>(((long long)m_local + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_rebase_rowptr, dim3(grid), dim3(256), 0, d->hstream, m_local, lp, nnzOff[me],
+                           d_rowPtrC + rowOff[me]);
+        DIST_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, d->hstream, d_rowPtrC + m_total, (int)total);
+    DIST_HIP(hipGetLastError());
+    // ---- numeric half in row ranges; the transfers of range s ride the second stream while range s + 1 computes
+    auto cut_row = [&](int r, int s) { return (int)((long long)(rowOff[r + 1] - rowOff[r]) * s / S); };
+    auto cut_nnz = [&](int r, int s) { return d->hSizes[(size_t)r * kSizeSlots + 2 + s]; };
+    for (int s = 0; s < S; ++s) {
+        DIST_TRY(bhs_spgemm_numeric(d->h, cut_row(me, s), cut_row(me, s + 1)));
+        if (W == 1) continue;
+        DIST_HIP(hipEventRecord(d->evRange, d->hstream));
+        DIST_HIP(hipStreamWaitEvent(d->cstream, d->evRange, 0));
+        DIST_NCCL(ncclGroupStart());
+        for (int step = 1; step < W; ++step) {                  // staggered peers: rank r sends to r + step, receives from r - step
+            const int dst = (me + step) % W, src = (me - step + W) % W;
+            const long long a = cut_nnz(me, s), b = cut_nnz(me, s + 1);
+            if (b > a) {
+                DIST_NCCL(ncclSend(d_colIndC + nnzOff[me] + a, (size_t)(b - a), ncclInt32, dst, d->comm, d->cstream));
+                DIST_NCCL(ncclSend(d_valC + nnzOff[me] + a, (size_t)(b - a) * sizeof(bhs_value_t), ncclInt8, dst, d->comm, d->cstream));
+            }
+            const long long ra = cut_nnz(src, s), rb = cut_nnz(src, s + 1);
+            if (rb > ra) {
+                DIST_NCCL(ncclRecv(d_colIndC + nnzOff[src] + ra, (size_t)(rb - ra), ncclInt32, src, d->comm, d->cstream));
+                DIST_NCCL(ncclRecv(d_valC + nnzOff[src] + ra, (size_t)(rb - ra) * sizeof(bhs_value_t), ncclInt8, src, d->comm, d->cstream));
+            }
+            if (s == 0) {                                       // row pointers travel with the first range
+                if (m_local > 0)
+                    DIST_NCCL(ncclSend(d_rowPtrC + rowOff[me], (size_t)m_local, ncclInt32, dst, d->comm, d->cstream));
+                const long long rm = rowOff[src + 1] - rowOff[src];
+                if (rm > 0)
+                    DIST_NCCL(ncclRecv(d_rowPtrC + rowOff[src], (size_t)rm, ncclInt32, src, d->comm, d->cstream));
+            }
+        }
+        DIST_NCCL(ncclGroupEnd());
+    }
+    const int rcFin = bhs_spgemm_finish(d->h, nullptr);
+    if (rcFin != BHS_SUCCESS) { (void)hipStreamSynchronize(d->cstream); return rcFin; }
+    const double t2 = now_ms();
+    DIST_HIP(hipEventRecord(d->evDone, d->cstream));
+    DIST_HIP(hipStreamSynchronize(d->cstream));
+    const double t3 = now_ms();
+    if (nnzCt_total_out) *nnzCt_total_out = ctTotal;
+    if (nnzC_total_out) *nnzC_total_out = total;
+    if (ms_out) { ms_out[0] = t1 - t0; ms_out[1] = t2 - t1; ms_out[2] = t3 - t2; }
+    return BHS_SUCCESS;
+}
+
+double bhs_dist_last_link_floor_ms(bhs_dist* d) { return d ? d->linkFloorMs : 0.0; }
+
+}  // extern "C"

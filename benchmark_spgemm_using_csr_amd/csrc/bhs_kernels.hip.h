@@ -429,6 +429,34 @@ __global__ __launch_bounds__(256) void k_scan_apply(int m, int* __restrict__ cnt
     }
 }
 
+// numeric-bin histogram and longest row of a ROW RANGE of C (rowPtrC is final): the scan delivers these for the
+// whole matrix, bhs_spgemm_numeric needs them per range
+__global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__ Cp, const int* __restrict__ Ap,
+                                                  BinSpec spec, int* __restrict__ binCount, int* __restrict__ maxCnt)
+{
+    __shared__ int hist[kMaxBins];
+    __shared__ int wmax[4];
+    const int tid = threadIdx.x;
+    if (tid < kMaxBins) hist[tid] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < m; i += (long long)gridDim.x * 256) {
+        const int v = Cp[i + 1] - Cp[i];
+        mx = max(mx, v);
+        const int b = bin_of(spec, v, Ap[i + 1] - Ap[i]);
+        if (b > 0) atomicAdd(&hist[b], 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+    __syncthreads();
+    if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
+    if (tid == 0) {
+        mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (mx) atomicMax(maxCnt, mx);
+    }
+}
+
 // longest row of a CSR matrix (chooses the lanes-per-row of k_upper_bound for skewed inputs).  One same-address
 // atomic per BLOCK: with one per wave (8192 of them on a 2 M-row matrix) the kernel took 98 us for 8 MB, all of
 // it atomics queueing on one L2 word.

@@ -189,6 +189,24 @@ struct bhs_handle {
     // by kernel_occupancy(), which also raises the dynamic-LDS limit of kernels that need more than 48 KB.  Both
     // are properties of (kernel, device): a process-wide static would hand a second device the first one's answers.
     std::unordered_map<const void*, int> occ;
+    // state handed from the symbolic half of a multiply (stages 1-3) to the numeric half (stage 4), which may be
+    // run in row ranges (bhs_spgemm_symbolic / bhs_spgemm_numeric / bhs_spgemm_finish)
+    struct PipeState {
+        bool open = false;                // symbolic done, finish pending
+        bool empty = false;               // empty product: nothing to launch
+        bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
+        int laneK = 0, rankOvf = 0, maxCnt = 0;
+        BinSpec numSpec;
+        int symStat[kMaxBins], numStat[kMaxBins];
+        int fullCount[kMaxBins];          // numeric-bin histogram of all rows (from the scan)
+        unsigned long long symSums[kMaxBins * 3];
+        bool numDirectFull = false;
+        int rangesRun = 0;
+    } ps;
+    // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
+    int* extCj = nullptr;
+    value_t* extCx = nullptr;
+    long long extCap = 0;
 };
 
 namespace {
@@ -251,6 +269,10 @@ int kernel_occupancy(bhs_handle* h, const void* kern, int block, size_t smem, in
     return BHS_SUCCESS;
 }
 
+// Output arrays of the numeric half: the library's own pool, or the caller's (bhs_set_output_device)
+int* out_cj(bhs_handle* h) { return h->extCj ? h->extCj : (int*)h->Cj.p; }
+value_t* out_cx(bhs_handle* h) { return h->extCx ? h->extCx : (value_t*)h->Cx.p; }
+
 int stat_index(bhs_handle* h, const char* name)
 {
     for (size_t i = 0; i < h->stats.size(); ++i)
@@ -294,7 +316,7 @@ int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, con
     long long grid = std::max<long long>(1, std::min<long long>((long long)qn, (long long)h->numCU * perCU));
     BHS_HIP(hipMemsetAsync((int*)h->small.p + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), smem, h->ls, queue, qn, h->n, h->bSorted, h->dAj,
-                       h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
+                       h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->ub.p, CpOrCnt, out_cj(h), out_cx(h),
                        (int*)h->small.p + S_ERR, (int*)h->small.p + h->ticketSlot, qnPtr);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -335,7 +357,7 @@ int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     int* small = (int*)h->small.p;
     BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL((k_row_spa<BLOCK, NUM>), dim3((unsigned)grid), dim3(BLOCK), 0, h->ls, queue, qn, h->n,
-                       h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
+                       h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h),
                        small + h->ticketSlot, (int*)h->spaRank.p, (unsigned*)h->spaBits.p);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -354,7 +376,7 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     int* small = (int*)h->small.p;
     BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->ls, queue,
-                       qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p,
+                       qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h),
                        small + h->ticketSlot);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
@@ -379,7 +401,7 @@ int launch_row_wave_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
     const bool wf = !NUM && queue == nullptr;             // wave-first symbolic pass: rows straight from rowPtrA
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WPB), smem, h->ls, queue, qn, chunkLog2, h->dAj, h->dAx,
-                       h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p, h->dAp,
+                       h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h), h->dAp,
                        wf ? (int*)h->ub.p : (int*)nullptr,
                        wf ? (unsigned long long*)((int*)h->small.p + S_CT_SLOTS) : (unsigned long long*)nullptr,
                        (int*)h->small.p + S_ERR);
@@ -479,8 +501,8 @@ int launch_num_rank(bhs_handle* h)
         auto kern = k_num_rank<RMAX, SB>;                                                                         \
         BHS_TRY(rank_grid(h, reinterpret_cast<const void*>(kern), smem, h->m, &grid, &cl));                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), smem, h->ls, h->m, cl, h->dAp,  \
-                           h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->Cp.p, (int*)h->Cj.p,            \
-                           (value_t*)h->Cx.p, (const int*)h->pat.p, (int*)h->small.p + S_ERR);                    \
+                           h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->Cp.p, out_cj(h),                \
+                           out_cx(h), (const int*)h->pat.p, (int*)h->small.p + S_ERR);                    \
     }
     if (smallB) BHS_NUMR(true) else BHS_NUMR(false)
 #undef BHS_NUMR
@@ -522,7 +544,7 @@ int launch_row_quad_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     long long grid = std::min<long long>(((long long)qn + 3) / 4, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, h->ls, queue, qn, h->dAp, h->dAj, h->dAx, h->dBp, h->dBj,
-                       h->dBx, CpOrCnt, (int*)h->Cj.p, (value_t*)h->Cx.p, (int*)h->small.p + S_ERR);
+                       h->dBx, CpOrCnt, out_cj(h), out_cx(h), (int*)h->small.p + S_ERR);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -548,12 +570,12 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
     case KK:                                                                                                  \
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
-                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p, ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
+                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
-                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, (int*)h->Cj.p,                \
-                               (value_t*)h->Cx.p, ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
+                               h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
         break;
     switch (K) {
         BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)
@@ -692,7 +714,7 @@ int join_bins(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
-int run_pipeline_impl(bhs_handle* h)
+int pipeline_symbolic(bhs_handle* h)
 {
     h->ls = h->stream;
     const int m = h->m;
@@ -705,6 +727,7 @@ int run_pipeline_impl(bhs_handle* h)
     h->nnzCt = 0;
     h->hasC = false;
     h->rowPtrStaged = false;          // (an empty product returns early: the previous multiply's staging must not be read)
+    h->ps = bhs_handle::PipeState();
 
     BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
     if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
@@ -712,6 +735,8 @@ int run_pipeline_impl(bhs_handle* h)
         for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
         h->hasC = true;
+        h->ps.open = true;
+        h->ps.empty = true;
         return BHS_SUCCESS;
     }
     BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
@@ -824,8 +849,8 @@ int run_pipeline_impl(bhs_handle* h)
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
 
     // ------------------------------------------------------------ stage 2: symbolic
-    int symStat[kMaxBins], numStat[kMaxBins];
-    for (int b = 0; b < kMaxBins; ++b) symStat[b] = numStat[b] = -1;
+    int (&symStat)[kMaxBins] = h->ps.symStat;
+    for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
     BHS_TRY(fork_bins(h, symCount, kNumSymBins));
     if (symCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
@@ -897,59 +922,28 @@ int run_pipeline_impl(bhs_handle* h)
         if (!noUpperBound || h->specFailed) return BHS_ERR_INTERNAL;
         h->specFailed = true;
         if (h->verbose > 1) printf("  [speculative direct launch refuted on the device: general pipeline]\n");
-        return run_pipeline_impl(h);
+        return pipeline_symbolic(h);
     }
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
     if (nnzC > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
     h->nnzC = nnzC;
-    int numCount[kMaxBins], numStart[kMaxBins + 1];
-    numStart[0] = 0;
-    for (int b = 0; b < kMaxBins; ++b) {
-        numCount[b] = hs[S_NUM_COUNT + b];
-        numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
+    h->ps.noUpperBound = noUpperBound;
+    h->ps.symDirect = symDirect;
+    h->ps.useRank = useRank;
+    h->ps.laneK = laneK;
+    h->ps.numSpec = numSpec;
+    h->ps.maxCnt = hs[S_MAXCNT];
+    h->ps.rankOvf = useRank ? hs[S_OVF] : 0;
+    for (int b = 0; b < kMaxBins; ++b) h->ps.fullCount[b] = hs[S_NUM_COUNT + b];
+    memcpy(h->ps.symSums, hs + S_SYM_SUMS, sizeof(h->ps.symSums));
+    // a data set that sends more than 2 % of its rows to the overflow queue is better served by the hash bins
+    if (useRank && (long long)h->ps.rankOvf * 50 > (long long)m) h->rankState = -1;
+    if (h->extCj) {
+        if (nnzC > h->extCap) return BHS_ERR_ALLOC;
+    } else {
+        BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
+        BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     }
-    BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
-    BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
-    bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
-    int rankOvf = 0;
-    if (useRank) {
-        rankOvf = hs[S_OVF];
-        for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
-        numStart[kMaxBins] = 0;
-        numDirect = true;
-        // a data set that sends more than 2 % of its rows to the overflow queue is better served by the hash bins
-        if ((long long)rankOvf * 50 > (long long)m) h->rankState = -1;
-    }
-    // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
-    // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
-    // queue, and the few short boundary rows no longer pay for kernels of their own.
-    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
-        const int maxCnt = hs[S_MAXCNT];
-        int nb = 0;
-        for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
-        if (nb && maxCnt > 0 && (double)nnzC / m * 4.0 >= (double)numSpec.upper[nb]) {
-            for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
-            numStart[kMaxBins] = 0;
-            numCount[nb] = m;
-            numDirect = true;
-        }
-    }
-    if (!numDirect) {
-    memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
-    BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
-    {
-        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
-        BHS_TRY(timed_begin(h, "fill_queues", &ep));
-        hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
-                           (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
-                           small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
-                           (unsigned long long*)(small + S_NUM_SUMS));
-        BHS_HIP(hipGetLastError());
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-    }
-    }
-    const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
     BHS_HIP(hipEventRecord(h->ev[3], h->stream));
     h->rowPtrStaged = false;
     if (h->wantHostRowPtr) {
@@ -963,25 +957,118 @@ int run_pipeline_impl(bhs_handle* h)
         BHS_HIP(hipEventRecord(h->evCopyDone, h->copyStream));
         h->rowPtrStaged = true;
     }
+    h->ps.open = true;
+    return BHS_SUCCESS;
+}
 
-    // ------------------------------------------------------------ stage 4: numeric
+// Stage 4 on the rows [r0, r1) of A / C.  A row range is the same multiply seen through shifted row pointers (the
+// kernels index rowPtrA / rowPtrC / ub / the pattern array by row), so the handle's views are shifted for the
+// duration of the call; bins and queues are rebuilt for the range.
+int numeric_stage(bhs_handle* h, int r0, int r1)
+{
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    if (h->ps.empty) return BHS_SUCCESS;
+    if (r0 < 0 || r1 > h->m || r0 > r1) return BHS_ERR_INVALID_ARG;
+    if (r0 == r1) return BHS_SUCCESS;
+    const bool full = r0 == 0 && r1 == h->m;
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    EventPair* ep;
+    const BinSpec& numSpec = h->ps.numSpec;
+    const int laneK = h->ps.laneK;
+    const bool useRank = h->ps.useRank;
+    int (&numStat)[kMaxBins] = h->ps.numStat;
+    h->ls = h->stream;
+    // overflow rows of the rank path carry absolute row numbers: all of them with the first range
+    if (useRank && h->ps.rankOvf > 0 && !h->ps.overflowDone) {
+        h->ps.overflowDone = true;
+        h->ticketSlot = S_TICKETS + kMaxBins - 2;
+        BHS_TRY(timed_begin(h, "numeric_overflow", &ep));
+        BHS_TRY((launch_row_block<13, 512, true>(h, (const int4*)h->queue.p, h->ps.rankOvf, (int*)h->Cp.p)));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += h->ps.rankOvf;
+        h->ticketSlot = S_TICKET;
+    }
+    // ---- the range as a view
+    struct View {
+        bhs_handle* h; int m; const int* dAp; void *cp, *ub, *pat;
+        View(bhs_handle* h_, int r0_, int mR) : h(h_), m(h_->m), dAp(h_->dAp), cp(h_->Cp.p), ub(h_->ub.p), pat(h_->pat.p)
+        {
+            h->m = mR;
+            h->dAp = dAp + r0_;
+            h->Cp.p = (int*)cp + r0_;
+            h->ub.p = (int*)ub + r0_;
+            if (pat) h->pat.p = (int*)pat + (size_t)r0_ * kPatStride;
+        }
+        ~View() { h->m = m; h->dAp = dAp; h->Cp.p = cp; h->ub.p = ub; h->pat.p = pat; }
+    } view(h, r0, r1 - r0);
+    const int m = r1 - r0;
+    int numCount[kMaxBins], numStart[kMaxBins + 1];
+    int maxCnt = h->ps.maxCnt;
+    if (full) {
+        for (int b = 0; b < kMaxBins; ++b) numCount[b] = h->ps.fullCount[b];
+    } else {
+        // bins of the range: histogram of its rows (one small round trip per range)
+        int* hr = hs + S_SMALL_INTS + 2 * kMaxBins;
+        BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));     // counts, starts, cursors
+        BHS_HIP(hipMemsetAsync(small + S_NUM_SUMS, 0, sizeof(unsigned long long) * 3 * kMaxBins, h->stream));
+        BHS_HIP(hipMemsetAsync(small + S_MAXCNT, 0, sizeof(int), h->stream));
+        const long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 4);
+        hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)grid), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
+                           numSpec, small + S_NUM_COUNT, small + S_MAXCNT);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(hr + kMaxBins, small + S_MAXCNT, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        for (int b = 0; b < kMaxBins; ++b) numCount[b] = hr[b];
+        maxCnt = hr[kMaxBins];
+    }
+    numStart[0] = 0;
+    for (int b = 0; b < kMaxBins; ++b) numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
+    bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    if (useRank) {
+        for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
+        numStart[kMaxBins] = 0;
+        numDirect = true;
+    }
+    // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
+    // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
+    // queue, and the few short boundary rows no longer pay for kernels of their own.
+    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+        int nb = 0;
+        for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
+        if (nb && maxCnt > 0 && (double)h->nnzC / std::max(view.m, 1) * 4.0 >= (double)numSpec.upper[nb]) {
+            for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
+            numStart[kMaxBins] = 0;
+            numCount[nb] = m;
+            numDirect = true;
+        }
+    }
+    if (!numDirect) {
+        memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
+        BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
+                           small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
+                           (unsigned long long*)(small + S_NUM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+    }
+    if (full) h->ps.numDirectFull = numDirect;
+    h->ps.rangesRun++;
+    const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
     if (useRank) {
         BHS_TRY(timed_begin(h, "numeric_rank", &ep));
-        if (hs[S_MAXCNT] <= 128) BHS_TRY(launch_num_rank<128>(h));
+        if (h->ps.maxCnt <= 128) BHS_TRY(launch_num_rank<128>(h));
         else BHS_TRY(launch_num_rank<256>(h));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += m;
         numStat[2] = ep->stat;
-        if (rankOvf > 0) {
-            h->ticketSlot = S_TICKETS + kMaxBins - 2;
-            BHS_TRY(timed_begin(h, "numeric_overflow", &ep));
-            BHS_TRY((launch_row_block<13, 512, true>(h, (const int4*)h->queue.p, rankOvf, (int*)h->Cp.p)));
-            BHS_TRY(timed_end(h, ep));
-            h->stats[ep->stat].launches++;
-            h->stats[ep->stat].rows += rankOvf;
-            h->ticketSlot = S_TICKET;
-        }
     }
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
     if (numCount[kLaneBin]) {
@@ -998,34 +1085,44 @@ int run_pipeline_impl(bhs_handle* h)
         if (!numCount[b]) continue;
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
-        int rc = dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[b] : nullptr, numCount[b], (int*)h->Cp.p);
-        if (rc) { h->ls = h->stream; return rc; }
+        BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[b] : nullptr, numCount[b], (int*)h->Cp.p));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += numCount[b];
         numStat[b] = ep->stat;
     }
     BHS_TRY(join_bins(h));
+    return BHS_SUCCESS;
+}
+
+// End of a multiply: everything launched has run, errors raised on the device are collected, timers are read.
+int pipeline_finish(bhs_handle* h)
+{
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    h->ps.open = false;
+    if (h->ps.empty) return BHS_SUCCESS;
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipEventRecord(h->ev[4], h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+    const bool oneRange = h->ps.rangesRun == 1;
     for (int b = 1; b < kMaxBins; ++b) {
         unsigned long long v[3];
-        if (symStat[b] >= 0) {
-            memcpy(v, hs + S_SYM_SUMS + 6 * b, sizeof(v));
-            if (symDirect) { v[0] = (unsigned long long)h->nnzCt; v[2] = (unsigned long long)h->nnzA; }   // no fill pass counted them
-            StatRec& r = h->stats[symStat[b]];
+        if (h->ps.symStat[b] >= 0) {
+            memcpy(v, h->ps.symSums + 3 * b, sizeof(v));
+            if (h->ps.symDirect) { v[0] = (unsigned long long)h->nnzCt; v[2] = (unsigned long long)h->nnzA; }   // no fill pass counted them
+            StatRec& r = h->stats[h->ps.symStat[b]];
             r.products += (int64_t)v[0]; r.nnzA_rows += (int64_t)v[2];
         }
-        if (numStat[b] >= 0) {
+        if (h->ps.numStat[b] >= 0 && oneRange) {             // (per-bin sums of the last range only: reported for whole multiplies)
             memcpy(v, hs + S_NUM_SUMS + 6 * b, sizeof(v));
-            if (numDirect) { v[0] = (unsigned long long)h->nnzCt; v[1] = (unsigned long long)h->nnzC; v[2] = (unsigned long long)h->nnzA; }
-            StatRec& r = h->stats[numStat[b]];
+            if (h->ps.numDirectFull) { v[0] = (unsigned long long)h->nnzCt; v[1] = (unsigned long long)h->nnzC; v[2] = (unsigned long long)h->nnzA; }
+            StatRec& r = h->stats[h->ps.numStat[b]];
             r.products += (int64_t)v[0]; r.nnz_out += (int64_t)v[1]; r.nnzA_rows += (int64_t)v[2];
         }
     }
-
     for (int i = 0; i < 4; ++i) {
         float ms = 0;
         BHS_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
@@ -1040,23 +1137,33 @@ int run_pipeline_impl(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
+int run_pipeline_impl(bhs_handle* h)
+{
+    BHS_TRY(pipeline_symbolic(h));
+    BHS_TRY(numeric_stage(h, 0, h->m));
+    return pipeline_finish(h);
+}
+
 // Every exit of the pipeline leaves the handle quiescent: an error taken while the bins of a stage are forked
 // onto the side streams would otherwise leave kernels queued there -- still writing Cp / Cj / the counters while
 // the next bhs_spgemm starts on `stream` -- and stale launch state (ls, ticket slot) behind.
+void quiesce(bhs_handle* h)
+{
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i)
+        if (h->binStream[i]) (void)hipStreamSynchronize(h->binStream[i]);
+    if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    h->ls = h->stream;
+    h->ticketSlot = S_TICKET;
+    h->binsForked = false;
+    h->rowPtrStaged = false;
+}
+
 int run_pipeline(bhs_handle* h)
 {
     const int rc = run_pipeline_impl(h);
-    if (rc != BHS_SUCCESS) {
-        for (int i = 0; i < bhs_handle::kBinStreams; ++i)
-            if (h->binStream[i]) (void)hipStreamSynchronize(h->binStream[i]);
-        if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
-        if (h->stream) (void)hipStreamSynchronize(h->stream);
-        (void)hipGetLastError();
-        h->ls = h->stream;
-        h->ticketSlot = S_TICKET;
-        h->binsForked = false;
-        h->rowPtrStaged = false;
-    }
+    if (rc != BHS_SUCCESS) { quiesce(h); h->ps.open = false; }
     return rc;
 }
 
@@ -1229,7 +1336,7 @@ int bhs_create(bhs_handle** out, int device_count, const int* device_ids)
         if (hipStreamCreateWithFlags(&h->binStream[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming) != hipSuccess) { delete h; return BHS_ERR_LAUNCH; }
     h->ls = h->stream;
-    if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * (S_SMALL_INTS + 2 * kMaxBins), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&h->hostSmall, sizeof(int) * (S_SMALL_INTS + 4 * kMaxBins + 16), hipHostMallocDefault) != hipSuccess) {
         delete h;
         return BHS_ERR_ALLOC;
     }
@@ -1264,6 +1371,8 @@ int bhs_free_data(bhs_handle* h)
     h->dAp = h->dAj = h->dBp = h->dBj = nullptr;
     h->dAx = h->dBx = nullptr;
     h->hasData = h->hasC = h->ownAB = false;
+    h->extCj = nullptr; h->extCx = nullptr; h->extCap = 0;
+    h->ps.open = false;
     return BHS_SUCCESS;
 }
 
@@ -1403,6 +1512,64 @@ int bhs_spgemm(bhs_handle* h, int* rowPtrC_out, int64_t* nnzCt_out, int* nnzC_ou
     return BHS_SUCCESS;
 }
 
+// ---- a multiply in two halves (multi-GPU: the counts of every rank are exchanged between the halves, and the
+// numeric half runs in row ranges so that the all-gatherv of one range overlaps the numeric kernels of the next)
+int bhs_spgemm_symbolic(bhs_handle* h, int64_t* nnzCt_out, int* nnzC_out)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->hasData) return BHS_ERR_NOT_READY;
+    BHS_HIP(hipSetDevice(h->device));
+    h->wantHostRowPtr = false;
+    if (h->useSpa && (h->spaDirty || h->spaCols != h->n)) BHS_TRY(ensure_spa(h));
+    const long long savedCap = h->extCap;
+    h->extCap = h->extCj ? (1LL << 62) : 0;          // the output arrays are (re)bound between the halves: no capacity check yet
+    int rc = pipeline_symbolic(h);
+    h->extCap = savedCap;
+    if (rc) { quiesce(h); h->ps.open = false; h->spaDirty = true; return rc; }
+    if (nnzCt_out) *nnzCt_out = h->nnzCt;
+    if (nnzC_out) *nnzC_out = (int)h->nnzC;
+    return BHS_SUCCESS;
+}
+
+int bhs_spgemm_numeric(bhs_handle* h, int row_begin, int row_end)
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    if (row_begin < 0 || row_end > h->m || row_begin > row_end) return BHS_ERR_INVALID_ARG;   // (the multiply stays open)
+    BHS_HIP(hipSetDevice(h->device));
+    if (h->extCj && h->nnzC > h->extCap) return BHS_ERR_ALLOC;
+    const int rc = numeric_stage(h, row_begin, row_end);
+    if (rc) { quiesce(h); h->ps.open = false; h->spaDirty = true; }
+    return rc;
+}
+
+int bhs_spgemm_finish(bhs_handle* h, double stage_ms_out[4])
+{
+    if (!h) return BHS_ERR_INVALID_ARG;
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    BHS_HIP(hipSetDevice(h->device));
+    const int rc = pipeline_finish(h);
+    if (rc) { quiesce(h); h->spaDirty = true; return rc; }
+    if (stage_ms_out) for (int i = 0; i < 4; ++i) stage_ms_out[i] = h->stageMs[i];
+    return BHS_SUCCESS;
+}
+
+int bhs_set_output_device(bhs_handle* h, int* d_colIndC, bhs_value_t* d_valC, int64_t capacity)
+{
+    if (!h || capacity < 0 || ((d_colIndC == nullptr) != (d_valC == nullptr))) return BHS_ERR_INVALID_ARG;
+    h->extCj = d_colIndC;
+    h->extCx = (value_t*)d_valC;
+    h->extCap = d_colIndC ? (long long)capacity : 0;
+    return BHS_SUCCESS;
+}
+
+int bhs_get_stream(bhs_handle* h, void** stream_out)
+{
+    if (!h || !stream_out) return BHS_ERR_INVALID_ARG;
+    *stream_out = (void*)h->stream;
+    return BHS_SUCCESS;
+}
+
 int bhs_get_nnzC(bhs_handle* h, int* nnzC_out)
 {
     if (!h || !nnzC_out) return BHS_ERR_INVALID_ARG;
@@ -1418,8 +1585,8 @@ int bhs_get_C(bhs_handle* h, int* csrColIndC, bhs_value_t* csrValC)
     if (h->nnzC && (!csrColIndC || !csrValC)) return BHS_ERR_INVALID_ARG;
     BHS_HIP(hipSetDevice(h->device));
     if (h->nnzC) {
-        BHS_HIP(hipMemcpyAsync(csrColIndC, h->Cj.p, sizeof(int) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipMemcpyAsync(csrValC, h->Cx.p, sizeof(value_t) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(csrColIndC, out_cj(h), sizeof(int) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(csrValC, out_cx(h), sizeof(value_t) * (size_t)h->nnzC, hipMemcpyDeviceToHost, h->stream));
     }
     BHS_HIP(hipStreamSynchronize(h->stream));
     return BHS_SUCCESS;
@@ -1438,10 +1605,10 @@ int bhs_get_rowptrC(bhs_handle* h, int* csrRowPtrC)
 int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC, const bhs_value_t** d_valC)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
-    if (!h->hasC) return BHS_ERR_NOT_READY;
+    if (!h->hasC && !h->ps.open) return BHS_ERR_NOT_READY;        // (between the halves rowPtrC is already final)
     if (d_rowPtrC) *d_rowPtrC = (const int*)h->Cp.p;
-    if (d_colIndC) *d_colIndC = (const int*)h->Cj.p;
-    if (d_valC) *d_valC = (const bhs_value_t*)h->Cx.p;
+    if (d_colIndC) *d_colIndC = (const int*)out_cj(h);
+    if (d_valC) *d_valC = (const bhs_value_t*)out_cx(h);
     return BHS_SUCCESS;
 }
 

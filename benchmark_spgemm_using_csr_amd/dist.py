@@ -24,6 +24,98 @@ def row_block(m, rank, world):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
+def row_blocks_balanced(rowptr_a, col_a, rowptr_b, world):
+    """Contiguous row blocks balanced by WORK: starts[r]..starts[r+1] are rank r's rows, chosen on
+    the prefix of the per-row product counts (the upper bound compute_nnzCt produces, bhsparse_cuda.h:210-237) plus a
+    constant per row.  Equal rows for stencils, very unequal rows for power-law matrices.  Accepts numpy arrays or
+    torch tensors (any device); returns a list of world + 1 ints.  Same rule as bhs_dist_partition_rows."""
+    t = torch.as_tensor
+    ap, aj, bp = t(rowptr_a).long(), t(col_a).long(), t(rowptr_b).long()
+    m = ap.numel() - 1
+    if m <= 0:
+        return [0] * (world + 1)
+    lens_b = bp[1:] - bp[:-1]
+    w = torch.full((m,), 8, dtype=torch.int64, device=ap.device)
+    if aj.numel():
+        rows = torch.repeat_interleave(torch.arange(m, device=ap.device), ap[1:] - ap[:-1])
+        w.index_add_(0, rows, lens_b[aj])
+    pre = torch.cat([torch.zeros(1, dtype=torch.int64, device=ap.device), torch.cumsum(w, 0)])
+    total = int(pre[-1])
+    starts = [0]
+    for r in range(1, world):
+        target = total // world * r + (total % world) * r // world
+        lo = int(torch.searchsorted(pre, torch.tensor([target], dtype=torch.int64, device=ap.device))[0])
+        starts.append(min(max(lo, starts[-1]), m))
+    starts.append(m)
+    return starts
+
+
+class NativeDist(object):
+    """ctypes binding of libbhsparse_dist.so (include/bhsparse_dist.h): the multiply of this rank's row block and the
+    RCCL all-gatherv of C issued by the library itself (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on its own
+    stream, overlapped with the numeric kernels of the next row range).  `bh` is the rank's facade.bhsparse with
+    initData_device already done; the communicator is bootstrapped through torch.distributed (only to hand rank 0's
+    unique id to the other ranks) or alone when world == 1."""
+
+    def __init__(self, bh, world=1, rank=0, group=None):
+        import ctypes as C
+        import os
+        from . import _lib
+        path = os.path.join(_lib.CSRC, "libbhsparse_dist.so")
+        if not os.path.exists(path):
+            raise ImportError("%s is not built: make -C %s" % (path, _lib.CSRC))
+        self._C = C
+        self._L = C.CDLL(path)
+        L = self._L
+        vp, i64 = C.c_void_p, C.c_int64
+        L.bhs_dist_unique_id.argtypes = [C.c_char_p]
+        L.bhs_dist_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_char_p]
+        L.bhs_dist_destroy.argtypes = [vp]
+        L.bhs_dist_spgemm_allgatherv.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.POINTER(i64),
+                                                 C.POINTER(i64), C.POINTER(C.c_double)]
+        L.bhs_dist_last_link_floor_ms.argtypes = [vp]
+        L.bhs_dist_last_link_floor_ms.restype = C.c_double
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            err = L.bhs_dist_unique_id(idbuf)
+            if err:
+                raise RuntimeError("bhs_dist_unique_id: %d" % err)
+        if world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            tid = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).to(dev)
+            dist.broadcast(tid, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+            idbuf = C.create_string_buffer(bytes(tid.cpu().numpy().tobytes()), 128)
+        h = vp()
+        err = L.bhs_dist_create(C.byref(h), bh._h, world, rank, idbuf)
+        if err:
+            raise RuntimeError("bhs_dist_create: %d" % err)
+        self._d, self.world, self.rank = h, world, rank
+        self.ms = (0.0, 0.0, 0.0)
+
+    def spgemm_allgatherv(self, m_local, m_total, rowptr, col, val, sub_blocks=4):
+        """rowptr int32[m_total+1], col int32[cap], val float64[cap]: device tensors that receive the assembled C.
+        Returns (nnzCt_total, nnzC_total)."""
+        C = self._C
+        ct, cc = C.c_int64(0), C.c_int64(0)
+        ms = (C.c_double * 3)()
+        err = self._L.bhs_dist_spgemm_allgatherv(self._d, m_local, m_total, sub_blocks, C.c_void_p(rowptr.data_ptr()),
+                                                 C.c_void_p(col.data_ptr()), C.c_void_p(val.data_ptr()),
+                                                 int(col.numel()), C.byref(ct), C.byref(cc), ms)
+        if err:
+            from . import _lib
+            raise RuntimeError("bhs_dist_spgemm_allgatherv: %d (%s)" % (err, _lib.strerror(err)))
+        self.ms = tuple(ms)
+        return int(ct.value), int(cc.value)
+
+    def link_floor_ms(self):
+        return float(self._L.bhs_dist_last_link_floor_ms(self._d))
+
+    def close(self):
+        if self._d:
+            self._L.bhs_dist_destroy(self._d)
+            self._d = None
+
+
 def _all_gatherv(parts, group):
     """parts = [(full, local, sizes, offsets), ...]: for every part,
     full[offsets[r]:offsets[r]+sizes[r]] <- rank r's `local`, on every rank.

@@ -1,0 +1,68 @@
+/* bhsparse_dist.h — C-ABI of libbhsparse_dist.so: the multi-GPU layer of the
+ * CSR SpGEMM hot path (one process per GPU, RCCL over xGMI).
+ *
+ * The reference is single-device (device 0 is hard-coded, SpGEMM_cuda/
+ * bhsparse_cuda.h:100-101); this layer is new.  Rows of A -- and therefore of C
+ * -- shard across the GPUs of one node in contiguous blocks, B is replicated,
+ * every rank runs the single-GPU pipeline (include/bhsparse_hip.h) on its block
+ * and ONE all-gatherv assembles the CSR of C on every rank.  The all-gatherv is
+ * a group of point-to-point transfers (ncclGroupStart / ncclSend / ncclRecv /
+ * ncclGroupEnd): block sizes differ per rank, and on a fully connected xGMI
+ * node every GPU then sends its block straight to each of its 7 peers.
+ *
+ * A reference-style C++ driver binds it like this (tests/driver/spgemm_main.cpp,
+ * option -gpus N: one child process per GPU):
+ *     bhs_dist_unique_id(id) on rank 0, id handed to the other ranks;
+ *     bhs_create / bhs_set_data with the rank's row block of A and all of B;
+ *     bhs_dist_create(&d, handle, world, rank, id);
+ *     bhs_dist_spgemm_allgatherv(d, ...);      // multiply + assemble
+ * Plain C types only; every function returns a bhs_status (0 = success).       */
+#ifndef BHSPARSE_DIST_H
+#define BHSPARSE_DIST_H
+#include "bhsparse_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bhs_dist bhs_dist;
+#define BHS_DIST_ID_BYTES 128              /* sizeof(ncclUniqueId) */
+
+/* rank 0 creates the rendezvous id and hands the bytes to every other rank (pipe, file, MPI, torch broadcast ..) */
+BHS_API int bhs_dist_unique_id(char id_out[BHS_DIST_ID_BYTES]);
+/* collective: every rank of the job calls it with the same id; `h` is the rank's bhs_handle (its device and stream) */
+BHS_API int bhs_dist_create(bhs_dist **out, bhs_handle *h, int world, int rank, const char id[BHS_DIST_ID_BYTES]);
+BHS_API int bhs_dist_destroy(bhs_dist *d);
+
+/* Contiguous row blocks of A balanced by WORK: starts_out[r] .. starts_out[r+1] are the rows of rank r, chosen so that
+ * every block carries about the same number of intermediate products (the prefix of the per-row upper bound that
+ * compute_nnzCt produces, bhsparse_cuda.h:210-237).  For stencil matrices this is the equal-rows split; for power-law
+ * matrices it is not.  Host arrays; starts_out has world + 1 entries.                                              */
+BHS_API int bhs_dist_partition_rows(int m, const int *rowPtrA, const int *colIndA, const int *rowPtrB, int world,
+                                    int *starts_out);
+
+/* One multiply of this rank's row block (already bound to the handle with bhs_set_data[_device]) and the all-gatherv
+ * of C.  Collective.
+ *   m_local / m_total      rows of this rank's block / of the whole matrix
+ *   sub_blocks             >= 1: the numeric half runs in this many row ranges, and the transfers of range s (on a
+ *                          second stream) overlap the numeric kernels of range s + 1
+ *   d_rowPtrC / d_colIndC / d_valC   device arrays of m_total + 1 / capacity / capacity entries on THIS rank that
+ *                          receive the assembled C (every rank ends with the same content).  The rank's own block is
+ *                          written there by the numeric kernels themselves (bhs_set_output_device): no staging copy.
+ *   nnzCt_total_out, nnzC_total_out  products / entries of the whole job; may be NULL
+ *   ms_out                 [0] symbolic half + size exchange, [1] numeric half with the overlapped transfers,
+ *                          [2] wait for the remaining transfers (host wall clock, ms); may be NULL
+ * Returns after the assembled C is complete on this rank.  BHS_ERR_NNZ_OVERFLOW when nnz(C) of the job does not fit
+ * the int32 index_type, BHS_ERR_ALLOC when it exceeds `capacity`.                                                  */
+BHS_API int bhs_dist_spgemm_allgatherv(bhs_dist *d, int m_local, int m_total, int sub_blocks, int *d_rowPtrC,
+                                       int *d_colIndC, bhs_value_t *d_valC, int64_t capacity,
+                                       int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);
+
+/* per-link lower bound of the all-gatherv in ms: bytes this rank receives from its largest peer / 153 GB/s (one xGMI
+ * link; /opt/skills/guides/MI355X_MICROARCH.md), for the sizes of the last bhs_dist_spgemm_allgatherv               */
+BHS_API double bhs_dist_last_link_floor_ms(bhs_dist *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHSPARSE_DIST_H */

@@ -114,6 +114,26 @@ BHS_API int bhs_warmup(bhs_handle *h);
 BHS_API int bhs_spgemm(bhs_handle *h, int *rowPtrC_out, int64_t *nnzCt_out, int *nnzC_out,
                        double stage_ms_out[4]);
 
+/* The same multiply in two halves, for callers that place C themselves (the multi-GPU layer, include/bhsparse_dist.h):
+ *   bhs_spgemm_symbolic  stages 1-3 of bhsparse::spgemm_cuda (bhsparse.h:297-325: compute_nnzCt, binning, and here the
+ *                        exact symbolic pass + scan): afterwards nnz(C) and rowPtrC (bhs_get_C_device / bhs_get_rowptrC)
+ *                        are final and the library's own C arrays are allocated;
+ *   bhs_set_output_device (optional, between the halves) binds caller-owned device arrays of `capacity` entries: the
+ *                        numeric half then writes colIndC / valC there (entry k of C at index k) instead of into the
+ *                        library's pool -- e.g. straight into this rank's slice of the assembled global C.  Stays bound
+ *                        until bhs_free_data or a call with NULL pointers;
+ *   bhs_spgemm_numeric   stage 4 (bhsparse.h:327-335, compute_nnzC_Ct_* + copy) for rows [row_begin, row_end) of C,
+ *                        enqueued on the handle's stream (bhs_get_stream): returns without waiting for the kernels, so
+ *                        the caller can overlap the transfer of one row range with the numeric kernels of the next;
+ *   bhs_spgemm_finish    waits for everything enqueued, collects errors raised on the device, reads the stage timers.
+ * bhs_spgemm == symbolic + numeric(0, m) + finish.                                                              */
+BHS_API int bhs_spgemm_symbolic(bhs_handle *h, int64_t *nnzCt_out, int *nnzC_out);
+BHS_API int bhs_set_output_device(bhs_handle *h, int *d_colIndC, bhs_value_t *d_valC, int64_t capacity);
+BHS_API int bhs_spgemm_numeric(bhs_handle *h, int row_begin, int row_end);
+BHS_API int bhs_spgemm_finish(bhs_handle *h, double stage_ms_out[4]);
+/* the HIP stream (hipStream_t) every kernel of this handle is enqueued on */
+BHS_API int bhs_get_stream(bhs_handle *h, void **stream_out);
+
 /* replaces bhsparse::get_nnzC (bhsparse.h: get_nnzC -> bhsparse_cuda::get_nnzC). */
 BHS_API int bhs_get_nnzC(bhs_handle *h, int *nnzC_out);
 
@@ -190,6 +210,9 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     has <= 60 % as many pairs as entries (FEM-like inputs: keeps rows out of the workgroup-per-row
  *                     symbolic kernels), 2 always.  Only for B with ascending rows.  Set it before bhs_set_data for
  *                     mode 1 to be decided there.
+ *   "rank_path"       1: matrices of the wave-first class take the pattern + rank kernels (bhs_rank.hip.h: the symbolic
+ *                     pass hands every row's sorted column list to a numeric pass without hash inserts or sort);
+ *                     0 (default): measured slower than the hash kernels on poisson27pt
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)

@@ -835,3 +835,108 @@ def test_rank_path_overflow_rows_take_the_hash_kernels(oracle):
         assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
     assert "numeric_overflow" in seen[0] and "numeric_rank" not in seen[1], seen
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+def _phase_cases():
+    from benchmark_spgemm_using_csr_amd import gallery
+    rng = np.random.default_rng(5)
+    yield "p27", poisson_case("poisson27pt", 15, 14, 13)[1:], None
+    yield "p5", poisson_case("poisson5pt", 70, 60)[1:], None
+    rp, col = gallery.powerlaw_csr(30000, 30000, 110000, 2500, hubs=3)
+    yield "powerlaw", (rp, col, gallery.fill_values(len(col))), None
+    A = random_csr(700, 500, 0.03, rng, empty_rows=(0, 3, 699))
+    B = random_csr(500, 2500, 0.02, rng)
+    yield "rect", A, B
+
+
+@pytest.mark.parametrize("nranges", [1, 3, 7])
+def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges):
+    """bhs_spgemm_symbolic / bhs_spgemm_numeric(row range) / bhs_spgemm_finish == bhs_spgemm, for every kernel family
+    (direct lane / wave launches and binned queues), with the ranges issued in any order, into the library's own C
+    arrays and into caller-owned ones (bhs_set_output_device)."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    for tag, A, B in _phase_cases():
+        B = A if B is None else B
+        Ap, Aj, Ax = A
+        Bp, Bj, Bx = B
+        m, k = len(Ap) - 1, len(Bp) - 1
+        n = int(max(Bj.max() + 1, k)) if len(Bj) else k
+        ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        dA, dB = (t(Ap), t(Aj), t(Ax)), (t(Bp), t(Bj), t(Bx))
+        plats = [False] * bhmod.NUM_PLATFORMS
+        plats[bhmod.BHSPARSE_HIP] = True
+        bh = bhmod.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        assert bh.initData_device(m, k, n, len(Aj), dA[2], dA[0], dA[1], len(Bj), dB[2], dB[0], dB[1]) == 0
+        L, h = bh._lib, bh._h
+        for external in (False, True):
+            ct, cc = C.c_int64(0), C.c_int(0)
+            assert L.bhs_spgemm_symbolic(h, C.byref(ct), C.byref(cc)) == 0, tag
+            assert ct.value == oracle.nnzCt(Ap, Aj, Bp) and cc.value == ref[0][-1]
+            if external:
+                oj = torch.full((cc.value + 5,), -1, dtype=torch.int32, device=dev)
+                ox = torch.full((cc.value + 5,), -1.0, dtype=torch.float64, device=dev)
+                assert L.bhs_set_output_device(h, C.c_void_p(oj.data_ptr()), C.c_void_p(ox.data_ptr()), cc.value + 5) == 0
+            cuts = [m * s // nranges for s in range(nranges + 1)]
+            order = list(range(nranges))[::-1] if external else list(range(nranges))      # any order
+            for s in order:
+                assert L.bhs_spgemm_numeric(h, cuts[s], cuts[s + 1]) == 0, (tag, s)
+            assert L.bhs_spgemm_numeric(h, 5, 4) == bhmod._lib.BHS_ERR_INVALID_ARG
+            assert L.bhs_spgemm_finish(h, None) == 0
+            assert L.bhs_spgemm_numeric(h, 0, m) == bhmod._lib.BHS_ERR_NOT_READY      # no multiply open any more
+            Cp = bh.get_rowptrC()
+            if external:
+                Cj, Cx = oj[:cc.value].cpu().numpy(), ox[:cc.value].cpu().numpy()
+                assert bool((oj[cc.value:] == -1).all())                                # nothing written past the end
+                assert L.bhs_set_output_device(h, None, None, 0) == 0
+            else:
+                Cj = np.empty(cc.value, np.int32); Cx = np.empty(cc.value, np.float64)
+                assert bh.get_C(Cj, Cx) == 0
+            res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+            assert res["ok"], (tag, external, res)
+        # and an ordinary multiply on the same handle afterwards
+        assert bh.spgemm() == 0 and bh.get_nnzC() == ref[0][-1]
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+@pytest.mark.parametrize("sub_blocks", [1, 4])
+def test_native_allgatherv_world_size_1(oracle, sub_blocks):
+    """libbhsparse_dist.so on one GPU (world_size 1: communicator, size exchange, in-place output, row-pointer rebase,
+    numeric half in row ranges; no peers to send to): the assembled CSR equals the oracle's, twice in a row."""
+    import torch
+    from benchmark_spgemm_using_csr_amd import dist as bdist, gallery
+    dev = torch.device("cuda", 0)
+    rp, col = gallery.powerlaw_csr(20000, 20000, 80000, 2000, hubs=3)
+    val = gallery.fill_values(len(col))
+    m = len(rp) - 1
+    ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dp, dj, dx = t(rp), t(col), t(val)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.initData_device(m, m, m, len(col), dx, dp, dj, len(col), dx, dp, dj) == 0
+    nd = bdist.NativeDist(bh, world=1, rank=0)
+    cap = int(ref[0][-1]) + 17
+    frp = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    fc = torch.empty(cap, dtype=torch.int32, device=dev)
+    fv = torch.empty(cap, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        frp.fill_(-1); fc.fill_(-1); fv.fill_(-1.0)
+        ct, cc = nd.spgemm_allgatherv(m, m, frp, fc, fv, sub_blocks=sub_blocks)
+        torch.cuda.synchronize()
+        assert ct == oracle.nnzCt(rp, col, rp) and cc == ref[0][-1]
+        res = oracle.compare(ref, (frp.cpu().numpy(), fc[:cc].cpu().numpy(), fv[:cc].cpu().numpy()), rel_tol=0.0)
+        assert res["ok"], res
+    # too small a destination is an error code, not a crash
+    small_c = torch.empty(10, dtype=torch.int32, device=dev)
+    small_v = torch.empty(10, dtype=torch.float64, device=dev)
+    with pytest.raises(RuntimeError):
+        nd.spgemm_allgatherv(m, m, frp, small_c, small_v, sub_blocks=sub_blocks)
+    assert bh.spgemm() == 0                       # the handle is usable afterwards
+    nd.close()
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
