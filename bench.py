@@ -75,12 +75,13 @@ def main():
     stencil, dims, scaling = workload_dims(args.workload, world)
     nx, ny, nz = dims
     m = nx * ny * nz
-    r0, r1 = bdist.row_block(m, rank, world)
-
     # ---- synthetic inputs, generated on the device (B = A, separate buffers: main.cpp:225-232)
     Bp, Bj = gallery.poisson_csr_torch(stencil, nx, ny, nz, device=dev)
     nnzB = int(Bj.numel())
     Bx = gallery.fill_values_torch(nnzB, device=dev)
+    # row blocks balanced by work (prefix of the per-row product counts); one block at N = 1
+    starts = bdist.row_blocks_balanced(Bp, Bj, Bp, world) if world > 1 else [0, m]
+    r0, r1 = starts[rank], starts[rank + 1]
     if world == 1:
         Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
     else:
@@ -103,8 +104,36 @@ def main():
     assert err == 0, facade._lib.strerror(err)
 
     gather_out = [None]
+    # N > 1: the library's own all-gatherv (libbhsparse_dist.so: ncclSend / ncclRecv groups on its stream, row ranges
+    # of the numeric half overlapped with the transfers).  BENCH_GATHER=torch keeps the torch.distributed version.
+    native = None
+    use_native = os.environ.get("BENCH_GATHER", "native") != "torch"
+    sub_blocks = int(os.environ.get("BENCH_SUB_BLOCKS", "4"))
+    if (world > 1 or force_gather) and not args.no_gather and use_native:
+        native = bdist.NativeDist(bh, world=world, rank=rank)
+    gather_ms = [0.0, 0.0, 0.0]
+    native_totals = [0, 0]
 
     def step():
+        if native is not None:
+            if gather_out[0] is None:
+                # capacity: this rank's share times the world (weak scaling: equal shares) plus slack, grown on demand
+                e = bh.spgemm()
+                assert e == 0, facade._lib.strerror(e)
+                capn = int(bh.nnzC * world * 1.05) + 1024
+                gather_out[0] = (torch.empty(m + 1, dtype=torch.int32, device=dev),
+                                 torch.empty(capn, dtype=torch.int32, device=dev),
+                                 torch.empty(capn, dtype=torch.float64, device=dev))
+            rp, cc, vv = gather_out[0]
+            tq = time.perf_counter()
+            ct, cn = native.spgemm_allgatherv(r1 - r0, m, rp, cc, vv, sub_blocks=sub_blocks)
+            bh.time_ms = (time.perf_counter() - tq) * 1e3 - native.ms[2]      # multiply + overlapped part
+            for i in range(3):
+                gather_ms[i] += native.ms[i]
+            native_totals[0], native_totals[1] = ct, cn
+            if world == 1:
+                bh.nnzCt, bh.nnzC = ct, cn
+            return rp, cc[:cn], vv[:cn]
         e = bh.spgemm()
         if e != 0:
             raise RuntimeError("spgemm: " + facade._lib.strerror(e))
@@ -150,9 +179,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cnt = torch.tensor([bh.nnzCt, bh.nnzC], dtype=torch.int64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        nnzCt_total, nnzC_total = int(cnt[0].item()), int(cnt[1].item())
+        if native is not None:
+            nnzCt_total, nnzC_total = native_totals          # the library's size exchange already summed them
+        else:
+            cnt = torch.tensor([bh.nnzCt, bh.nnzC], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            nnzCt_total, nnzC_total = int(cnt[0].item()), int(cnt[1].item())
     else:
         nnzCt_total, nnzC_total = bh.nnzCt, bh.nnzC
     ms_per_step = elapsed / args.steps * 1e3
@@ -164,12 +196,18 @@ def main():
         assert int(rp[-1].item()) == nnzC_total and int(rp[0].item()) == 0
         assert bool((rp[1:] >= rp[:-1]).all())
         if world == 1:      # forced self-test: the gathered copy must equal the local result bit for bit
+            if native is not None:                # ... of an ordinary multiply into the library's own arrays
+                rp, cc, vv = rp.clone(), cc.clone(), vv.clone()
+                assert bh.set_output_device(None, None, 0) == 0
+                assert bh.spgemm() == 0
             pr, pc, pv = bh.get_C_device()
             assert torch.equal(rp, bdist.device_view(pr, m + 1, torch.int32, dev))
             assert torch.equal(cc, bdist.device_view(pc, bh.nnzC, torch.int32, dev))
             assert torch.equal(vv, bdist.device_view(pv, bh.nnzC, torch.float64, dev))
 
     if rank != 0:
+        if native is not None:
+            native.close()
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -313,7 +351,10 @@ def main():
         "config": {"workload": "%s %s C=A^2 (%s)" % (stencil, "x".join(map(str, dims)), args.workload),
                    "m": m, "nnzA_total": nnzB, "nnzCt": nnzCt_total, "nnzC": nnzC_total,
                    "parallelism": "rowblock%d+allgatherv" % world if world > 1 else "single",
-                   "values": "1+lcg%9 seed 20140519", "gather_in_step": bool((world > 1 or force_gather) and not args.no_gather)},
+                   "values": "1+lcg%9 seed 20140519", "gather_in_step": bool((world > 1 or force_gather) and not args.no_gather),
+                   "gather": ("native ncclSend/ncclRecv groups, %d row ranges overlapped" % sub_blocks) if native is not None
+                             else ("torch batch_isend_irecv" if (world > 1 or force_gather) and not args.no_gather else None),
+                   "row_blocks": "balanced by products" if world > 1 else "single"},
         "ms_min": round(float(np.min(step_ms)), 4), "ms_median": round(float(np.median(step_ms)), 4),
         "setup_ms": round(setup_ms, 4), "general_path": general,
         "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
@@ -321,6 +362,8 @@ def main():
         "stage_ms": [round(float(x) / args.steps, 4) for x in stage],
         "host_ms_per_step_spgemm": round(t_compute / args.steps, 4),
         "gather_ms_per_step": round(ms_per_step - t_compute / args.steps, 4) if (world > 1 or force_gather) else 0.0,
+        "gather_link_floor_ms": round(native.link_floor_ms(), 4) if native is not None else None,
+        "native_ms_per_step": [round(x / args.steps, 4) for x in gather_ms] if native is not None else None,
         "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),
         "pipeline_compulsory_bytes": int(bytes_alg_total),
         "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
@@ -328,6 +371,8 @@ def main():
         "roofline": roof, "cpu_baseline": cpu, "additional_configs": extra,
     }
     print(json.dumps(out))
+    if native is not None:
+        native.close()
     if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()

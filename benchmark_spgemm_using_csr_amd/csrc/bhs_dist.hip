@@ -24,8 +24,12 @@ struct bhs_dist {
     hipEvent_t evRange = nullptr, evDone = nullptr;
     long long* dSizes = nullptr;        // device: world x kSizeSlots int64 (sizes exchange)
     long long* hSizes = nullptr;        // pinned mirror
-    int* hCuts = nullptr;               // pinned: rowPtrC of this rank at the sub-block boundaries
     double linkFloorMs = 0.0;
+    // assembled C owned by this object (the host-pointer entry points): grow-only
+    int *ownRp = nullptr, *ownCj = nullptr;
+    bhs_value_t* ownCx = nullptr;
+    long long ownRows = 0, ownCap = 0, lastTotal = 0;
+    int lastRows = 0;
 };
 
 namespace {
@@ -108,6 +112,9 @@ int bhs_dist_destroy(bhs_dist* d)
     if (d->evDone) (void)hipEventDestroy(d->evDone);
     if (d->dSizes) (void)hipFree(d->dSizes);
     if (d->hSizes) (void)hipHostFree(d->hSizes);
+    if (d->ownRp) (void)hipFree(d->ownRp);
+    if (d->ownCj) (void)hipFree(d->ownCj);
+    if (d->ownCx) (void)hipFree(d->ownCx);
     delete d;
     return BHS_SUCCESS;
 }
@@ -141,7 +148,17 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
                                bhs_value_t* d_valC, int64_t capacity, int64_t* nnzCt_total_out,
                                int64_t* nnzC_total_out, double ms_out[3])
 {
-    if (!d || m_local < 0 || m_total < m_local || !d_rowPtrC || capacity < 0) return BHS_ERR_INVALID_ARG;
+    if (!d || m_local < 0 || m_total < m_local || capacity < 0) return BHS_ERR_INVALID_ARG;
+    const bool own = d_rowPtrC == nullptr;            // host-pointer callers: the assembled C lives in this object
+    if (own) {
+        if ((long long)m_total + 1 > d->ownRows) {
+            if (d->ownRp) (void)hipFree(d->ownRp);
+            d->ownRp = nullptr; d->ownRows = 0;
+            if (hipMalloc((void**)&d->ownRp, sizeof(int) * ((size_t)m_total + 1)) != hipSuccess) return BHS_ERR_ALLOC;
+            d->ownRows = (long long)m_total + 1;
+        }
+        d_rowPtrC = d->ownRp;
+    }
     const int S = std::max(1, std::min(sub_blocks, kMaxSub));
     const int W = d->world, me = d->rank;
     DIST_HIP(hipSetDevice(d->device));
@@ -180,6 +197,22 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
     if (rowOff[W] != m_total) return BHS_ERR_INVALID_ARG;
     const long long total = nnzOff[W];
     if (total > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
+    if (own) {
+        if (total > d->ownCap) {
+            if (d->ownCj) (void)hipFree(d->ownCj);
+            if (d->ownCx) (void)hipFree(d->ownCx);
+            d->ownCj = nullptr; d->ownCx = nullptr; d->ownCap = 0;
+            const size_t cap = (size_t)std::max<long long>(total, 1);
+            if (hipMalloc((void**)&d->ownCj, sizeof(int) * cap) != hipSuccess ||
+                hipMalloc((void**)&d->ownCx, sizeof(bhs_value_t) * cap) != hipSuccess) return BHS_ERR_ALLOC;
+            d->ownCap = (long long)cap;
+        }
+        d_colIndC = d->ownCj;
+        d_valC = d->ownCx;
+        capacity = d->ownCap;
+    }
+    d->lastTotal = total;
+    d->lastRows = m_total;
     if (total > capacity || (total > 0 && (!d_colIndC || !d_valC))) return BHS_ERR_ALLOC;
     // per-link floor: the largest block this rank receives over one link
     long long worst = 0;
@@ -244,5 +277,28 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
 }
 
 double bhs_dist_last_link_floor_ms(bhs_dist* d) { return d ? d->linkFloorMs : 0.0; }
+
+int bhs_dist_spgemm_allgatherv_host(bhs_dist* d, int m_local, int m_total, int sub_blocks, int* rowPtrC_out,
+                                    int64_t* nnzCt_total_out, int64_t* nnzC_total_out, double ms_out[3])
+{
+    if (!d) return BHS_ERR_INVALID_ARG;
+    DIST_TRY(bhs_dist_spgemm_allgatherv(d, m_local, m_total, sub_blocks, nullptr, nullptr, nullptr, 0, nnzCt_total_out,
+                                        nnzC_total_out, ms_out));
+    if (rowPtrC_out) {
+        DIST_HIP(hipMemcpy(rowPtrC_out, d->ownRp, sizeof(int) * ((size_t)m_total + 1), hipMemcpyDeviceToHost));
+    }
+    return BHS_SUCCESS;
+}
+
+int bhs_dist_get_C_host(bhs_dist* d, int* csrColIndC, bhs_value_t* csrValC)
+{
+    if (!d || !d->ownRp) return BHS_ERR_NOT_READY;
+    if (d->lastTotal && (!csrColIndC || !csrValC)) return BHS_ERR_INVALID_ARG;
+    if (d->lastTotal) {
+        DIST_HIP(hipMemcpy(csrColIndC, d->ownCj, sizeof(int) * (size_t)d->lastTotal, hipMemcpyDeviceToHost));
+        DIST_HIP(hipMemcpy(csrValC, d->ownCx, sizeof(bhs_value_t) * (size_t)d->lastTotal, hipMemcpyDeviceToHost));
+    }
+    return BHS_SUCCESS;
+}
 
 }  // extern "C"

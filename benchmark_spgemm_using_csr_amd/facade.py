@@ -164,6 +164,27 @@ class bhsparse(object):
             err = self._lib.bhs_get_rowptrC(self._h, _ptr(self._rowptrC))   # reference re-copies rowPtrC here
         return err
 
+    # -- the multiply in two halves (include/bhsparse_hip.h): multi-GPU callers place C themselves
+    def spgemm_symbolic(self):
+        nnzCt, nnzC = C.c_int64(0), C.c_int(0)
+        err = self._lib.bhs_spgemm_symbolic(self._h, C.byref(nnzCt), C.byref(nnzC))
+        if err == BHSPARSE_SUCCESS:
+            self.nnzCt, self.nnzC = int(nnzCt.value), int(nnzC.value)
+        return err
+
+    def set_output_device(self, d_colIndC, d_valC, capacity):
+        return self._lib.bhs_set_output_device(self._h, _ptr(d_colIndC), _ptr(d_valC), int(capacity))
+
+    def spgemm_numeric(self, row_begin, row_end):
+        return self._lib.bhs_spgemm_numeric(self._h, int(row_begin), int(row_end))
+
+    def spgemm_finish(self):
+        st = (C.c_double * 4)()
+        err = self._lib.bhs_spgemm_finish(self._h, st)
+        if err == BHSPARSE_SUCCESS:
+            self.stage_ms = list(st)
+        return err
+
     def get_C_device(self):
         """(rowPtrC, colIndC, valC) device addresses of the last result."""
         p = [C.c_void_p(), C.c_void_p(), C.c_void_p()]

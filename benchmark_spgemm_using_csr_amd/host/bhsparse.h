@@ -37,6 +37,8 @@ public:
     // additions (not in the reference): product count and device stage times of the last spgemm()
     long long get_nnzCt() const { return _nnzCt_full; }
     const double *get_stage_ms() const { return _stage_ms; }
+    // the C-ABI handle behind this object, for the multi-GPU layer (include/bhsparse_dist.h)
+    bhs_handle *handle() const { return _h; }
 
 private:
     bool       *_spgemm_platform;

@@ -58,6 +58,14 @@ BHS_API int bhs_dist_spgemm_allgatherv(bhs_dist *d, int m_local, int m_total, in
                                        int *d_colIndC, bhs_value_t *d_valC, int64_t capacity,
                                        int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);
 
+/* The same for host-pointer callers (the reference-style driver): the assembled C is kept in device memory owned by
+ * `d`; rowPtrC_out (m_total + 1 ints, host) is filled, the entry count comes back in nnzC_total_out, and
+ * bhs_dist_get_C_host copies colIndC / valC out afterwards -- the get_nnzC / malloc / get_C sequence of the
+ * reference's driver (main.cu:123-135) at job scope.                                                              */
+BHS_API int bhs_dist_spgemm_allgatherv_host(bhs_dist *d, int m_local, int m_total, int sub_blocks, int *rowPtrC_out,
+                                            int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);
+BHS_API int bhs_dist_get_C_host(bhs_dist *d, int *csrColIndC, bhs_value_t *csrValC);
+
 /* per-link lower bound of the all-gatherv in ms: bytes this rank receives from its largest peer / 153 GB/s (one xGMI
  * link; /opt/skills/guides/MI355X_MICROARCH.md), for the sizes of the last bhs_dist_spgemm_allgatherv               */
 BHS_API double bhs_dist_last_link_floor_ms(bhs_dist *d);

@@ -8,11 +8,17 @@
 // runs unchanged on them.
 //
 //   ./spgemm -hip|-cuda|-opencl -spgemm <0|1|2|3|4|A.mtx> [B.mtx] [-seed S] [-grid NX NY [NZ]]
-//            [-keepvalues] [-nocheck] [-cpu]
+//            [-keepvalues] [-nocheck] [-cpu] [-gpus N [-ranges S]]
+// -gpus N: one child process per GPU (forked before anything touches a GPU), rows of A in N work-balanced blocks, B
+// replicated, C assembled on every rank by the library's RCCL all-gatherv (include/bhsparse_dist.h); rank 0 checks.
 // datasets (main.cu:30-53): 0 built-in 4x6*6x4 test, 1 poisson5pt 256^2, 2 poisson9pt 256^2,
 // 3 poisson7pt 51^3, 4 poisson27pt 51^3, else Matrix Market file(s).
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -22,6 +28,7 @@
 #include "../../benchmark_spgemm_using_csr_amd/host/bhsparse.h"
 #include "../../benchmark_spgemm_using_csr_amd/host/csr_sort.h"
 #include "../../benchmark_spgemm_using_csr_amd/host/mtx_reader.h"
+#include "../../include/bhsparse_dist.h"
 #include "../../oracle/ref_spgemm_oracle.h"
 
 using namespace std;
@@ -30,6 +37,7 @@ struct Options {
     uint64_t seed = 20140519ull;
     int gx = 0, gy = 0, gz = 0;
     bool keepvalues = false, check = true, cpu_time = false;
+    int gpus = 0, ranges = 4;
 };
 
 // ref_spgemm::compData (ref_spgemm.h:65-127) with the CPU oracle in place of cusp::multiply and
@@ -102,6 +110,120 @@ static int run(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const Optio
     return ok ? BHSPARSE_SUCCESS : -100;
 }
 
+// ---- -gpus N: one process per GPU -------------------------------------------------------------------------------
+static int rank_main(const CsrHost &A, const CsrHost &B, bool *platforms, int warmups, const Options &opt, int world,
+                     int rank, const vector<int> &starts, const string &idfile)
+{
+    const int m = A.num_rows, k = A.num_cols, n = B.num_cols;
+    const int r0 = starts[rank], r1 = starts[rank + 1], mloc = r1 - r0;
+    // this rank's block of A: rows [r0, r1), row pointer rebased
+    const int lo = A.row_offsets[r0], hi = A.row_offsets[r1];
+    vector<index_type> ap(mloc + 1);
+    for (int i = 0; i <= mloc; ++i) ap[i] = A.row_offsets[r0 + i] - lo;
+    vector<index_type> aj(A.column_indices.begin() + lo, A.column_indices.begin() + hi);
+    vector<value_type> ax(A.values.begin() + lo, A.values.begin() + hi);
+    CsrHost Bc = B;
+    char devs[16];
+    snprintf(devs, sizeof(devs), "%d", rank);
+    setenv("BHSPARSE_DEVICE", devs, 1);                        // the facade creates its handle on this device
+    vector<index_type> rowPtrLocal(mloc + 1);
+    bhsparse *bh_sparse = new bhsparse();
+    int err = bh_sparse->initPlatform(platforms);
+    if (err != BHSPARSE_SUCCESS) return err;
+    index_type dummy = 0;
+    value_type vdummy = 0;
+    err = bh_sparse->initData(mloc, k, n, hi - lo, ax.empty() ? &vdummy : ax.data(), ap.data(),
+                              aj.empty() ? &dummy : aj.data(), B.num_entries, Bc.values.data(), Bc.row_offsets.data(),
+                              Bc.column_indices.data(), rowPtrLocal.data());
+    if (err != BHSPARSE_SUCCESS) return err;
+    // rendezvous: rank 0 publishes the RCCL id through a file
+    char id[BHS_DIST_ID_BYTES];
+    if (rank == 0) {
+        err = bhs_dist_unique_id(id);
+        if (err != BHSPARSE_SUCCESS) return err;
+        const string tmp = idfile + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return -20;
+        fclose(f);
+        rename(tmp.c_str(), idfile.c_str());
+    } else {
+        FILE *f = nullptr;
+        for (int t = 0; t < 6000 && !(f = fopen(idfile.c_str(), "rb")); ++t) usleep(10000);
+        if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) return -21;
+        fclose(f);
+    }
+    bhs_dist *d = nullptr;
+    err = bhs_dist_create(&d, bh_sparse->handle(), world, rank, id);
+    if (err != BHSPARSE_SUCCESS) return err;
+    vector<index_type> rowPtrC(m + 1);
+    int64_t nnzCt = 0, nnzC = 0;
+    double ms[3] = {0, 0, 0};
+    for (int i = 0; i < warmups; ++i) {
+        err = bhs_dist_spgemm_allgatherv_host(d, mloc, m, opt.ranges, rowPtrC.data(), &nnzCt, &nnzC, ms);
+        if (err != BHSPARSE_SUCCESS) return err;
+    }
+    const auto t0 = chrono::steady_clock::now();
+    err = bhs_dist_spgemm_allgatherv_host(d, mloc, m, opt.ranges, rowPtrC.data(), &nnzCt, &nnzC, ms);
+    if (err != BHSPARSE_SUCCESS) return err;
+    const double t = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
+    bool ok = true;
+    if (rank == 0) {
+        cout << "[ HIP x " << world << " ] SpGEMM + all-gatherv time: " << t << " ms. Gflops = " << 2.0 * nnzCt / (t * 1e6)
+             << "  (symbolic+sizes " << ms[0] << ", numeric with overlapped transfers " << ms[1] << ", remaining transfers "
+             << ms[2] << " ms; per-link floor " << bhs_dist_last_link_floor_ms(d) << " ms)" << endl;
+        vector<index_type> col(max<int64_t>(nnzC, 1));
+        vector<value_type> val(max<int64_t>(nnzC, 1));
+        err = bhs_dist_get_C_host(d, col.data(), val.data());
+        if (err != BHSPARSE_SUCCESS) return err;
+        if (opt.check) ok = compData(A, B, m, (int)nnzC, rowPtrC.data(), col.data(), val.data(), opt.cpu_time, nnzCt);
+        cout << "{\"gpus\": " << world << ", \"nnzCt\": " << nnzCt << ", \"nnzC\": " << nnzC << ", \"pass\": "
+             << (ok ? "true" : "false") << "}" << endl;
+    }
+    bhs_dist_destroy(d);
+    bh_sparse->free_mem();
+    bh_sparse->freePlatform();
+    delete bh_sparse;
+    if (rank == 0) remove(idfile.c_str());
+    return ok ? BHSPARSE_SUCCESS : -100;
+}
+
+static int run_multi(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const Options &opt)
+{
+    const int world = opt.gpus, m = A.num_rows;
+    cout << " A: ( " << m << " by " << A.num_cols << ", nnz = " << A.num_entries << " ) " << endl;
+    cout << " B: ( " << B.num_rows << " by " << B.num_cols << ", nnz = " << B.num_entries << " ) " << endl;
+    vector<int> starts(world + 1);
+    int err = bhs_dist_partition_rows(m, A.row_offsets.data(), A.column_indices.data(), B.row_offsets.data(), world,
+                                      starts.data());
+    if (err != BHSPARSE_SUCCESS) return err;
+    cout << " row blocks (balanced by products):";
+    for (int r = 0; r <= world; ++r) cout << " " << starts[r];
+    cout << endl;
+    char idfile[64];
+    snprintf(idfile, sizeof(idfile), "/tmp/bhs_dist_id_%d", (int)getpid());
+    remove(idfile);
+    cout.flush();
+    vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        const pid_t pid = fork();                              // nothing in this process has touched a GPU yet
+        if (pid < 0) return -22;
+        if (pid == 0) {
+            const int rc = rank_main(A, B, platforms, warmups, opt, world, r, starts, idfile);
+            if (rc != BHSPARSE_SUCCESS) cout << "rank " << r << ": Found an err, code = " << rc << endl;
+            cout.flush();
+            _exit(rc == BHSPARSE_SUCCESS ? 0 : 1);
+        }
+        kids.push_back(pid);
+    }
+    int bad = 0;
+    for (pid_t p : kids) {
+        int st = 0;
+        waitpid(p, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) ++bad;
+    }
+    return bad ? -23 : BHSPARSE_SUCCESS;
+}
+
 static int benchmark_spgemm(const char *dataset_name1, const char *dataset_name2, bool *platforms, const Options &opt)
 {
     CsrHost A, B;
@@ -130,6 +252,7 @@ static int benchmark_spgemm(const char *dataset_name1, const char *dataset_name2
         fill_values(A.values, opt.seed, 0);
         fill_values(B.values, opt.seed, (uint64_t)A.num_entries);
     }
+    if (opt.gpus > 0) return run_multi(A, B, platforms, 3, opt);
     return run(A, B, platforms, 3, opt);
 }
 
@@ -145,6 +268,7 @@ static int test_small_spgemm(bool *platforms, const Options &opt)
     B.row_offsets = {0, 1, 3, 5, 5, 5, 7};
     B.column_indices = {0, 1, 3, 0, 1, 1, 3};
     for (int i = 0; i < 7; i++) B.values.push_back((value_type)(i + 1));
+    if (opt.gpus > 0) return run_multi(A, B, platforms, 0, opt);
     return run(A, B, platforms, 0, opt);
 }
 
@@ -175,6 +299,8 @@ int main(int argc, char **argv)
         } else if (o == "-keepvalues") opt.keepvalues = true;
         else if (o == "-nocheck") opt.check = false;
         else if (o == "-cpu") opt.cpu_time = true;
+        else if (o == "-gpus" && argc > argi) opt.gpus = atoi(argv[argi++]);
+        else if (o == "-ranges" && argc > argi) opt.ranges = atoi(argv[argi++]);
     }
     cout << "------------------------" << endl;
     int err = 0;

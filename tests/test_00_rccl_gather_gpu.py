@@ -42,10 +42,12 @@ def _bench_rank(workload, extra_env=None):
     return json.loads(line)
 
 
+@pytest.mark.parametrize("gather", ["native", "torch"])
 @pytest.mark.parametrize("workload", ["p27_51", "p5_256"])
-def test_rccl_allgatherv_world_size_1(workload):
-    out = _bench_rank(workload)
+def test_rccl_allgatherv_world_size_1(workload, gather):
+    out = _bench_rank(workload, {"BENCH_GATHER": gather})
     assert out["config"]["gather_in_step"] is True and out["n_gpus"] == 1
+    assert out["config"]["gather"].startswith(gather)
     assert out["gather_ms_per_step"] > 0.0
     if workload == "p27_51":
         assert out["config"]["nnzCt"] == (9 * 51 - 10) ** 3 and out["config"]["nnzC"] == (5 * 51 - 6) ** 3

@@ -200,3 +200,17 @@ int main(int argc, char** argv) {
                        timeout=120, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "nnzCt=269 nnzC=81" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,expect", [(["-spgemm", "0"], '"nnzCt": 7, "nnzC": 6'),
+                                         (["-spgemm", "4", "-ranges", "3"], '"nnzC": %d' % ((5 * 51 - 6) ** 3)),
+                                         (["-spgemm", "1", "-ranges", "5"], "RowPtrC PASS!")])
+def test_driver_gpus_option_one_process_per_gpu(driver, args, expect):
+    """-gpus N: the driver forks one process per GPU before touching one, partitions A by work, and
+    every rank assembles C with the library's RCCL all-gatherv (libbhsparse_dist.so).  One GPU on the test box, so
+    N = 1: communicator, size exchange, numeric half in row ranges, in-place output and the host copy-out run."""
+    out = _run(driver, "-hip", *args, "-gpus", "1")
+    assert "[ HIP x 1 ] SpGEMM + all-gatherv time:" in out and "row blocks (balanced by products): 0" in out
+    assert "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out and '"gpus": 1' in out and '"pass": true' in out
+    assert expect in out
