@@ -1153,7 +1153,10 @@ constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // si
 // thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
 // and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
 constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
-constexpr int wave_min_waves(int TS, bool NUM) { return !NUM || TS < 512 ? 5 : (TS >= 1024 ? 3 : BHS_LONG_WAVES); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
+#ifndef BHS_NUM_WAVES
+#define BHS_NUM_WAVES 5
+#endif
+constexpr int wave_min_waves(int TS, bool NUM) { return !NUM ? 5 : (TS < 512 ? BHS_NUM_WAVES : (TS >= 1024 ? 3 : BHS_LONG_WAVES)); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
 // otherwise (col << 32 | slot) in 64 bits.
@@ -1742,8 +1745,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                 wave_sort_and_store<LOG2TS, PACK32, 1>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
             else if (TS >= 128 && uniq <= 128)
                 wave_sort_and_store<LOG2TS, PACK32, 2>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+#ifndef BHS_NO_E4
             else if (TS >= 256 && uniq <= 256)
                 wave_sort_and_store<LOG2TS, PACK32, 4>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
+#endif
             else if (TS >= 512 && uniq <= 512)
                 wave_sort_and_store<LOG2TS, PACK32, 8>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
             else if (TS >= 1024 && uniq <= 1024)
