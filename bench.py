@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (compute-only)")
     ap.add_argument("--no-extra", action="store_true", help="N=1: skip the short runs of the other BASELINE configs")
+    ap.add_argument("--no-general", action="store_true", help="N=1: skip the second headline (general pipeline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,7 +125,12 @@ def main():
                 # capacity: this rank's share times the world (weak scaling: equal shares) plus slack, grown on demand
                 e = bh.spgemm()
                 assert e == 0, facade._lib.strerror(e)
-                capn = int(bh.nnzC * world * 1.05) + 1024
+                # capacity of the assembled C: the exact total, the SAME on every rank (a rank that fell short alone
+                # would leave the collective while its peers wait in it)
+                tot = torch.tensor([bh.nnzC], dtype=torch.int64, device=dev)
+                if world > 1:
+                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                capn = int(tot.item()) + 1024
                 gather_out[0] = (torch.empty(m + 1, dtype=torch.int32, device=dev),
                                  torch.empty(capn, dtype=torch.int32, device=dev),
                                  torch.empty(capn, dtype=torch.float64, device=dev))
@@ -302,7 +308,7 @@ def main():
     # re-runs the general pipeline), but their choice comes from bhs_set_data's scans -- `setup_ms` -- so both
     # figures are printed.
     general = None
-    if world == 1:
+    if world == 1 and not args.no_general:
         for key in ("wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 0) == 0
         for _ in range(2):

@@ -53,7 +53,8 @@ BHS_API int bhs_dist_partition_rows(int m, const int *rowPtrA, const int *colInd
  *   ms_out                 [0] symbolic half + size exchange, [1] numeric half with the overlapped transfers,
  *                          [2] wait for the remaining transfers (host wall clock, ms); may be NULL
  * Returns after the assembled C is complete on this rank.  BHS_ERR_NNZ_OVERFLOW when nnz(C) of the job does not fit
- * the int32 index_type, BHS_ERR_ALLOC when it exceeds `capacity`.                                                  */
+ * the int32 index_type, BHS_ERR_ALLOC when it exceeds `capacity` -- pass the SAME capacity on every rank: both
+ * conditions are then decided identically everywhere, before any transfer is posted.                                               */
 BHS_API int bhs_dist_spgemm_allgatherv(bhs_dist *d, int m_local, int m_total, int sub_blocks, int *d_rowPtrC,
                                        int *d_colIndC, bhs_value_t *d_valC, int64_t capacity,
                                        int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);

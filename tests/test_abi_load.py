@@ -68,3 +68,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         _lib.load()
+
+
+def test_dist_library_exports_every_declared_symbol(hiplib):
+    """libbhsparse_dist.so (include/bhsparse_dist.h): the multi-GPU layer loads next to the core library and exports
+    every entry the header declares; no RCCL call is made here (no GPU)."""
+    hdr = os.path.join(os.path.dirname(_lib.HEADER), "bhsparse_dist.h")
+    decl = sorted(set(re.findall(r"BHS_API\s+[\w\s\*]+?\b(bhs_dist_\w+)\s*\(", open(hdr).read())))
+    assert len(decl) >= 7
+    so = os.path.join(_lib.CSRC, "libbhsparse_dist.so")
+    assert os.path.exists(so), "make -C %s" % _lib.CSRC
+    raw = C.CDLL(so)
+    for name in decl:
+        assert getattr(raw, name) is not None
+    # argument checks that need no device
+    assert raw.bhs_dist_destroy(None) == _lib.BHS_ERR_INVALID_ARG
+    out = (C.c_int * 3)()
+    assert raw.bhs_dist_partition_rows(-1, None, None, None, 2, out) == _lib.BHS_ERR_INVALID_ARG
+    assert raw.bhs_dist_partition_rows(0, None, None, None, 2, out) == 0 and list(out) == [0, 0, 0]

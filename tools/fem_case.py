@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 from benchmark_spgemm_using_csr_amd import gallery, facade
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40

@@ -6,7 +6,7 @@ out=$ROOT/gpurun_out/prof_$tag
 cd /tmp
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-general $@"
 timeout 120 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $ROOT/bench.py $ARGS > $out/bench_stats.json 2> $out/stats.err
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $out/pmc1 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc1.err
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -d $out/pmc2 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc2.err
