@@ -338,6 +338,7 @@ def main():
             ap2, aj2, ax2 = bp2.clone(), bj2.clone(), bx2.clone()
             m2 = int(bp2.numel()) - 1
             assert bh.initData_device(m2, m2, m2, int(aj2.numel()), ax2, ap2, aj2, int(bj2.numel()), bx2, bp2, bj2) == 0
+            assert bh.set_option("kernel_stats", 0) == 0      # (library default; the headline keeps them for the roofline)
             for _ in range(3):
                 assert bh.spgemm() == 0
             torch.cuda.synchronize()

@@ -150,6 +150,8 @@ struct bhs_handle {
     double avgRowA = 1.0, avgRowB = 1.0;
     int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
     int maxRowB = 0;
+    int kernelStats = 0;                 // per-kernel-family hipEvent pairs (bhs_get_kernel_stats): off unless asked for -- they cost
+                                         // 34 us of a 0.24 ms poisson5pt 1024^2 multiply; the four stage timers are always read
     int rankPath = 0;                    // pattern + rank kernels (bhs_rank.hip.h) for the matrices that qualify for wave-first: 0 off (default:
                                          // measured slower than the hash kernels on poisson27pt), 1 on
     int rankState = 0;                   // per data set: -1 after a multiply that sent too many rows to the overflow queue
@@ -285,6 +287,13 @@ int stat_index(bhs_handle* h, const char* name)
 
 int timed_begin(bhs_handle* h, const char* name, EventPair** out)
 {
+    if (!h->kernelStats) {                                   // no events: the record still counts launches / rows
+        static thread_local EventPair dummy;
+        dummy.a = dummy.b = nullptr;
+        dummy.stat = stat_index(h, name);
+        *out = &dummy;
+        return BHS_SUCCESS;
+    }
     if (h->evUsed == h->evPool.size()) {
         EventPair p;
         BHS_HIP(hipEventCreate(&p.a));
@@ -301,6 +310,7 @@ int timed_begin(bhs_handle* h, const char* name, EventPair** out)
 
 int timed_end(bhs_handle* h, EventPair* p)
 {
+    if (!p->b) return BHS_SUCCESS;
     BHS_HIP(hipEventRecord(p->b, h->ls));
     return BHS_SUCCESS;
 }
@@ -1660,6 +1670,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "rank_path")) { h->rankPath = (int)value; h->rankState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }

@@ -72,6 +72,8 @@ class bhsparse(object):
         if err != BHSPARSE_SUCCESS:
             return err
         self._h = h
+        # this mirror reports per-kernel times (kernel_stats()): tests and bench.py read them; C callers leave it off
+        self._lib.bhs_set_option(self._h, b"kernel_stats", 1)
         if not self.quiet:
             self._lib.bhs_set_verbose(self._h, 1)
         return BHSPARSE_SUCCESS

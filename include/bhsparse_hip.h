@@ -161,7 +161,7 @@ BHS_API int bhs_csr_sort_indices_device(bhs_handle *h, int n_row, const int *d_r
                                         bhs_value_t *d_val);
 
 /* ---- measurement ----------------------------------------------------------
- * Per-kernel-family device times of the LAST bhs_spgemm, measured with
+ * Per-kernel-family device times of the LAST bhs_spgemm (option "kernel_stats" = 1), measured with
  * hipEvents on the stream the kernels were launched on (what bench.py reports
  * as roofline.achieved; replaces the reference's never-enabled `_profiling`
  * prints, bhsparse_cuda.h:728-733).  Returns the number of records; fills up to
@@ -210,6 +210,11 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     has <= 60 % as many pairs as entries (FEM-like inputs: keeps rows out of the workgroup-per-row
  *                     symbolic kernels), 2 always.  Only for B with ascending rows.  Set it before bhs_set_data for
  *                     mode 1 to be decided there.
+ *   "kernel_stats"    1: every kernel family of a multiply is bracketed by a hipEvent pair for bhs_get_kernel_stats
+ *                     (times of the families; launches / rows are always counted); 0 (default): only the four stage
+ *                     timers are recorded -- the pairs cost 34 us of a 0.24 ms poisson5pt 1024^2 multiply, 0.16 ms of
+ *                     the 3.3 ms power-law stand-in (many bins).  The reference's own `_profiling` prints are off by
+ *                     default too (bhsparse_cuda.h:728-733).
  *   "rank_path"       1: matrices of the wave-first class take the pattern + rank kernels (bhs_rank.hip.h: the symbolic
  *                     pass hands every row's sorted column list to a numeric pass without hash inserts or sort);
  *                     0 (default): measured slower than the hash kernels on poisson27pt
