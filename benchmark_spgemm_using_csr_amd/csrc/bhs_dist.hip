@@ -56,6 +56,48 @@ __global__ void k_gather_cuts(int S, int m_local, const int* __restrict__ rowPtr
     if (s <= S) out[s] = rowPtr[(long long)m_local * s / S];
 }
 
+// ---- transfer plan -------------------------------------------------------------------------------------------------
+// The point-to-point operations of one rank, in issue order, as plain numbers: the executor below walks it, and the CPU
+// tests replay the plans of all ranks of a job against each other (every send must meet a receive of the same size, in
+// the same order, between the same two ranks; the received pieces must tile the assembled arrays exactly once) --
+// the N > 1 transfers cannot run on the one-GPU development boxes.
+struct PlanOp { long long kind, peer, array, offset, count, group; };   // kind 0 send / 1 recv; array 0 col, 1 val, 2 rowPtr
+
+static int build_plan(int W, int me, int S, const long long* sizes /* W x kSizeSlots */, PlanOp* out, int cap)
+{
+    std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0);
+    for (int r = 0; r < W; ++r) {
+        rowOff[r + 1] = rowOff[r] + sizes[(size_t)r * kSizeSlots];
+        nnzOff[r + 1] = nnzOff[r] + sizes[(size_t)r * kSizeSlots + 2 + S];
+    }
+    auto cut_nnz = [&](int r, int s) { return sizes[(size_t)r * kSizeSlots + 2 + s]; };
+    int n = 0;
+    auto put = [&](long long kind, long long peer, long long array, long long off, long long cnt, long long grp) {
+        if (n < cap) out[n] = PlanOp{kind, peer, array, off, cnt, grp};
+        ++n;
+    };
+    for (int s = 0; s < S; ++s)
+        for (int step = 1; step < W; ++step) {                  // staggered peers: rank r sends to r + step, receives from r - step
+            const int dst = (me + step) % W, src = (me - step + W) % W;
+            const long long a = cut_nnz(me, s), b = cut_nnz(me, s + 1);
+            if (b > a) {
+                put(0, dst, 0, nnzOff[me] + a, b - a, s);
+                put(0, dst, 1, nnzOff[me] + a, b - a, s);
+            }
+            const long long ra = cut_nnz(src, s), rb = cut_nnz(src, s + 1);
+            if (rb > ra) {
+                put(1, src, 0, nnzOff[src] + ra, rb - ra, s);
+                put(1, src, 1, nnzOff[src] + ra, rb - ra, s);
+            }
+            if (s == 0) {                                       // row pointers travel with the first range
+                const long long mm = rowOff[me + 1] - rowOff[me], rm = rowOff[src + 1] - rowOff[src];
+                if (mm > 0) put(0, dst, 2, rowOff[me], mm, s);
+                if (rm > 0) put(1, src, 2, rowOff[src], rm, s);
+            }
+        }
+    return n;
+}
+
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -235,32 +277,29 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
     DIST_HIP(hipGetLastError());
     // ---- numeric half in row ranges; the transfers of range s ride the second stream while range s + 1 computes
     auto cut_row = [&](int r, int s) { return (int)((long long)(rowOff[r + 1] - rowOff[r]) * s / S); };
-    auto cut_nnz = [&](int r, int s) { return d->hSizes[(size_t)r * kSizeSlots + 2 + s]; };
+    std::vector<PlanOp> plan;
+    if (W > 1) {
+        plan.resize((size_t)S * (W - 1) * 6);
+        const int np = build_plan(W, me, S, d->hSizes, plan.data(), (int)plan.size());
+        plan.resize((size_t)np);
+    }
+    size_t next = 0;
     for (int s = 0; s < S; ++s) {
         DIST_TRY(bhs_spgemm_numeric(d->h, cut_row(me, s), cut_row(me, s + 1)));
         if (W == 1) continue;
         DIST_HIP(hipEventRecord(d->evRange, d->hstream));
         DIST_HIP(hipStreamWaitEvent(d->cstream, d->evRange, 0));
         DIST_NCCL(ncclGroupStart());
-        for (int step = 1; step < W; ++step) {                  // staggered peers: rank r sends to r + step, receives from r - step
-            const int dst = (me + step) % W, src = (me - step + W) % W;
-            const long long a = cut_nnz(me, s), b = cut_nnz(me, s + 1);
-            if (b > a) {
-                DIST_NCCL(ncclSend(d_colIndC + nnzOff[me] + a, (size_t)(b - a), ncclInt32, dst, d->comm, d->cstream));
-                DIST_NCCL(ncclSend(d_valC + nnzOff[me] + a, (size_t)(b - a) * sizeof(bhs_value_t), ncclInt8, dst, d->comm, d->cstream));
-            }
-            const long long ra = cut_nnz(src, s), rb = cut_nnz(src, s + 1);
-            if (rb > ra) {
-                DIST_NCCL(ncclRecv(d_colIndC + nnzOff[src] + ra, (size_t)(rb - ra), ncclInt32, src, d->comm, d->cstream));
-                DIST_NCCL(ncclRecv(d_valC + nnzOff[src] + ra, (size_t)(rb - ra) * sizeof(bhs_value_t), ncclInt8, src, d->comm, d->cstream));
-            }
-            if (s == 0) {                                       // row pointers travel with the first range
-                if (m_local > 0)
-                    DIST_NCCL(ncclSend(d_rowPtrC + rowOff[me], (size_t)m_local, ncclInt32, dst, d->comm, d->cstream));
-                const long long rm = rowOff[src + 1] - rowOff[src];
-                if (rm > 0)
-                    DIST_NCCL(ncclRecv(d_rowPtrC + rowOff[src], (size_t)rm, ncclInt32, src, d->comm, d->cstream));
-            }
+        for (; next < plan.size() && plan[next].group == s; ++next) {
+            const PlanOp& op = plan[next];
+            void* ptr;
+            size_t count;
+            ncclDataType_t type = ncclInt32;
+            if (op.array == 0) { ptr = d_colIndC + op.offset; count = (size_t)op.count; }
+            else if (op.array == 1) { ptr = d_valC + op.offset; count = (size_t)op.count * sizeof(bhs_value_t); type = ncclInt8; }
+            else { ptr = d_rowPtrC + op.offset; count = (size_t)op.count; }
+            if (op.kind == 0) DIST_NCCL(ncclSend(ptr, count, type, (int)op.peer, d->comm, d->cstream));
+            else DIST_NCCL(ncclRecv(ptr, count, type, (int)op.peer, d->comm, d->cstream));
         }
         DIST_NCCL(ncclGroupEnd());
     }
@@ -277,6 +316,20 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
 }
 
 double bhs_dist_last_link_floor_ms(bhs_dist* d) { return d ? d->linkFloorMs : 0.0; }
+
+int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t* rows, const int64_t* cuts, int64_t* ops_out, int cap_ops)
+{
+    if (world < 1 || rank < 0 || rank >= world || sub_blocks < 1 || sub_blocks > kMaxSub || !rows || !cuts) return BHS_ERR_INVALID_ARG;
+    std::vector<long long> sizes((size_t)world * kSizeSlots, 0);
+    for (int r = 0; r < world; ++r) {
+        sizes[(size_t)r * kSizeSlots] = rows[r];
+        for (int s = 0; s <= sub_blocks; ++s) sizes[(size_t)r * kSizeSlots + 2 + s] = cuts[(size_t)r * (sub_blocks + 1) + s];
+    }
+    std::vector<PlanOp> plan((size_t)std::max(cap_ops, 0));
+    const int n = build_plan(world, rank, sub_blocks, sizes.data(), plan.data(), (int)plan.size());
+    for (int i = 0; i < n && i < cap_ops; ++i) memcpy(ops_out + (size_t)i * 6, &plan[i], sizeof(PlanOp));
+    return n;
+}
 
 int bhs_dist_spgemm_allgatherv_host(bhs_dist* d, int m_local, int m_total, int sub_blocks, int* rowPtrC_out,
                                     int64_t* nnzCt_total_out, int64_t* nnzC_total_out, double ms_out[3])

@@ -579,6 +579,11 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
             }
             if (tid < 2) sm.counter[tid] = 0;
             __syncthreads();
+            // The whole row in one window whose table cannot overflow (need = exact nnz / upper bound <= CAP): the fill
+            // level needs no watching, so the per-batch wave reduction, LDS atomic and block barrier go away and the
+            // new keys are added up once at the end of the row (most rows of the workgroup bins are of this kind).
+            const bool fits = full && need <= CAP;
+            int accNew = 0;
 
             for (int ca = a0; ca < a1; ca += BLOCK) {
                 if (sm.counter[1]) break;                       // uniform: read after a barrier
@@ -656,6 +661,11 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                             if (NUM && !ovf) unsafeAtomicAdd(&sm.vals[h], (acc_t)avu[u] * (acc_t)bxu[u]);
                         }
                     }
+                    if (fits) {
+                        accNew += myNew;
+                        if (ovf) sm.counter[1] = 1;                 // (cannot happen while need <= CAP holds; ends in S_ERR)
+                        continue;
+                    }
                     // ---- fill level after this batch (one LDS atomic per wave)
                     const int wNew = wave_sum_dpp(myNew);
                     const unsigned long long anyOvf = __ballot(ovf);
@@ -667,6 +677,10 @@ __global__ __launch_bounds__(BLOCK) void k_row_block(
                     if (sm.counter[1]) break;                       // uniform
                 }
                 __syncthreads();                                    // sIncl/sBase are rewritten by the next chunk
+            }
+            if (fits) {
+                const int wNew = wave_sum_dpp(accNew);
+                if (lane == 0 && wNew) atomicAdd(&sm.counter[0], wNew);
             }
             __syncthreads();
             const int uniq = sm.counter[0];

@@ -67,6 +67,14 @@ BHS_API int bhs_dist_spgemm_allgatherv_host(bhs_dist *d, int m_local, int m_tota
                                             int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);
 BHS_API int bhs_dist_get_C_host(bhs_dist *d, int *csrColIndC, bhs_value_t *csrValC);
 
+/* The point-to-point operations bhs_dist_spgemm_allgatherv issues on `rank`, in order, for a job whose ranks own
+ * rows[r] rows and whose rowPtrC at the sub-block boundaries are cuts[r * (sub_blocks + 1) + s]: 6 int64 per operation
+ * {kind 0 send / 1 recv, peer, array 0 colInd / 1 val / 2 rowPtr, element offset in the assembled array, element count,
+ * group = sub-block}.  Returns the number of operations (writes at most cap_ops).  No device, no communicator: the CPU
+ * tests replay the plans of all ranks against each other.                                                          */
+BHS_API int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t *rows, const int64_t *cuts,
+                          int64_t *ops_out, int cap_ops);
+
 /* per-link lower bound of the all-gatherv in ms: bytes this rank receives from its largest peer / 153 GB/s (one xGMI
  * link; /opt/skills/guides/MI355X_MICROARCH.md), for the sizes of the last bhs_dist_spgemm_allgatherv               */
 BHS_API double bhs_dist_last_link_floor_ms(bhs_dist *d);

@@ -148,3 +148,56 @@ def test_allgatherv_uneven_power_law_blocks_world3(oracle, tmp_path):
         z = np.load(os.path.join(str(tmp_path), "u%d.npz" % r))
         assert np.array_equal(z["rp"], Cp.astype(np.int32)) and np.array_equal(z["cc"], Cj) and np.array_equal(z["vv"], Cx)
         assert z["rows"].sum() == m and z["rows"].max() > 2 * z["rows"].min()
+
+
+@pytest.mark.parametrize("world,S", [(2, 1), (2, 4), (3, 3), (5, 4), (8, 4), (8, 16)])
+def test_native_allgatherv_plans_match_across_ranks(world, S):
+    """The native all-gatherv's point-to-point plan (bhs_dist_plan: what bhs_dist_spgemm_allgatherv issues inside its
+    ncclGroupStart / End pairs) replayed for ALL ranks of a job on the CPU: between any two ranks the k-th send meets the
+    k-th receive with the same array, size and group; every rank's receives plus its own block tile the assembled
+    arrays exactly once; empty blocks and empty sub-blocks are skipped on both sides."""
+    import ctypes as C
+    from benchmark_spgemm_using_csr_amd import _lib
+    so = os.path.join(_lib.CSRC, "libbhsparse_dist.so")
+    if not os.path.exists(so):
+        pytest.skip("libbhsparse_dist.so not built")
+    L = C.CDLL(so)
+    rng = np.random.default_rng(100 * world + S)
+    for trial in range(6):
+        rows = rng.integers(0, 50, world).astype(np.int64)
+        if trial == 0:
+            rows[rng.integers(0, world)] = 0                       # a rank without rows
+        cuts = np.zeros((world, S + 1), np.int64)
+        for r in range(world):
+            per = rng.integers(0, 40, S) * (rows[r] > 0)
+            if trial == 1:
+                per[rng.integers(0, S)] = 0                        # an empty sub-block
+            cuts[r, 1:] = np.cumsum(per)
+        row_off = np.concatenate([[0], np.cumsum(rows)])
+        nnz_off = np.concatenate([[0], np.cumsum(cuts[:, -1])])
+        plans = []
+        for r in range(world):
+            buf = (C.c_int64 * (6 * 6 * S * world))()
+            n = L.bhs_dist_plan(world, r, S, rows.ctypes.data_as(C.c_void_p), cuts.ctypes.data_as(C.c_void_p), buf,
+                                6 * S * world)
+            assert 0 <= n <= 6 * S * world
+            plans.append(np.array(buf[:6 * n], np.int64).reshape(n, 6))
+        for x in range(world):
+            for y in range(world):
+                if x == y:
+                    continue
+                sends = [tuple(op[2:]) for op in plans[x] if op[0] == 0 and op[1] == y]
+                recvs = [tuple(op[2:]) for op in plans[y] if op[0] == 1 and op[1] == x]
+                assert sends == recvs, (x, y, sends, recvs)        # same arrays, offsets, counts, groups, same order
+        for r in range(world):
+            for array, total, own in ((0, nnz_off[-1], (nnz_off[r], nnz_off[r + 1])),
+                                      (1, nnz_off[-1], (nnz_off[r], nnz_off[r + 1])),
+                                      (2, row_off[-1], (row_off[r], row_off[r + 1]))):
+                cover = np.zeros(int(total), np.int32)
+                cover[own[0]:own[1]] += 1
+                for op in plans[r]:
+                    if op[0] == 1 and op[2] == array:
+                        cover[op[3]:op[3] + op[4]] += 1
+                assert (cover == 1).all(), (r, array)
+            groups = plans[r][:, 5]
+            assert (np.diff(groups) >= 0).all()                    # issued group by group
