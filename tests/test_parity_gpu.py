@@ -849,8 +849,9 @@ def _phase_cases():
     yield "rect", A, B
 
 
+@pytest.mark.parametrize("rank_path", [0, 1])
 @pytest.mark.parametrize("nranges", [1, 3, 7])
-def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges):
+def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
     """bhs_spgemm_symbolic / bhs_spgemm_numeric(row range) / bhs_spgemm_finish == bhs_spgemm, for every kernel family
     (direct lane / wave launches and binned queues), with the ranges issued in any order, into the library's own C
     arrays and into caller-owned ones (bhs_set_output_device)."""
@@ -870,6 +871,7 @@ def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges):
         plats[bhmod.BHSPARSE_HIP] = True
         bh = bhmod.bhsparse()
         assert bh.initPlatform(plats) == 0
+        assert bh.set_option("rank_path", rank_path) == 0          # (only the wave-first class takes it)
         assert bh.initData_device(m, k, n, len(Aj), dA[2], dA[0], dA[1], len(Bj), dB[2], dB[0], dB[1]) == 0
         L, h = bh._lib, bh._h
         for external in (False, True):
