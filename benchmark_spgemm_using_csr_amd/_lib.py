@@ -53,6 +53,7 @@ SYMBOLS = {
     "bhs_csr_sort_indices_device": (_i, [_vp, _i, _vp, _vp, _vp]),
     "bhs_get_kernel_stats": (_i, [_vp, C.POINTER(KernelStat), _i]),
     "bhs_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "bhs_get_info": (_i, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "bhs_strerror": (C.c_char_p, [_i]),
     "bhs_version": (C.c_char_p, []),
 }
@@ -63,7 +64,7 @@ _lib = None
 _libs = {}
 
 
-SOURCES = ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_rank.hip.h", "bhs_wave.hip.h", "bhs_dist.hip.h")
+SOURCES = ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_rank.hip.h", "bhs_hub.hip.h", "bhs_wave.hip.h")
 
 
 def source_digest():

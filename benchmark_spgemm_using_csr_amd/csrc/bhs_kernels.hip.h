@@ -68,15 +68,19 @@ struct BinSpec {                    // bin b >= 2 holds rows with upper[b-1] < v
     int nbins;                      // bin 1 ("quad" bin): 0 < v <= quadMax and at most kQuadMaxA entries in the A row
     int quadMax;                    // 0 disables the quad bin
     int laneMax, laneMaxA;          // lane bin (kLaneBin, k_row_lane): 0 < v <= laneMax and at most laneMaxA entries in the A row
+    int hubMin;                     // hub bin (kHubBin, bhs_hub.hip.h): rows with at least hubMin products; 0 disables
     int upper[kMaxBins];            // upper[1] is 0: the size ladder starts at bin 2
 };
 constexpr int kLaneBin = kMaxBins - 1;   // outside every size ladder (ladders have at most 12 bins)
+constexpr int kHubBin = kMaxBins - 2;    // rows split across workgroups, whatever their size-ladder bin would be
 constexpr int kQuadMaxA = 16;       // a 16-lane quarter wave holds one A entry per lane
 
 // qv: the quantity the quad bin's 64-slot quarter tables are sized by (products / entries).  It differs from v
 // only for symbolic bins keyed by the compressed pair count, where the quad kernel still walks plain products.
-__device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA, int qv)
+// prod: the row's product count (upper bound), the key of the hub bin in both stages.
+__device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA, int qv, int prod)
 {
+    if (s.hubMin > 0 && v > 0 && prod >= s.hubMin) return kHubBin;
     if (qv > 0 && qv <= s.laneMax && nA <= s.laneMaxA) return kLaneBin;
     if (qv > 0 && qv <= s.quadMax && nA <= kQuadMaxA) return 1;
     int b = 0;
@@ -98,7 +102,6 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m)   // number of set 
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
 
-__device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA) { return bin_of(s, v, nA, v); }
 
 __device__ __forceinline__ int wave_sum(int v) { return wave_sum_dpp(v); }
 
@@ -111,6 +114,12 @@ __device__ __forceinline__ int wave_sum(int v) { return wave_sum_dpp(v); }
 // rows each lane group keeps in flight: short rows (G <= 8 lanes per row: poisson5pt, web graphs) are pure
 // latency, 8 rows hide it (poisson5pt 1024^2: 0.109 -> 0.066 ms); longer rows are gather-bound and 4 is best
 __host__ __device__ constexpr int ub_rows_in_flight(int G) { return G <= 8 ? 8 : 4; }
+constexpr int kUbLongA = 512;       // A rows beyond this go to k_upper_bound_long (when the launch provides the list)
+constexpr int kLongParts = 16;      // workgroups that share one such row (also: one long B row in k_check_sorted_long)
+__host__ __device__ constexpr int long_parts(long long len)     // parts of >= 2048 entries
+{
+    return len >= 2048LL * kLongParts ? kLongParts : (len < 2048 ? 1 : (int)(len / 2048));
+}
 
 // CMP (B's pattern has been compressed, k_compress_b): the gather reads (len, pairs) of the B row from cLen
 // instead of the two row pointers, and the symbolic bin of a row is chosen by its PAIR count -- the key the
@@ -124,8 +133,12 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
                                                      unsigned long long* __restrict__ total,
                                                      int* __restrict__ binCount, BinSpec spec,
                                                      const int2* __restrict__ cLen, int* __restrict__ keyOut,
-                                                     int keyMax)
+                                                     int keyMax, int2* __restrict__ longList,
+                                                     int* __restrict__ longCount)
 {
+    // Rows of A with more than kUbLongA entries would be walked by their G lanes alone while the rest of the device
+    // idles (a 180 k-entry row: 7 ms); with a list to put them on (longList != nullptr) they are left to
+    // k_upper_bound_long, which spreads every such row over 16 workgroups.
     // The per-row work is a chain of three dependent loads (rowPtrA -> colIndA -> rowPtrB) and little
     // else, so every lane group keeps R rows in flight: all rowPtrA pairs, then all colIndA, then all
     // rowPtrB gathers are issued before the first sum is needed.
@@ -151,9 +164,13 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
             if (r < m) { a0_[k] = Ap[r]; a1_[k] = Ap[r + 1]; }
         }
     };
+    auto deferred = [&](int a0_, int a1_) { return longList != nullptr && a1_ - a0_ > kUbLongA; };
     auto load_aj = [&](const int (&a0_)[R], const int (&a1_)[R], int (&c_)[R]) {
 #pragma unroll
-        for (int k = 0; k < R; ++k) { c_[k] = -1; if (a0_[k] + g < a1_[k]) c_[k] = Aj[a0_[k] + g]; }
+        for (int k = 0; k < R; ++k) {
+            c_[k] = -1;
+            if (a0_[k] + g < a1_[k] && !deferred(a0_[k], a1_[k])) c_[k] = Aj[a0_[k] + g];
+        }
     };
     long long rbase = (long long)blockIdx.x * rows_per_block * R;
     int a0[R], a1[R], c[R], a0n[R], a1n[R];
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
         load_ap(rbase + 2 * stride, a0nn, a1nn);
 #pragma unroll
         for (int k = 0; k < R; ++k)                          // rows longer than G entries: the rest, plainly
-            for (int j = a0[k] + g + G; j < a1[k]; j += G) {
+            for (int j = a0[k] + g + G; j < (deferred(a0[k], a1[k]) ? a0[k] : a1[k]); j += G) {
                 const int cc = Aj[j];
                 int2 be;
                 if constexpr (CMP) {
@@ -214,13 +231,19 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
             }
             const long long r = rbase + k * rows_per_block + tid / G;
             if (r < m && g == G - 1) {
-                const int v = tot > 0x7fffffffLL ? 0x7fffffff : (int)tot;
-                ub[r] = v;
-                if (v == 0) cnt[r] = 0;   // ESC_0 (bhsparse_cuda.h:1582-1595): nothing else to do
-                int key = v;
-                if constexpr (CMP) { if (ctot <= keyMax) key = ctot; keyOut[r] = key; }
-                atomicAdd(&hist[bin_of(spec, key, a1[k] - a0[k], v)], 1);
-                mySum += (unsigned long long)tot;
+                if (deferred(a0[k], a1[k])) {
+                    const int np = long_parts(a1[k] - a0[k]);           // one list entry {row, part, parts} per part
+                    const int at = atomicAdd(longCount, np);
+                    for (int p = 0; p < np; ++p) longList[at + p] = make_int2((int)r, p | (np << 8));
+                } else {
+                    const int v = tot > 0x7fffffffLL ? 0x7fffffff : (int)tot;
+                    ub[r] = v;
+                    if (v == 0) cnt[r] = 0;   // ESC_0 (bhsparse_cuda.h:1582-1595): nothing else to do
+                    int key = v;
+                    if constexpr (CMP) { if (ctot <= keyMax) key = ctot; keyOut[r] = key; }
+                    atomicAdd(&hist[bin_of(spec, key, a1[k] - a0[k], v, v)], 1);
+                    mySum += (unsigned long long)tot;
+                }
             }
         }
         // ---- rotate the pipeline
@@ -231,6 +254,69 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
     __syncthreads();
     if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
     if (tid == 0 && bsum) atomicAdd(total, bsum);
+}
+
+// The rows k_upper_bound left on its list, one entry per (row, part): a workgroup sums one part of one row into
+// part[]; k_upper_bound_long_finish adds a row's parts up and does what the leader lane does for a short row.
+template <bool CMP>
+__global__ __launch_bounds__(256) void k_upper_bound_long(const int2* __restrict__ longList,
+                                                          const int* __restrict__ longCount,
+                                                          const int* __restrict__ Ap, const int* __restrict__ Aj,
+                                                          const int* __restrict__ Bp, const int2* __restrict__ cLen,
+                                                          long long* __restrict__ part)
+{
+    __shared__ long long ws[4], wc[4];
+    const int tid = threadIdx.x;
+    const int items = *longCount;
+    for (int v = blockIdx.x; v < items; v += gridDim.x) {
+        const int2 it = longList[v];
+        const int r = it.x, p = it.y & 255, np = it.y >> 8;
+        const long long a0 = Ap[r], len = Ap[r + 1] - a0;
+        const long long j0 = a0 + len * p / np, j1 = a0 + len * (p + 1) / np;
+        long long s = 0, cs = 0;
+        for (long long j = j0 + tid; j < j1; j += 256) {
+            const int cc = Aj[j];
+            int2 be;
+            if constexpr (CMP) { be = cLen[cc]; s += be.x; cs += be.y; }
+            else { __builtin_memcpy(&be, Bp + cc, sizeof(be)); s += be.y - be.x; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); cs += __shfl_xor(cs, o, 64); }
+        if ((tid & 63) == 0) { ws[tid >> 6] = s; wc[tid >> 6] = cs; }
+        __syncthreads();
+        if (tid == 0) {
+            part[2 * (long long)v] = ws[0] + ws[1] + ws[2] + ws[3];
+            part[2 * (long long)v + 1] = wc[0] + wc[1] + wc[2] + wc[3];
+        }
+        __syncthreads();
+    }
+}
+
+template <bool CMP>
+__global__ __launch_bounds__(256) void k_upper_bound_long_finish(const int2* __restrict__ longList,
+                                                                 const int* __restrict__ longCount,
+                                                                 const int* __restrict__ Ap,
+                                                                 const long long* __restrict__ part,
+                                                                 int* __restrict__ ub, int* __restrict__ cnt,
+                                                                 unsigned long long* __restrict__ total,
+                                                                 int* __restrict__ binCount, BinSpec spec,
+                                                                 int* __restrict__ keyOut, int keyMax)
+{
+    const int n = *longCount;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int2 it = longList[i];
+        if (it.y & 255) continue;                              // the entry of part 0 speaks for the row
+        const int r = it.x, np = it.y >> 8;
+        long long tot = 0, ctot = 0;
+        for (int p = 0; p < np; ++p) { tot += part[2 * (long long)(i + p)]; ctot += part[2 * (long long)(i + p) + 1]; }
+        const int v = tot > 0x7fffffffLL ? 0x7fffffff : (int)tot;
+        ub[r] = v;
+        if (v == 0) cnt[r] = 0;
+        int key = v;
+        if constexpr (CMP) { if (ctot <= keyMax) key = (int)ctot; keyOut[r] = key; }
+        atomicAdd(&binCount[bin_of(spec, key, Ap[r + 1] - Ap[r], v, v)], 1);
+        atomicAdd(total, (unsigned long long)tot);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -277,7 +363,7 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
                 a0 = Ap[row];
                 a1 = Ap[row + 1];
                 ubv = ub[row];
-                b = bin_of(spec, v, a1 - a0, FROM_ROWPTR ? v : ubv);   // (symbolic keys may be pair counts: quad bin by products)
+                b = bin_of(spec, v, a1 - a0, FROM_ROWPTR ? v : ubv, ubv);   // (symbolic keys may be pair counts: quad bin by products)
             }
             // all 64 lanes take part (rows past m carry b == 0 and never match a leader's bin)
             unsigned long long todo = __ballot(b > 0);
@@ -344,7 +430,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restric
                                                      const int* __restrict__ Ap,
                                                      long long* __restrict__ blockSum,
                                                      int* __restrict__ binCount, BinSpec spec,
-                                                     int* __restrict__ maxCnt)
+                                                     int* __restrict__ maxCnt, const int* __restrict__ ub)
 {
     __shared__ int hist[kMaxBins];
     __shared__ long long wsum[4];
@@ -362,7 +448,7 @@ __global__ __launch_bounds__(256) void k_scan_reduce(int m, const int* __restric
             const int v = cnt[idx];
             s += v;
             mx = max(mx, v);
-            const int b = bin_of(spec, v, Ap[idx + 1] - Ap[idx]);
+            const int b = bin_of(spec, v, Ap[idx + 1] - Ap[idx], v, spec.hubMin > 0 ? ub[idx] : 0);
             if (b > 0) atomicAdd(&hist[b], 1);
         }
     }
@@ -432,7 +518,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(int m, int* __restrict__ cnt
 // numeric-bin histogram and longest row of a ROW RANGE of C (rowPtrC is final): the scan delivers these for the
 // whole matrix, bhs_spgemm_numeric needs them per range
 __global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__ Cp, const int* __restrict__ Ap,
-                                                  BinSpec spec, int* __restrict__ binCount, int* __restrict__ maxCnt)
+                                                  BinSpec spec, int* __restrict__ binCount, int* __restrict__ maxCnt,
+                                                  const int* __restrict__ ub)
 {
     __shared__ int hist[kMaxBins];
     __shared__ int wmax[4];
@@ -443,7 +530,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + tid; i < m; i += (long long)gridDim.x * 256) {
         const int v = Cp[i + 1] - Cp[i];
         mx = max(mx, v);
-        const int b = bin_of(spec, v, Ap[i + 1] - Ap[i]);
+        const int b = bin_of(spec, v, Ap[i + 1] - Ap[i], v, spec.hubMin > 0 ? ub[i] : 0);
         if (b > 0) atomicAdd(&hist[b], 1);
     }
 #pragma unroll
@@ -480,14 +567,42 @@ __global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ 
 // the compressed symbolic pass and the column-window path rely on strictly ascending rows).  G = 2^logG lanes per
 // row walk it with coalesced loads; neighbours are compared inside a row only, so no search for row boundaries
 // (the element-parallel version with a binary search at every row end took 0.93 ms on poisson27pt 128^3).
+constexpr int kSortedLongB = 4096;
 __global__ __launch_bounds__(256) void k_check_sorted(int k, int logG, const int* __restrict__ Bp,
-                                                      const int* __restrict__ Bj, int* __restrict__ flag)
+                                                      const int* __restrict__ Bj, int* __restrict__ flag,
+                                                      int2* __restrict__ longList, int* __restrict__ longCount)
 {
     const int G = 1 << logG, g = threadIdx.x & (G - 1), rpb = 256 >> logG;
     int bad = 0;
     for (long long r = (long long)blockIdx.x * rpb + (threadIdx.x >> logG); r < k; r += (long long)gridDim.x * rpb) {
         const int a0 = Bp[r], a1 = Bp[r + 1];
+        if (longList != nullptr && a1 - a0 > kSortedLongB) {
+            if (g == 0) {                                                // left to k_check_sorted_long, in parts
+                const int np = long_parts(a1 - a0);
+                const int at = atomicAdd(longCount, np);
+                for (int p = 0; p < np; ++p) longList[at + p] = make_int2((int)r, p | (np << 8));
+            }
+            continue;
+        }
         for (int e = a0 + g; e + 1 < a1; e += G) bad |= Bj[e] >= Bj[e + 1] ? 1 : 0;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// the rows k_check_sorted left on its list: one workgroup per (row, part)
+__global__ __launch_bounds__(256) void k_check_sorted_long(const int2* __restrict__ longList,
+                                                           const int* __restrict__ longCount,
+                                                           const int* __restrict__ Bp, const int* __restrict__ Bj,
+                                                           int* __restrict__ flag)
+{
+    int bad = 0;
+    const int items = *longCount;
+    for (int v = blockIdx.x; v < items; v += gridDim.x) {
+        const int2 it = longList[v];
+        const int r = it.x, p = it.y & 255, np = it.y >> 8;
+        const long long a0 = Bp[r], len = Bp[r + 1] - a0;
+        const long long e0 = a0 + len * p / np, e1 = a0 + len * (p + 1) / np;   // pairs (e, e+1), e in [e0, e1)
+        for (long long e = e0 + threadIdx.x; e < e1 && e + 1 < a0 + len; e += 256) bad |= Bj[e] >= Bj[e + 1] ? 1 : 0;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }

@@ -15,6 +15,7 @@
 #include "../../include/bhsparse_hip.h"
 #include "bhs_kernels.hip.h"
 #include "bhs_rank.hip.h"
+#include "bhs_hub.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -75,11 +76,12 @@ constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a
 constexpr int kLaneMaxK = 12;       // heads a lane keeps in registers (k_row_lane<K>: K = 4, 6, .., 12)
 constexpr int kLaneMax = kLaneMaxK * kLaneMaxK;   // products (symbolic) / entries (numeric) of a lane-bin row
 
-BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad, int laneK)
+BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad, int laneK, int hubMin)
 {
     BinSpec s;
     memset(&s, 0, sizeof(s));
     s.nbins = nbins;
+    s.hubMin = hubMin;
     s.laneMax = laneK > 0 ? kLaneMax : 0;
     s.laneMaxA = laneK;
     s.quadMax = (quad && maxLog2 >= 6) ? kQuadMax : 0;
@@ -131,6 +133,11 @@ struct bhs_handle {
     DevBuf spaRank, spaBits;             // bitmap-accumulator slots for rows beyond the LDS tables (bitmaps kept all-zero)
     int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1, ldsBitmapMinLog2 = 12;
     bool spaDirty = false;
+    // hub rows (bhs_hub.hip.h): rows with at least hubMin products are cut into items of hubItemProducts products
+    // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
+    DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
+    DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
+    int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
     int* hostSmall = nullptr;            // pinned mirror of `small`
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
     size_t hostRowPtrCap = 0;
@@ -197,7 +204,7 @@ struct bhs_handle {
         bool open = false;                // symbolic done, finish pending
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
-        int laneK = 0, rankOvf = 0, maxCnt = 0;
+        int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
         int fullCount[kMaxBins];          // numeric-bin histogram of all rows (from the scan)
@@ -220,9 +227,10 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_PAIRS = 102 /* 2 ints = u64: (block, mask) pairs of the compressed B */,
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
-       S_MAXCNT = 104 + 192 /* longest row of C */,
+       S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
        S_ZERO_END = 104 + 194,   /* everything below is zeroed at the start of every spgemm */
        S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* rows k_sym_blocks sent to the overflow queue */,
+       S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
        S_SMALL_INTS = 448 };
@@ -389,6 +397,56 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
                        qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h),
                        small + h->ticketSlot);
     BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+// Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
+template <bool NUM>
+int launch_hub(bhs_handle* h, const int4* hubQ, int nHub, int* CpOrCnt)
+{
+    const HubGeom g = hub_geom(h->n);
+    size_t freeB = 0, totalB = 0;
+    BHS_HIP(hipMemGetInfo(&freeB, &totalB));
+    const size_t perSlot = ((size_t)g.slotWords + (size_t)g.nW) * sizeof(int);
+    long long slots = (long long)(std::min(totalB / 16, freeB / 2) / perSlot);
+    if (h->hubMaxSlots > 0) slots = std::min<long long>(slots, h->hubMaxSlots);
+    slots = std::min<long long>(slots, nHub);
+    if (slots < 1) return BHS_ERR_ALLOC;
+    // every chunk of 512 A entries yields ceil(products / item) items
+    const long long cap = (long long)h->nnzA / kHubChunk + h->nnzCt / h->hubItemProducts + 2LL * nHub + 16;
+    if (cap > 0x7fffffffLL) return BHS_ERR_ALLOC;
+    BHS_TRY(ensure(h, h->hubBits, (size_t)slots * (size_t)g.slotWords * sizeof(unsigned)));
+    if (NUM) {
+        BHS_TRY(ensure(h, h->hubRank, (size_t)slots * (size_t)g.nW * sizeof(int)));
+        BHS_TRY(ensure(h, h->hubSeg, (size_t)slots * (size_t)g.seg * sizeof(int)));
+    }
+    BHS_TRY(ensure(h, h->hubItems, (size_t)cap * sizeof(int4)));
+    BHS_TRY(ensure(h, h->hubCtl, 16 * sizeof(int)));
+    int* ctl = (int*)h->hubCtl.p;                 // [0] item count, [1] ticket of mark, [2] ticket of place
+    int* err = (int*)h->small.p + S_ERR;
+    const unsigned grid = (unsigned)(h->numCU * 2);
+    for (int b0 = 0; b0 < nHub; b0 += (int)slots) {
+        const int nb = std::min<int>((int)slots, nHub - b0);
+        const int4* q = hubQ + b0;
+        BHS_HIP(hipMemsetAsync(h->hubBits.p, 0, (size_t)nb * (size_t)g.slotWords * sizeof(unsigned), h->ls));
+        BHS_HIP(hipMemsetAsync(ctl, 0, 16 * sizeof(int), h->ls));
+        hipLaunchKernelGGL(k_hub_plan, dim3((unsigned)nb * kHubPlanWG), dim3(256), 0, h->ls, q, h->dAj, h->dBp, (int4*)h->hubItems.p,
+                           ctl, (int)cap, h->hubItemProducts, NUM ? (int*)nullptr : CpOrCnt, err);
+        hipLaunchKernelGGL(k_hub_mark<NUM>, dim3(grid), dim3(kHubBlock), 0, h->ls, (const int4*)h->hubItems.p,
+                           (const int*)ctl, q, h->dAj, h->dBp, h->dBj, (unsigned*)h->hubBits.p, g.slotWords, g.nW, ctl + 1,
+                           (h->hubAggregate && h->bSorted) ? 1 : 0);
+        hipLaunchKernelGGL(k_hub_count<NUM>, dim3((unsigned)(nb * g.seg)), dim3(kHubBlock), 0, h->ls, q,
+                           (const unsigned*)h->hubBits.p, g.slotWords, g.seg, g.segW, (int*)h->hubSeg.p, CpOrCnt);
+        if constexpr (NUM) {
+            hipLaunchKernelGGL(k_hub_emit, dim3((unsigned)(nb * g.seg)), dim3(kHubBlock), 0, h->ls, q,
+                               (const unsigned*)h->hubBits.p, g.slotWords, g.nW, g.seg, g.segW, (const int*)h->hubSeg.p,
+                               (int*)h->hubRank.p, out_cj(h), out_cx(h));
+            hipLaunchKernelGGL(k_hub_place, dim3(grid), dim3(kHubBlock), 0, h->ls, (const int4*)h->hubItems.p,
+                               (const int*)ctl, q, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const unsigned*)h->hubBits.p,
+                               g.slotWords, g.nW, (const int*)h->hubRank.p, out_cx(h), ctl + 2);
+        }
+        BHS_HIP(hipGetLastError());
+    }
     return BHS_SUCCESS;
 }
 
@@ -660,18 +718,29 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
     // cover many rows each, run fewer and longer blocks (poisson5pt 1024^2: 0.066 -> 0.048 ms)
     grid = std::max<long long>(1, std::min<long long>(grid, (long long)h->numCU * (G <= 8 ? 4 : 32)));
     int* small = (int*)h->small.p;
+    // rows of A beyond kUbLongA entries (if the data set has any: maxRowA is the hint) are listed and summed by
+    // k_upper_bound_long, 16 workgroups per row
+    const bool useLong = h->maxRowA > kUbLongA;
+    int2* longList = nullptr;
+    if (useLong) {
+        const size_t cap = (size_t)h->nnzA / kUbLongA + 2;       // a listed row of len entries takes <= len / 512 entries
+        BHS_TRY(ensure(h, h->longList, cap * sizeof(int2)));
+        BHS_TRY(ensure(h, h->longPart, cap * 2 * sizeof(long long)));
+        longList = (int2*)h->longList.p;
+    }
 #define BHS_UB(GG)                                                                                       \
     case GG:                                                                                             \
         if (cmp)                                                                                         \
             hipLaunchKernelGGL((k_upper_bound<GG, true>), dim3((unsigned)grid), dim3(256), 0, h->stream, \
                                h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
                                (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
-                               (const int2*)h->cLen.p, (int*)h->symKey.p, keyMax);                       \
+                               (const int2*)h->cLen.p, (int*)h->symKey.p, keyMax, longList,              \
+                               small + S_UB_LONG);                                                       \
         else                                                                                             \
             hipLaunchKernelGGL((k_upper_bound<GG, false>), dim3((unsigned)grid), dim3(256), 0, h->stream,\
                                h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
                                (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
-                               (const int2*)nullptr, (int*)nullptr, 0);                                  \
+                               (const int2*)nullptr, (int*)nullptr, 0, longList, small + S_UB_LONG);     \
         break;
     switch (G) {
         BHS_UB(1) BHS_UB(2) BHS_UB(4) BHS_UB(8) BHS_UB(16) BHS_UB(32) BHS_UB(64)
@@ -679,6 +748,27 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
     }
 #undef BHS_UB
     BHS_HIP(hipGetLastError());
+    if (useLong) {
+        const unsigned g1 = (unsigned)(h->numCU * 4), g2 = (unsigned)std::min<size_t>(((size_t)h->nnzA / kUbLongA + 257) / 256, 1024);
+        if (cmp) {
+            hipLaunchKernelGGL(k_upper_bound_long<true>, dim3(g1), dim3(256), 0, h->stream, (const int2*)longList,
+                               (const int*)(small + S_UB_LONG), h->dAp, h->dAj, h->dBp, (const int2*)h->cLen.p,
+                               (long long*)h->longPart.p);
+            hipLaunchKernelGGL(k_upper_bound_long_finish<true>, dim3(g2), dim3(256), 0, h->stream, (const int2*)longList,
+                               (const int*)(small + S_UB_LONG), h->dAp, (const long long*)h->longPart.p, (int*)h->ub.p,
+                               (int*)h->Cp.p, (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,
+                               (int*)h->symKey.p, keyMax);
+        } else {
+            hipLaunchKernelGGL(k_upper_bound_long<false>, dim3(g1), dim3(256), 0, h->stream, (const int2*)longList,
+                               (const int*)(small + S_UB_LONG), h->dAp, h->dAj, h->dBp, (const int2*)nullptr,
+                               (long long*)h->longPart.p);
+            hipLaunchKernelGGL(k_upper_bound_long_finish<false>, dim3(g2), dim3(256), 0, h->stream, (const int2*)longList,
+                               (const int*)(small + S_UB_LONG), h->dAp, (const long long*)h->longPart.p, (int*)h->ub.p,
+                               (int*)h->Cp.p, (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,
+                               (int*)nullptr, 0);
+        }
+        BHS_HIP(hipGetLastError());
+    }
     return BHS_SUCCESS;
 }
 
@@ -759,9 +849,12 @@ int pipeline_symbolic(bhs_handle* h)
     int laneK = 0;
     if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || h->maxRowA <= kLaneMaxK))
         laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
-    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK);
-    const BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
-                                      (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 8)) ? laneK : 0);
+    // hub bin: rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
+    const int hubMin = (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25))
+                           ? h->hubMin : 0;
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK, hubMin);
+    BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
+                                (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 8)) ? laneK : 0, hubMin);
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     h->cmpActive = false;
@@ -803,6 +896,7 @@ int pipeline_symbolic(bhs_handle* h)
     const bool useRank = wfBin > 0 && h->rankPath && h->rankState >= 0 && h->maxRowA <= 64;
     if (useRank) BHS_TRY(ensure(h, h->pat, sizeof(int) * (size_t)kPatStride * (size_t)m));
     const bool noUpperBound = laneFirst || wfBin > 0;
+    if (noUpperBound) numSpec.hubMin = 0;     // (every row is bounded by maxRow(A) x maxRow(B), far below the hub bin)
     int symCount[kMaxBins], symStart[kMaxBins + 1];
     if (noUpperBound) {
         BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
@@ -873,6 +967,16 @@ int pipeline_symbolic(bhs_handle* h)
         h->stats[ep->stat].rows += symCount[kLaneBin];
         symStat[kLaneBin] = ep->stat;
     }
+    if (symCount[kHubBin]) {
+        bin_stream(h, kHubBin);
+        BHS_TRY(timed_begin(h, "symbolic_hub_rows", &ep));
+        int rc = launch_hub<false>(h, symQueue + symStart[kHubBin], symCount[kHubBin], (int*)h->Cp.p);
+        if (rc) { h->ls = h->stream; return rc; }
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[kHubBin];
+        symStat[kHubBin] = ep->stat;
+    }
     if (useRank) {
         BHS_TRY(timed_begin(h, "symbolic_sorted", &ep));
         BHS_TRY(launch_sym_sorted(h));
@@ -908,7 +1012,7 @@ int pipeline_symbolic(bhs_handle* h)
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
-                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT);
+                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
                        (long long*)h->blockSum.p, (long long*)(small + S_TOTAL_C));
     hipLaunchKernelGGL(k_scan_apply, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (int*)h->Cp.p,
@@ -943,6 +1047,7 @@ int pipeline_symbolic(bhs_handle* h)
     h->ps.laneK = laneK;
     h->ps.numSpec = numSpec;
     h->ps.maxCnt = hs[S_MAXCNT];
+    h->ps.hubRows = noUpperBound ? 0 : symCount[kHubBin];
     h->ps.rankOvf = useRank ? hs[S_OVF] : 0;
     for (int b = 0; b < kMaxBins; ++b) h->ps.fullCount[b] = hs[S_NUM_COUNT + b];
     memcpy(h->ps.symSums, hs + S_SYM_SUMS, sizeof(h->ps.symSums));
@@ -1026,7 +1131,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         BHS_HIP(hipMemsetAsync(small + S_MAXCNT, 0, sizeof(int), h->stream));
         const long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 4);
         hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)grid), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
-                           numSpec, small + S_NUM_COUNT, small + S_MAXCNT);
+                           numSpec, small + S_NUM_COUNT, small + S_MAXCNT, (const int*)h->ub.p);
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipMemcpyAsync(hr + kMaxBins, small + S_MAXCNT, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1045,7 +1150,8 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
     // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
     // queue, and the few short boundary rows no longer pay for kernels of their own.
-    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15) {
+    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+        h->ps.hubRows == 0) {
         int nb = 0;
         for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
         if (nb && maxCnt > 0 && (double)h->nnzC / std::max(view.m, 1) * 4.0 >= (double)numSpec.upper[nb]) {
@@ -1081,6 +1187,15 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         numStat[2] = ep->stat;
     }
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
+    if (numCount[kHubBin]) {
+        bin_stream(h, kHubBin);
+        BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));
+        BHS_TRY(launch_hub<true>(h, numQueue + numStart[kHubBin], numCount[kHubBin], (int*)h->Cp.p));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += numCount[kHubBin];
+        numStat[kHubBin] = ep->stat;
+    }
     if (numCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
         BHS_TRY(timed_begin(h, "numeric_lane", &ep));
@@ -1242,7 +1357,7 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipMemcpyAsync(&h->maxRowB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
     }
-    h->ubG = pow2_at_least(std::max(avgA, maxRowA / 32.0), 1, 64);
+    h->ubG = pow2_at_least(std::max(avgA, std::min(maxRowA, kUbLongA) / 32.0), 1, 64);   // (longer rows: k_upper_bound_long)
     int L = pow2_at_least(avgB, 1, 64);
     int lg = 0;
     while ((1 << lg) < L) ++lg;
@@ -1258,9 +1373,23 @@ int finish_set_data(bhs_handle* h)
         const int logG = std::min(h->logL, 6);                  // lanes per row of B: its average length
         long long grid = std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16);
         grid = std::max<long long>(grid, 1);
-        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
-                           small + S_SORTED);
-        BHS_HIP(hipGetLastError());
+        // rows of B beyond kSortedLongB entries are listed and checked by k_check_sorted_long, 16 workgroups per row
+        int2* longB = nullptr;
+        if (h->maxRowB > kSortedLongB) {
+            BHS_TRY(ensure(h, h->longList, ((size_t)h->nnzB / 2048 + 2) * sizeof(int2)));
+            longB = (int2*)h->longList.p;
+        }
+        auto check_sorted = [&]() -> int {
+            BHS_HIP(hipMemsetAsync(small + S_LONG_B, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
+                               small + S_SORTED, longB, small + S_LONG_B);
+            if (longB)
+                hipLaunchKernelGGL(k_check_sorted_long, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream,
+                                   (const int2*)longB, (const int*)(small + S_LONG_B), h->dBp, h->dBj, small + S_SORTED);
+            BHS_HIP(hipGetLastError());
+            return BHS_SUCCESS;
+        };
+        BHS_TRY(check_sorted());
         int flag = 0;
         BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
@@ -1279,9 +1408,7 @@ int finish_set_data(bhs_handle* h)
             }
             BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
             BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
-                               small + S_SORTED);
-            BHS_HIP(hipGetLastError());
+            BHS_TRY(check_sorted());
             BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             BHS_HIP(hipStreamSynchronize(h->stream));
             h->bSorted = flag ? 0 : 1;          // (duplicate columns inside a row still count as "not ascending")
@@ -1405,6 +1532,8 @@ int bhs_destroy(bhs_handle* h)
     release(h->blockSum);
     release(h->small);
     release(h->spaRank);
+    release(h->longList); release(h->longPart);
+    release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
     if (h->hostRowPtr) (void)hipHostFree(h->hostRowPtr);
@@ -1675,6 +1804,10 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
+    if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "hub_slots")) { h->hubMaxSlots = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_load_pct") || !strcmp(key, "num_load_pct")) {
         if (value < 5 || value > 75) return BHS_ERR_INVALID_ARG;
@@ -1682,6 +1815,16 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
         return BHS_SUCCESS;
     }
     if (!strcmp(key, "verbose")) return bhs_set_verbose(h, (int)value);
+    return BHS_ERR_INVALID_ARG;
+}
+
+int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
+{
+    if (!h || !key || !value_out) return BHS_ERR_INVALID_ARG;
+    if (!h->hasData) return BHS_ERR_NOT_READY;
+    if (!strcmp(key, "b_sorted")) { *value_out = h->bSorted; return BHS_SUCCESS; }
+    if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
+    if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
     return BHS_ERR_INVALID_ARG;
 }
 

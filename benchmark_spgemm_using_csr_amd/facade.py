@@ -225,6 +225,14 @@ class bhsparse(object):
     def set_option(self, key, value):
         return self._lib.bhs_set_option(self._h, key.encode(), int(value))
 
+    def get_info(self, key):
+        """bhs_get_info: what the library found out about the bound data set ("b_sorted", "max_row_a", "max_row_b")"""
+        v = C.c_int64(0)
+        err = self._lib.bhs_get_info(self._h, key.encode(), C.byref(v))
+        if err:
+            raise BhsparseError("get_info(%s)" % key, err)
+        return v.value
+
     # -- bhsparse.h:151-178 / 127-149 ----------------------------------------
     def free_mem(self):
         if self._h is None:

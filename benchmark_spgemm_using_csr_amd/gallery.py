@@ -127,6 +127,24 @@ def fill_values_torch(nnz, seed=SEED, offset=0, device="cuda"):
     return (1 + hi % 9).to(torch.float64)
 
 
+def dense_rows_csr(n, per_row=8, dense=4, dense_nnz=200000, seed=SEED):
+    """Seeded sparse square pattern (about per_row uniformly random entries per row) with `dense` rows of dense_nnz
+    entries spread evenly over the matrix: in A^2 each of them carries about dense_nnz x per_row products, and every
+    row that points at one inherits its dense_nnz entries -- the hub-row case the reference hands to its
+    multi-round global merge (bhsparse_cuda.h:2270-2525).  Rows sorted and duplicate-free."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(max(per_row - 3, 1), per_row + 4, n).astype(np.int64)
+    hub = (np.arange(dense, dtype=np.int64) * n) // max(dense, 1) + n // (2 * max(dense, 1)) if dense else np.empty(0, np.int64)
+    lens[hub] = min(n, dense_nnz)
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    cols = rng.integers(0, n, rows.size)
+    key = np.unique(rows * n + cols)
+    r = key // n
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=n), out=rowptr[1:])
+    return rowptr.astype(np.int32), (key - r * n).astype(np.int32)
+
+
 def powerlaw_csr(m, n, nnz_target, max_row, seed=SEED, alpha=1.8, hubs=8, colpow=1.6):
     """Seeded power-law CSR pattern: stand-in for SuiteSparse webbase-1M when the
     file is absent.  Row lengths ~ Zipf scaled to about

@@ -221,10 +221,20 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)
+ *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
+ *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
+ *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),
+ *                     "hub_slots" (rows per batch; default: as many as fit 1/16 of the device memory)
  *   "wg_per_cu"       persistent workgroups per CU of the wave kernels (default: occupancy API)
  *   "verbose"         same as bhs_set_verbose
  * Returns BHS_ERR_INVALID_ARG for unknown keys.                               */
 BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
+
+/* What the library found out about the bound data set (after bhs_set_data[_device]):
+ *   "b_sorted"   1 when every row of B (as multiplied: after the optional sort) is strictly ascending
+ *   "max_row_a", "max_row_b"   longest row of A / B
+ * Returns BHS_ERR_INVALID_ARG for unknown keys, BHS_ERR_NOT_READY without data.  */
+BHS_API int bhs_get_info(bhs_handle *h, const char *key, int64_t *value_out);
 
 BHS_API const char *bhs_strerror(int status);
 BHS_API const char *bhs_version(void);

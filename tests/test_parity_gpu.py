@@ -465,6 +465,38 @@ def test_unsorted_B_rows_still_correct(oracle):
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
+@pytest.mark.parametrize("where", ["first_pair", "part_boundary", "last_pair", "sorted"])
+def test_long_rows_of_A_and_B_in_the_row_scans(oracle, where):
+    """Rows far beyond the lanes-per-row of the per-row scans: k_upper_bound hands A rows with more than 512 entries
+    to k_upper_bound_long, k_check_sorted hands B rows with more than 4096 entries to k_check_sorted_long (16
+    workgroups per row each).  One swapped pair anywhere in a 40 000-entry row of B must still be seen."""
+    rng = np.random.default_rng(21)
+    n = 50000
+    Ap, Aj = _dense_row_case(n, 6, {7, 30000}, 40000, rng)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    Bj, Bx = Aj.copy(), Ax.copy()
+    a0, L = int(Ap[30000]), int(Ap[30001] - Ap[30000])
+    assert L == 40000
+    if where != "sorted":
+        e = a0 + {"first_pair": 0, "part_boundary": L * 5 // 16 - 1, "last_pair": L - 2}[where]
+        Bj[e], Bj[e + 1] = Bj[e + 1], Bj[e]
+        Bx[e], Bx[e + 1] = Bx[e + 1], Bx[e]
+    Cp, Cj, Cx, info = _check(oracle, n, n, n, (Ap, Aj, Ax), (Ap, Bj, Bx))
+    assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Ap)
+    # multiplied as they are (sort_b = 0): an unsorted B disables the kernels that need ascending rows, which shows
+    # in the symbolic kernel mix only if the check saw the swapped pair
+    if where != "sorted":
+        plats = [False] * bhmod.NUM_PLATFORMS
+        plats[bhmod.BHSPARSE_HIP] = True
+        bh = bhmod.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        assert bh.set_option("sort_b", 0) == 0
+        c = np.zeros(n + 1, np.int32)
+        assert bh.initData(n, n, n, len(Aj), Ax, Ap, Aj, len(Bj), Bx, Ap, Bj, c) == 0
+        assert bh.get_info("b_sorted") == 0 and bh.get_info("max_row_b") == 40000
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
 @pytest.mark.parametrize("cap", [6, 8, 10])
 def test_column_window_path_forced(oracle, cap):
     """Capping the LDS table forces the column-window (long-row) path on ordinary rows:
@@ -499,6 +531,121 @@ def test_hub_row_power_law(oracle):
     # float values through the global fp64 atomics stay within tolerance
     valf = np.random.default_rng(1).standard_normal(len(col))
     _check(oracle, m, m, m, (rp, col, valf), (rp, col, valf), exact=False)
+
+
+def _dense_row_case(n, per_row, dense_rows, dense_nnz, rng):
+    """A sparse square matrix with a few rows of dense_nnz entries: in A^2 those rows carry dense_nnz x per_row
+    products, and every row that points at one of them inherits its dense_nnz entries."""
+    rows = []
+    for i in range(n):
+        if i in dense_rows:
+            rows.append(np.sort(rng.choice(n, dense_nnz, replace=False)))
+        else:
+            rows.append(np.unique(rng.integers(0, n, int(rng.integers(max(per_row - 3, 1), per_row + 4)))))
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.int32)
+    return rp, col
+
+
+@pytest.mark.parametrize("case", ["dense_rows", "tiny_items_batches", "wide_segments", "float_values", "f32_build"])
+def test_hub_rows_split_across_workgroups(oracle, case):
+    """Hub bin (bhs_hub.hip.h): a row with hub_min_products products or more is cut into items that the whole device
+    works on, its accumulator a bitmap slot shared by all of its workgroups.  Replaces the reference's multi-round
+    global merge (bhsparse_cuda.h:2270-2525, :2527-2780).  Same bits as the one-workgroup-per-row kernels."""
+    rng = np.random.default_rng(11)
+    value_dtype = np.float32 if case == "f32_build" else np.float64
+    if case == "wide_segments":
+        # 3 M columns: 16 bitmap segments per row; B rows collide inside a pool, first / last columns present
+        n, k = 3000000, 3000
+        pool = np.sort(rng.choice(n, 8000, replace=False))
+        rowsB = []
+        for j in range(k):
+            L = int(rng.integers(20, 60))
+            rowsB.append(np.sort(rng.choice(pool, L, replace=False) if j < k // 2 else rng.choice(n, L, replace=False)))
+        rowsB[k - 1] = np.array([0, 15, 16, 31, 32, n - 2, n - 1])
+        Bp = np.zeros(k + 1, np.int32); Bp[1:] = np.cumsum([len(r) for r in rowsB])
+        Bj = np.concatenate(rowsB).astype(np.int32)
+        rowsA = [np.arange(k), np.sort(rng.choice(k, 1500, replace=False)), np.sort(rng.choice(k, 10, replace=False)),
+                 np.empty(0, np.int64), np.sort(rng.choice(k // 2, 900, replace=False)), np.arange(k - 700, k)]
+        Ap = np.zeros(len(rowsA) + 1, np.int32); Ap[1:] = np.cumsum([len(r) for r in rowsA])
+        Aj = np.concatenate(rowsA).astype(np.int32)
+        m = len(rowsA)
+        opts = {"hub_min_products": 20000}
+    else:
+        n = k = m = 40000
+        Ap, Aj = _dense_row_case(n, 9, {5, 17000, n - 1}, 16000, rng)
+        Bp, Bj = Ap, Aj
+        opts = {} if case == "dense_rows" else {"hub_min_products": 3000}
+        if case == "tiny_items_batches":
+            opts.update({"hub_item_products": 64, "hub_slots": 2})
+    if case == "float_values":
+        Ax = Bx = rng.standard_normal(len(Aj))
+    else:
+        Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+        Bx = Ax if Bj is Aj else rng.integers(1, 10, len(Bj)).astype(np.float64)
+    A, B = (Ap, Aj, Ax), (Bp, Bj, Bx)
+    ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax.astype(value_dtype), Bp, Bj, Bx.astype(value_dtype),
+                                  options=opts, value_dtype=value_dtype)
+    names = _kernel_names(info)
+    assert {"symbolic_hub_rows", "numeric_hub_rows"} <= names, names
+    assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp)
+    assert np.array_equal(Cp, ref[0]) and np.array_equal(Cj, ref[1])
+    if case == "float_values":
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=REL_TOL)["ok"]
+    else:
+        assert np.array_equal(Cx.astype(np.float64), ref[2])             # small integers: exact in either build
+    check_csr_invariants(m, n, Cp, Cj)
+    hub = [kk for kk in info["kernels"] if kk["name"] == "numeric_hub_rows"][0]
+    assert hub["rows"] >= 3 and hub["products"] >= 3 * (20000 if case == "wide_segments" else 3000)
+    # the hub bin off: the same rows through the one-workgroup-per-row kernels
+    Cp2, Cj2, Cx2, info2 = spgemm_csr(m, k, n, Ap, Aj, Ax.astype(value_dtype), Bp, Bj, Bx.astype(value_dtype),
+                                      options={"hub_min_products": 0}, value_dtype=value_dtype)
+    assert "numeric_hub_rows" not in _kernel_names(info2)
+    assert np.array_equal(Cp, Cp2) and np.array_equal(Cj, Cj2)
+    if case != "float_values":
+        assert np.array_equal(Cx, Cx2)
+    # one atomic per product instead of one per run of neighbouring lanes in the same bitmap word
+    Cp3, Cj3, Cx3, info3 = spgemm_csr(m, k, n, Ap, Aj, Ax.astype(value_dtype), Bp, Bj, Bx.astype(value_dtype),
+                                      options=dict(opts, hub_aggregate=0), value_dtype=value_dtype)
+    assert "numeric_hub_rows" in _kernel_names(info3)
+    assert np.array_equal(Cp, Cp3) and np.array_equal(Cj, Cj3)
+    if case != "float_values":
+        assert np.array_equal(Cx, Cx3)
+
+
+def test_hub_rows_in_row_ranges(oracle):
+    """The numeric half in row ranges with hub rows in several of them (their queue entries carry the range's
+    row numbers, their output base comes from rowPtrC)."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 30000
+    Ap, Aj = _dense_row_case(n, 8, {0, 9000, 20000, n - 1}, 9000, rng)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    ref = oracle.spgemm(n, n, n, Ap, Aj, Ax, Ap, Aj, Ax)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.set_option("hub_min_products", 5000) == 0
+    Cp = np.zeros(n + 1, np.int32)
+    assert bh.initData(n, n, n, len(Aj), Ax, Ap, Aj, len(Aj), Ax, Ap, Aj, Cp) == 0
+    L, h = bh._lib, bh._h
+    for nranges in (1, 4):
+        ct, cc = C.c_int64(0), C.c_int(0)
+        assert L.bhs_spgemm_symbolic(h, C.byref(ct), C.byref(cc)) == 0
+        assert cc.value == ref[0][-1]
+        cuts = [n * s // nranges for s in range(nranges + 1)]
+        for s in reversed(range(nranges)):
+            assert L.bhs_spgemm_numeric(h, cuts[s], cuts[s + 1]) == 0
+        assert L.bhs_spgemm_finish(h, None) == 0
+        Cj = np.empty(cc.value, np.int32); Cx = np.empty(cc.value, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        res = oracle.compare(ref, (bh.get_rowptrC(), Cj, Cx), rel_tol=0.0)
+        assert res["ok"], (nranges, res)
+    assert "numeric_hub_rows" in {s["name"] for s in bh.kernel_stats()}
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
 @pytest.mark.parametrize("n", [2 ** 20, 2 ** 20 + 1, 3000000])

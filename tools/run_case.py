@@ -10,6 +10,10 @@ if name == "webbase":
     rp, col = gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
     val = gallery.fill_values(len(col))
     Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
+elif name == "denserows":
+    rp, col = gallery.dense_rows_csr(1 << 20, 8, 4, 200000)
+    val = gallery.fill_values(len(col))
+    Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 else:
     st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
                 "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1)),
