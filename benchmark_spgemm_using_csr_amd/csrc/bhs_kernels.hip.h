@@ -1051,7 +1051,8 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
     const int4* __restrict__ desc, int qn, int nWords,       // nWords: bitmap words, a multiple of 1024
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
-    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket)
+    int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket,
+    int reverse)                                               // 1: queue taken from its end (longest rows there)
 {
     constexpr int BLOCK = kLdsBitmapBlock, CH = kLdsBitmapChunk, U = 4, NW = BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
         const int q = wtot[NW];
         __syncthreads();
         if (q >= qn) break;
-        const int4 d = desc[q];
+        const int4 d = desc[reverse ? qn - 1 - q : q];
         const int row = d.x, a0 = d.y, a1 = d.z;
         BHS_TICK_SPA(8);
         // ---- pass 1: occupancy bits

@@ -137,6 +137,7 @@ struct bhs_handle {
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
+    int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
     int* hostSmall = nullptr;            // pinned mirror of `small`
     int* hostRowPtr = nullptr;           // pinned staging of rowPtrC for the host-pointer API
@@ -383,7 +384,7 @@ int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 
 // Long rows of matrices with <= 2^20 columns: bitmap accumulator in LDS, one 1024-lane workgroup per CU.
 template <bool NUM>
-int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, int reverse = 0)
 {
     auto kern = k_row_bitmap_lds<NUM>;
     int perCUunused = 1;     // (one workgroup per CU by design; the call raises the dynamic-LDS limit for this device)
@@ -395,7 +396,7 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->ls, queue,
                        qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h),
-                       small + h->ticketSlot);
+                       small + h->ticketSlot, reverse);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -654,17 +655,21 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
     return BHS_SUCCESS;
 }
 
+// does this bin run k_row_bitmap_lds? (long rows, and the numeric workgroup bins from ldsBitmapMinLog2 up)
 template <bool NUM>
-int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt)
+bool bin_takes_lds_bitmap(const bhs_handle* h, const KernelCfg& c)
+{
+    if (!(h->useSpa && h->maxTableLog2 >= 15 && h->useLdsBitmap && h->n <= kLdsBitmapCols)) return false;
+    if (c.win) return true;
+    return NUM && c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->forcePath == 0;
+}
+
+template <bool NUM>
+int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt, int reverse = 0)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
-    if (c.win && h->useSpa && h->maxTableLog2 >= 15) {           // long rows: bitmap accumulators
-        if (h->useLdsBitmap && h->n <= kLdsBitmapCols) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
-        if (h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
-    }
-    if (NUM && c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->useSpa && h->useLdsBitmap && h->n <= kLdsBitmapCols &&
-        h->maxTableLog2 >= 15 && h->forcePath == 0)
-        return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt);
+    if (bin_takes_lds_bitmap<NUM>(h, c)) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt, reverse);
+    if (c.win && h->useSpa && h->maxTableLog2 >= 15 && h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
     const bool win = c.win || lg < c.log2ts;   // a capped table can overflow => window variant
     if constexpr (!NUM) {
@@ -1208,13 +1213,19 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     for (int i = 1; i < kNumNumBins; ++i) {
         const int b = kNumNumBins - i;
         if (!numCount[b]) continue;
+        // Neighbouring bins that all run the LDS-bitmap kernel (one workgroup per CU: two such kernels side by side
+        // only take CUs from each other, and the shorter bins' launch would trail behind) go as ONE queue, taken
+        // from its end so that the longest rows start first.
+        int lo = b, rows = numCount[b];
+        if (numQueue && h->mergeBitmapBins && bin_takes_lds_bitmap<true>(h, kNumCfg[b]))
+            while (lo - 1 >= 2 && bin_takes_lds_bitmap<true>(h, kNumCfg[lo - 1])) { --lo; rows += numCount[lo]; }
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
-        BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[b] : nullptr, numCount[b], (int*)h->Cp.p));
+        BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[lo] : nullptr, rows, (int*)h->Cp.p, lo < b));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
-        h->stats[ep->stat].rows += numCount[b];
-        numStat[b] = ep->stat;
+        h->stats[ep->stat].rows += rows;
+        for (int bb = lo; bb <= b; ++bb) { if (numCount[bb]) numStat[bb] = ep->stat; numCount[bb] = 0; }
     }
     BHS_TRY(join_bins(h));
     return BHS_SUCCESS;
@@ -1806,6 +1817,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_slots")) { h->hubMaxSlots = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "spa_slots")) { h->spaMaxSlots = (int)value; h->spaDirty = true; return BHS_SUCCESS; }
