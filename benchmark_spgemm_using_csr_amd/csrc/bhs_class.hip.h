@@ -1,0 +1,471 @@
+// bhs_class.hip.h -- row classes: the structure of one row of C, worked out once per CLASS of rows.
+//
+// On the matrices this benchmark is about (the gallery's finite-difference stencils, SpGEMM_cuda/main.cu:56-64 and
+// README.md:40-54, and anything else assembled on a regular grid) almost every row looks like its neighbours, shifted:
+// the columns of row i of A are i + a_0, i + a_1, ..  and the row j of B behind each of them has columns j + b_0, ..
+// Two rows of A whose offset lists a_k are equal, and whose B rows are pairwise equal as offset lists too, produce the
+// same intermediate products at the same relative columns: the same sorted column list (relative to the row), the
+// same number of entries, and the same map from product number to position in the row.  poisson27pt on a 128^3 grid has
+// 2 097 152 rows and 125 such classes.
+//
+// The general pipeline re-discovers that structure for every row (hash inserts, compaction, sort: ~900 wavefront
+// instructions per row).  Here it is found once per class:
+//   k_class_rows<false>  class id of every row of B: hash of its relative pattern -> slot of a small hash table whose
+//                        entry names the class's representative row; the row is COMPARED with the representative
+//                        entry by entry, so a hash collision costs a probe, never a wrong answer
+//   k_class_rows<true>   class id of every row of A: the same over the list of (relative column, class of that B row)
+//   k_class_patterns     per class: the products of the representative row, sorted and made unique -> relative column
+//                        list, entry count, and for every product its {A entry, B entry, position} triple
+//   k_class_counts       rowPtrC counts: the class's entry count
+//   k_class_numeric      per row: 1 load of A's entries and rowPtrB, then every product is one load of B's value, one
+//                        multiply and one ds_add_f64 into its known position; the row is written out with its columns
+//                        (class list + row number) in ascending order.  No column of B is read, nothing is hashed,
+//                        compacted or sorted.
+// Rows the tables cannot take (more than kClassMaxRow entries in a row of A or B, more than kClassMaxP products or
+// kClassMaxNnz entries per row, a full table) send the whole multiply back to the general pipeline, and the data set
+// stays there.  Replaces, for the matrices that qualify, all of SpGEMM_cuda/bhsparse_cuda.h:210-2780.
+#pragma once
+
+namespace bhs {
+
+constexpr int kClassSlots = 4096;          // slots of each hash table; a class id is a slot number
+constexpr int kClassProbe = 32;            // linear probes before a row counts as unclassified
+constexpr int kClassMaxRow = 64;           // entries per row of A / of B
+constexpr int kClassMaxP = 1024;           // products per row of C
+constexpr int kClassMaxNnz = 512;          // entries per row of C
+constexpr unsigned long long kClassEmpty = ~0ull;
+
+// `stats` block written by k_class_rows / k_class_patterns (ints)
+constexpr int kClassSumSlots = 32;
+enum { CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
+       CS_MAXNA = 6 /* longest A row of any class */,
+       CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_INTS = 8 + 2 * kClassSumSlots };
+
+__device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
+{
+    h = (h ^ v) * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+
+// ---------------------------------------------------------------------------
+// Class of every row.  IS_A = false: rows of B, element = relative column.  IS_A = true: rows of A, element =
+// (relative column, class of the B row it selects); also counts the rows of every class.
+// G lanes share a row (coalesced loads of its entries, one entry per lane and pass); the row's hash is the sum of
+// its position-keyed element hashes, the comparison with the class's representative row is one entry per lane too.
+// ---------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ unsigned group_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+template <bool IS_A, int G>
+__global__ __launch_bounds__(256) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
+                                                    const int* __restrict__ classB,
+                                                    unsigned long long* __restrict__ table,
+                                                    int* __restrict__ classOut, int* __restrict__ stats)
+{
+    constexpr int E = kClassMaxRow / G;                            // entries per lane
+    constexpr int RPB = 256 / G;                                   // rows per block and pass
+    // Block-local cache of the table, indexed by the hash: {slot, 20 bits of the hash} and the class's pattern (the
+    // relative columns, for A rows also the B classes) -- a row whose class is here is recognised without touching
+    // the representative row in memory.  The blocks are persistent and a stretch of rows has few classes; the
+    // device-wide table (coherent loads, compare-and-swap) is for the misses.  An entry is claimed once (LDS
+    // compare-and-swap to "busy"), filled, then published; it never changes afterwards.
+    constexpr int NC = 32;
+    constexpr unsigned kBusy = 0xFFFFFFFEu;
+    __shared__ unsigned ctag[NC];
+    __shared__ int cpat[NC][kClassMaxRow];
+    __shared__ int cpatB[IS_A ? NC : 1][kClassMaxRow];
+    const int tid = threadIdx.x, lane = tid & 63, g = tid % G;
+    if (tid < NC) ctag[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int leaderLane = lane - g;                               // first lane of this lane's group
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << leaderLane;
+    const long long span = ((long long)nrows + RPB - 1) / RPB * RPB;     // whole blocks take part in the shuffles
+    for (long long row = (long long)blockIdx.x * RPB + tid / G; row < span; row += (long long)gridDim.x * RPB) {
+        int cls = -1;
+        const bool live = row < nrows;
+        int a0 = 0, len = 0;
+        if (live) { a0 = Rp[row]; len = Rp[row + 1] - a0; }
+        bool ok = live && len <= kClassMaxRow;
+        // all loads of the row first, without predicates (a position past the row's end re-reads its last entry), so
+        // that they are in flight together; then the gather of the B classes, likewise; then the hash
+        int el[E], cb[E], cc[E];
+        unsigned hp = 0;
+        bool bad = false;
+        const int lastPos = ok && len > 0 ? a0 + len - 1 : 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) cc[e] = Rj[min(a0 + e * G + g, lastPos)];
+        if (IS_A) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) cb[e] = classB[cc[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int pos = e * G + g;
+            const bool in = ok && pos < len;
+            el[e] = in ? cc[e] - (int)row : 0;
+            if (!IS_A || !in) cb[e] = 0;
+            unsigned hh = class_mix(0x85EBCA6Bu * (unsigned)(pos + 1), (unsigned)el[e]);
+            if (IS_A) {
+                bad = bad || cb[e] < 0;
+                hh = class_mix(hh, (unsigned)cb[e]);
+            }
+            hp += in ? hh : 0u;
+        }
+        if (IS_A && (__ballot(bad) & gmask)) ok = false;           // a B row without a class: none for this row either
+        const unsigned h = group_sum_u32<G>(hp) + (unsigned)len * 0x9E3779B1u + 1u;
+        // does this row equal row `rep` entry by entry?  (one entry per lane and pass; the group votes)
+        auto equals = [&](bool cand, int rep) {
+            bool same = true;
+            if (cand && rep != (int)row) {
+                const int r0 = Rp[rep];
+                same = Rp[rep + 1] - r0 == len;
+                if (same) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int pos = e * G + g;
+                        if (pos < len) {
+                            const int cr = Rj[r0 + pos];
+                            same = same && el[e] == cr - rep;
+                            if (IS_A) same = same && cb[e] == classB[cr];
+                        }
+                    }
+                }
+            }
+            return cand && !(__ballot(cand && !same) & gmask);
+        };
+        bool searching = ok;
+        const int ci = (int)(h & (NC - 1));
+        {
+            unsigned tg = 0xFFFFFFFFu;
+            if (searching && g == 0) tg = ctag[ci];
+            tg = (unsigned)__shfl((int)tg, leaderLane, 64);
+            const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (h >> 12);
+            bool same = true;
+            {
+                same = cpat[ci][kClassMaxRow - 1] == len || len == kClassMaxRow;      // (the last cell holds the length of shorter rows)
+                int pc[E], pb[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { pc[e] = cpat[ci][e * G + g]; pb[e] = IS_A ? cpatB[ci][e * G + g] : 0; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool in = e * G + g < len;
+                    same = same && (!in || (el[e] == pc[e] && (!IS_A || cb[e] == pb[e])));
+                }
+            }
+            if (cand && !(__ballot(cand && !same) & gmask)) { cls = (int)(tg >> 20); searching = false; }
+        }
+        const unsigned long long mine = ((unsigned long long)h << 32) | (unsigned)row;
+        int s = (int)(h & (kClassSlots - 1));
+        for (int probe = 0; probe < kClassProbe; ++probe) {
+            if (!__any(searching)) break;
+#ifdef BHS_CLS_DEBUG
+            if (lane == 0) atomicAdd(&stats[7], 1);
+#endif
+            // An entry changes once (empty -> final).  The load is device-coherent: a plain one could keep returning
+            // the "empty" line this XCD's L2 cached before another XCD claimed the slot.
+            unsigned long long v = kClassEmpty;
+            if (searching && g == 0) {
+                v = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == kClassEmpty) {
+                    const unsigned long long old = atomicCAS(&table[s], kClassEmpty, mine);
+                    v = old == kClassEmpty ? mine : old;
+                }
+            }
+            v = (unsigned long long)__shfl((long long)v, leaderLane, 64);
+            const int rep = (int)(unsigned)v;
+            if (equals(searching && (unsigned)(v >> 32) == h, rep)) {
+                cls = s;
+                searching = false;
+                // publish in the block's cache if its cell is still free
+                unsigned won = 0;
+                if (g == 0) won = atomicCAS(&ctag[ci], 0xFFFFFFFFu, kBusy) == 0xFFFFFFFFu ? 1u : 0u;
+                won = (unsigned)__shfl((int)won, leaderLane, 64);
+                if (won) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int pos = e * G + g;
+                        if (pos < len) {
+                            cpat[ci][pos] = el[e];
+                            if (IS_A) cpatB[ci][pos] = cb[e];
+                        }
+                    }
+                    if (g == 0 && len < kClassMaxRow) cpat[ci][kClassMaxRow - 1] = len;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (g == 0) ctag[ci] = ((unsigned)s << 20) | (h >> 12);
+                }
+            }
+            s = (s + 1) & (kClassSlots - 1);
+        }
+        if (live && g == 0) classOut[row] = cls;
+        if (__any(live && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pattern of every class of A rows: one 256-lane workgroup per table slot.
+// classInfo[s] = {entries of the A row, products, entries of the C row (-1: beyond the limits), representative row}
+// classMap[s * kClassMaxP + p] = A entry | B entry << 6 | position << 16   for product p (A-entry-major order)
+// classRel[s * kClassMaxNnz + e] = column of entry e minus the row number, ascending
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long* __restrict__ tableA,
+                                                        const int* __restrict__ Ap, const int* __restrict__ Aj,
+                                                        const int* __restrict__ Bp, const int* __restrict__ Bj,
+                                                        int4* __restrict__ classInfo, unsigned* __restrict__ classMap,
+                                                        int* __restrict__ classRel, int* __restrict__ stats)
+{
+    __shared__ int keys[kClassMaxP], srt[kClassMaxP], pk[kClassMaxP];
+    __shared__ int sIncl[kClassMaxRow], sB0[kClassMaxRow], scan[256];
+    const int tid = threadIdx.x, s = blockIdx.x;
+    const unsigned long long v = tableA[s];
+    if (v == kClassEmpty) {
+        if (tid == 0) classInfo[s] = make_int4(0, 0, 0, -1);
+        return;
+    }
+    const int rep = (int)(unsigned)v;
+    const int a0 = Ap[rep], nA = Ap[rep + 1] - a0;               // <= kClassMaxRow (k_class_rows)
+    if (tid < 64) {
+        int b0 = 0, len = 0;
+        if (tid < nA) {
+            const int j = Aj[a0 + tid];
+            b0 = Bp[j];
+            len = Bp[j + 1] - b0;
+        }
+        const int incl = wave_incl_scan_dpp(len);
+        sIncl[tid] = incl;
+        sB0[tid] = b0 - (incl - len);
+    }
+    __syncthreads();
+    const int P = nA > 0 ? sIncl[nA - 1] : 0;
+    if (P > kClassMaxP) {
+        if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
+        return;
+    }
+    int N2 = 1;
+    while (N2 < P) N2 <<= 1;
+    for (int p = tid; p < N2; p += 256) {
+        int key = 0x7fffffff, code = 0;
+        if (p < P) {
+            int k = 0;
+            while (sIncl[k] <= p) ++k;                           // <= 64 steps, once per class
+            key = Bj[sB0[k] + p] - rep;
+            code = k | ((p - (k ? sIncl[k - 1] : 0)) << 6);
+        }
+        keys[p] = key;
+        srt[p] = key;
+        pk[p] = code;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= N2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int x = srt[i], y = srt[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    // distinct keys: thread t owns srt[t * per .. (t + 1) * per)
+    const int per = (N2 + 255) / 256;
+    int heads = 0;
+    for (int i = tid * per; i < (tid + 1) * per && i < P; ++i) heads += (i == 0 || srt[i] != srt[i - 1]) ? 1 : 0;
+    scan[tid] = heads;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int add = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    const int nnz = scan[255];
+    if (nnz > kClassMaxNnz) {
+        if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
+        return;
+    }
+    __shared__ int ulist[kClassMaxNnz];
+    int at = scan[tid] - heads;
+    for (int i = tid * per; i < (tid + 1) * per && i < P; ++i)
+        if (i == 0 || srt[i] != srt[i - 1]) ulist[at++] = srt[i];
+    __syncthreads();
+    for (int e = tid; e < nnz; e += 256) classRel[(size_t)s * kClassMaxNnz + e] = ulist[e];
+    for (int p = tid; p < P; p += 256) {
+        const int key = keys[p];
+        int l = 0, r = nnz - 1;
+        while (l < r) { const int mid = (l + r) >> 1; if (ulist[mid] < key) l = mid + 1; else r = mid; }
+        classMap[(size_t)s * kClassMaxP + p] = (unsigned)pk[p] | ((unsigned)l << 16);
+    }
+    if (tid == 0) {
+        classInfo[s] = make_int4(nA, P, nnz, rep);
+        atomicMax(&stats[CS_MAXP], P);
+        atomicMax(&stats[CS_MAXNNZ], nnz);
+        atomicMax(&stats[CS_MAXNA], nA);
+        atomicAdd(&stats[CS_CLASSES], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restrict__ classC,
+                                                      const int4* __restrict__ classInfo, int* __restrict__ cnt,
+                                                      int* __restrict__ stats)
+{
+    __shared__ unsigned long long wsum[4];
+    unsigned long long products = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256) {
+        const int c = classC[i];
+        int v = 0;
+        if (c >= 0) {
+            const int4 ci = classInfo[c];
+            v = ci.z;
+            products += (unsigned long long)ci.y;
+        }
+        cnt[i] = v > 0 ? v : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) products += __shfl_xor(products, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = products;
+    __syncthreads();
+    // the product total (nnzCt of the reference's stage 1) over kClassSumSlots counters: one address would queue
+    if (threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (blockIdx.x % kClassSumSlots),
+                  wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Numeric pass.  A wave takes runs of kClassRun consecutive rows (neighbouring rows share their B rows: L1 / L2 hits,
+// and the rows of C they write are adjacent); blocks are dealt to the XCDs so that each XCD's L2 sees one contiguous
+// band of rows.
+//   per run   the A entries of its rows are one contiguous stretch of colIndA / valA: loaded with coalesced loads,
+//             their rowPtrB gathered, both parked in LDS -- two memory round trips for the whole run;
+//   per row   every lane holds MAXU product triples {A entry, B entry, position} of the row's class in registers:
+//             MAXU LDS reads of the B-row starts, MAXU loads of B's values (no predicates: all in flight at once),
+//             MAXU multiplies and ds_add_f64 into the row's accumulators, then the row is written out with its
+//             columns (class list + row number).  The class data stays in registers until a row of another class
+//             comes along.
+// What bounds it (ablations, poisson27pt 128^3, 2.3 ms): the LDS pipe -- 12 ds_add_f64 per row at ~33 cycles each
+// whatever the number of active lanes, 24 reads of the staged A data.  Variants measured slower: one batch per A entry
+// with plain read-fma-write accumulation (3.5 ms: 56 partial-lane LDS instructions per row), the same with four
+// accumulator copies (3.9 ms), the same with atomics (4.0 ms).
+// ---------------------------------------------------------------------------
+#ifndef BHS_CLS_ABL
+#define BHS_CLS_ABL 0
+#endif
+constexpr unsigned kClassIdle = 1u << 12;     // product triple of a lane without a product
+constexpr int kClassRun = 8;
+constexpr int kClassWaves = 4;
+
+template <int MAXU, int MAXV>
+__global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
+    int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const value_t* __restrict__ Bx, const int* __restrict__ classC,
+    const int4* __restrict__ classInfo, const unsigned* __restrict__ classMap, const int* __restrict__ classRel,
+    const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx, int accStride, int stageCap,
+    int rowBase)                                               // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // per wave: acc[accStride] and sAx[stageCap] doubles; then, after all waves' doubles, sBp[stageCap] ints per wave
+    acc_t* acc = reinterpret_cast<acc_t*>(smemRaw) + (size_t)wv * (accStride + stageCap);
+    acc_t* sAx = acc + accStride;
+    int* sBp = reinterpret_cast<int*>(reinterpret_cast<acc_t*>(smemRaw) + (size_t)kClassWaves * (accStride + stageCap)) + wv * stageCap;
+    for (int i = lane; i < accStride; i += 64) acc[i] = 0.0;
+
+    const int nRuns = (m + kClassRun - 1) / kClassRun;
+    // XCD-aware: block b runs on XCD b % 8; XCD x takes the runs [x * perX, (x + 1) * perX)
+    const int xcd = blockIdx.x & 7, perX = (nRuns + 7) / 8;
+    const int wavesPerX = (gridDim.x >> 3) * kClassWaves;
+    const int wIdx = (blockIdx.x >> 3) * kClassWaves + wv;
+    constexpr int SE = kClassRun;                                  // staging passes: kClassRun rows x <= 64 entries
+
+    int cur = -2, P = 0, nnz = 0;
+    unsigned mp[MAXU];
+    int rel[MAXV];
+    for (int rr = wIdx; rr < perX; rr += wavesPerX) {
+        const int run = xcd * perX + rr;
+        if (run >= nRuns) break;
+        const int row0 = run * kClassRun;
+        const int nr = min(kClassRun, m - row0);
+        // row pointers and classes of the run: one lane per row (lane nr holds the end of the last row)
+        int myAp = 0, myCp = 0, myCls = -1;
+        if (lane <= nr) { myAp = Ap[row0 + lane]; myCp = Cp[row0 + lane]; }
+        if (lane < nr) myCls = classC[row0 + lane];
+        const int base = __builtin_amdgcn_readlane(myAp, 0);
+        const int nE = min(__builtin_amdgcn_readlane(myAp, nr) - base, stageCap - 64);
+        {
+            int aj[SE], bp[SE];
+            acc_t ax[SE];
+#pragma unroll
+            for (int i = 0; i < SE; ++i) {
+                aj[i] = -1;
+                ax[i] = 0.0;
+                if (i * 64 + lane < nE) { aj[i] = Aj[base + i * 64 + lane]; ax[i] = (acc_t)Ax[base + i * 64 + lane]; }
+            }
+#pragma unroll
+            for (int i = 0; i < SE; ++i) { bp[i] = 0; if (aj[i] >= 0) bp[i] = Bp[aj[i]]; }
+#pragma unroll
+            for (int i = 0; i < SE; ++i)
+                if (i * 64 < nE) { sAx[i * 64 + lane] = ax[i]; sBp[i * 64 + lane] = bp[i]; }
+        }
+        wave_sync();
+        for (int t = 0; t < nr; ++t) {
+            const int row = row0 + t;
+            const int cls = __builtin_amdgcn_readlane(myCls, t);
+            const int out = __builtin_amdgcn_readlane(myCp, t);
+            const int off = __builtin_amdgcn_readlane(myAp, t) - base;
+            if (cls < 0) continue;                                   // (cannot happen: such a multiply was sent back)
+            if (cls != cur) {                                        // (wave-uniform)
+                cur = cls;
+                const int4 ci = classInfo[cls];
+                P = __builtin_amdgcn_readfirstlane(ci.y);            // (uniform anyway: tells the compiler so)
+                nnz = __builtin_amdgcn_readfirstlane(ci.z);
+                // lanes past the class's last product get a harmless triple: entry 0 of B, the spare slot
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u)
+                    mp[u] = u * 64 + lane < P ? classMap[(size_t)cls * kClassMaxP + u * 64 + lane] : (kClassIdle | ((unsigned)(accStride - 1) << 16));
+#pragma unroll
+                for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
+                __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
+            }
+            // every lane, every batch: the loads carry no predicate, so all MAXU of them are in flight at once
+            int bpv[MAXU];
+            acc_t bv[MAXU], axv[MAXU];
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) bpv[u] = sBp[off + (int)(mp[u] & 63u)];
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                const unsigned e = mp[u];
+                const int valid = (int)((e >> 12) & 1u) - 1;         // idle lane: 0, else all ones
+                const long long idx = (long long)((bpv[u] + (int)((e >> 6) & 63u)) & valid);
+                bv[u] = (BHS_CLS_ABL & 1) ? (acc_t)idx : (acc_t)Bx[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) axv[u] = sAx[off + (int)(mp[u] & 63u)];
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                if (BHS_CLS_ABL & 2) { if (axv[u] * bv[u] == 12345.678) acc[0] = 1.0; }
+                else unsafeAtomicAdd(&acc[mp[u] >> 16], axv[u] * bv[u]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                const int s = v * 64 + lane;
+                if (s < nnz) {
+                    const acc_t val = acc[s];
+                    acc[s] = 0.0;
+                    if (!(BHS_CLS_ABL & 4) || val == 12345.678) {
+                    Cj[(long long)out + s] = rel[v] + row + rowBase;
+                    Cx[(long long)out + s] = (value_t)val;
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+}  // namespace bhs

@@ -16,6 +16,7 @@
 #include "bhs_kernels.hip.h"
 #include "bhs_rank.hip.h"
 #include "bhs_hub.hip.h"
+#include "bhs_class.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -136,6 +137,11 @@ struct bhs_handle {
     // hub rows (bhs_hub.hip.h): rows with at least hubMin products are cut into items of hubItemProducts products
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
+    // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
+    int classGridMul = 8, classPerLane = 4;   // tuning hooks of k_class_rows
+    int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries, until one multiply finds
+    int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
+    DevBuf classB, classC, classTab, classInfo, classMap, classRel;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -205,6 +211,8 @@ struct bhs_handle {
         bool open = false;                // symbolic done, finish pending
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
+        bool useClass = false;            // numeric half: k_class_numeric
+        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0;
         int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
@@ -399,6 +407,42 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
                        small + h->ticketSlot, reverse);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
+}
+
+// Numeric pass by row classes on the rows [r0, r1)
+template <int MAXU, int MAXV>
+int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
+{
+    auto kern = k_class_numeric<MAXU, MAXV>;
+    const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
+    // staging area of a run: its rows' A entries (rounded up to whole 64-entry passes) and 64 entries of slack
+    const int stageCap = ((kClassRun * h->ps.classMaxNA + 63) & ~63) + 64;
+    const size_t smem = (size_t)kClassWaves * ((size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int));
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * kClassWaves, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32 / kClassWaves));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    const int mR = r1 - r0;
+    const long long nRuns = ((long long)mR + kClassRun - 1) / kClassRun;
+    long long grid = std::min<long long>((nRuns + kClassWaves - 1) / kClassWaves, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kClassWaves), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+                       h->dBp, h->dBx, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
+                       (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->Cp.p + r0, out_cj(h),
+                       out_cx(h), accStride, stageCap, r0);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+int launch_class_numeric(bhs_handle* h, int r0, int r1)
+{
+    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
+    if (U <= 1 && V <= 1) return launch_class_numeric_impl<1, 1>(h, r0, r1);
+    if (U <= 2 && V <= 1) return launch_class_numeric_impl<2, 1>(h, r0, r1);
+    if (U <= 4 && V <= 2) return launch_class_numeric_impl<4, 2>(h, r0, r1);
+    if (U <= 8 && V <= 4) return launch_class_numeric_impl<8, 4>(h, r0, r1);
+    if (U <= 12 && V <= 2) return launch_class_numeric_impl<12, 2>(h, r0, r1);
+    return launch_class_numeric_impl<16, 8>(h, r0, r1);
 }
 
 // Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
@@ -819,36 +863,19 @@ int join_bins(bhs_handle* h)
     return BHS_SUCCESS;
 }
 
-int pipeline_symbolic(bhs_handle* h)
+// Stages 1 and 2 of the general pipeline: upper bound, symbolic bins and queues, the symbolic kernels.  Leaves the
+// per-row counts in Cp and tells stage 3 which choices it made.
+struct SymChoices {
+    bool noUpperBound = false, symDirect = false, useRank = false;
+    int laneK = 0, hubRows = 0;
+    BinSpec numSpec;
+};
+
+int symbolic_general(bhs_handle* h, SymChoices& out)
 {
-    h->ls = h->stream;
     const int m = h->m;
-    h->evUsed = 0;
-    for (auto& s : h->stats) { s.launches = 0; s.ms = 0; s.rows = s.products = s.nnz_out = s.nnzA_rows = 0; }
-    BHS_HIP(hipEventRecord(h->ev[0], h->stream));
     int* small = (int*)h->small.p;
     int* hs = h->hostSmall;
-    h->nnzC = 0;
-    h->nnzCt = 0;
-    h->hasC = false;
-    h->rowPtrStaged = false;          // (an empty product returns early: the previous multiply's staging must not be read)
-    h->ps = bhs_handle::PipeState();
-
-    BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
-    if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
-        BHS_HIP(hipMemsetAsync(h->Cp.p, 0, sizeof(int) * ((size_t)m + 1), h->stream));
-        for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
-        h->hasC = true;
-        h->ps.open = true;
-        h->ps.empty = true;
-        return BHS_SUCCESS;
-    }
-    BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
-    BHS_TRY(ensure(h, h->queue, sizeof(int4) * (size_t)m));
-    const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
-    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
-
     // ------------------------------------------------------------ stage 1
     // lane bin (k_row_lane): matrices whose A rows are all tiny, B rows strictly ascending
     int laneK = 0;
@@ -1014,6 +1041,129 @@ int pipeline_symbolic(bhs_handle* h)
     BHS_TRY(join_bins(h));
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
 
+    out.noUpperBound = noUpperBound;
+    out.symDirect = symDirect;
+    out.useRank = useRank;
+    out.laneK = laneK;
+    out.hubRows = noUpperBound ? 0 : symCount[kHubBin];
+    out.numSpec = numSpec;
+    return BHS_SUCCESS;
+}
+
+// Stages 1 and 2 by row classes (bhs_class.hip.h): classify the rows of B and A, work out every class's pattern,
+// write the per-row counts.  Everything is launched without a host round trip; stage 3's read-back tells whether every
+// row found a class (otherwise the multiply starts over on the general pipeline).
+int symbolic_class(bhs_handle* h)
+{
+    const int m = h->m, k = h->k;
+    int* small = (int*)h->small.p;
+    EventPair* ep;
+    BHS_TRY(ensure(h, h->classB, sizeof(int) * (size_t)std::max(k, 1)));
+    BHS_TRY(ensure(h, h->classC, sizeof(int) * (size_t)std::max(m, 1)));
+    BHS_TRY(ensure(h, h->classTab, sizeof(unsigned long long) * 2 * kClassSlots));
+    BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * kClassSlots));
+    BHS_TRY(ensure(h, h->classMap, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
+    BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
+    BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
+    BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * CS_INTS, h->stream));
+    BHS_HIP(hipMemsetAsync(h->classTab.p, 0xFF, sizeof(unsigned long long) * 2 * kClassSlots, h->stream));
+    for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
+    unsigned long long* tabB = (unsigned long long*)h->classTab.p;
+    unsigned long long* tabA = tabB + kClassSlots;
+    int* cstats = small + S_CT_SLOTS;
+    BHS_TRY(timed_begin(h, "classify_rows", &ep));
+    const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
+    // lanes per row: the average row, rounded up to a power of two
+#define BHS_CLASS_ROWS(ISA, G, grid, n, Rp, Rj, cb, tab, out)                                                  \
+    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(256), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats)
+    auto rows_grid = [&](int n, int G) {
+        return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + 256 / G - 1) / (256 / G), (long long)h->numCU * h->classGridMul));
+    };
+    const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
+    switch (GB) {
+        case 4: BHS_CLASS_ROWS(false, 4, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+        case 8: BHS_CLASS_ROWS(false, 8, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+        case 16: BHS_CLASS_ROWS(false, 16, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+        case 32: BHS_CLASS_ROWS(false, 32, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+        default: BHS_CLASS_ROWS(false, 64, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+    }
+    switch (GA) {
+        case 4: BHS_CLASS_ROWS(true, 4, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+        case 8: BHS_CLASS_ROWS(true, 8, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+        case 16: BHS_CLASS_ROWS(true, 16, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+        case 32: BHS_CLASS_ROWS(true, 32, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+        default: BHS_CLASS_ROWS(true, 64, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+    }
+#undef BHS_CLASS_ROWS
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += 2;
+    h->stats[ep->stat].rows += (int64_t)m + k;
+    BHS_HIP(hipEventRecord(h->ev[1], h->stream));
+    BHS_TRY(timed_begin(h, "class_patterns", &ep));
+    hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
+                       h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
+                       (unsigned*)h->classMap.p, (int*)h->classRel.p, cstats);
+    hipLaunchKernelGGL(k_class_counts, dim3(gA), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
+                       (const int4*)h->classInfo.p, (int*)h->Cp.p, cstats);
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += 2;
+    BHS_HIP(hipEventRecord(h->ev[2], h->stream));
+    return BHS_SUCCESS;
+}
+
+// restart: the same multiply starting over on another path (a refuted speculation, rows without a class): the
+// timers and kernel statistics of the abandoned attempt stay in -- it ran inside this multiply.
+int pipeline_symbolic(bhs_handle* h, bool restart = false)
+{
+    h->ls = h->stream;
+    const int m = h->m;
+    if (!restart) {
+        h->evUsed = 0;
+        for (auto& s : h->stats) { s.launches = 0; s.ms = 0; s.rows = s.products = s.nnz_out = s.nnzA_rows = 0; }
+        BHS_HIP(hipEventRecord(h->ev[0], h->stream));
+    }
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    h->nnzC = 0;
+    h->nnzCt = 0;
+    h->hasC = false;
+    h->rowPtrStaged = false;          // (an empty product returns early: the previous multiply's staging must not be read)
+    h->ps = bhs_handle::PipeState();
+
+    BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
+    if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
+        BHS_HIP(hipMemsetAsync(h->Cp.p, 0, sizeof(int) * ((size_t)m + 1), h->stream));
+        for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        h->hasC = true;
+        h->ps.open = true;
+        h->ps.empty = true;
+        return BHS_SUCCESS;
+    }
+    BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
+    BHS_TRY(ensure(h, h->queue, sizeof(int4) * (size_t)m));
+    const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
+    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
+
+    EventPair* ep;
+    SymChoices sc;
+    // Row classes first, for data sets whose rows are short on both sides (the hint from bhs_set_data time is
+    // verified on the device row by row)
+    const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+                          h->maxRowA <= kClassMaxRow && h->maxRowB <= kClassMaxRow;
+    if (useClass) {
+        BHS_TRY(symbolic_class(h));
+        sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)
+        sc.numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, true, 0, 0);
+    } else {
+        BHS_TRY(symbolic_general(h, sc));
+    }
+    const bool noUpperBound = sc.noUpperBound, symDirect = sc.symDirect, useRank = sc.useRank;
+    const int laneK = sc.laneK;
+    const BinSpec& numSpec = sc.numSpec;
+
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
     hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
@@ -1027,7 +1177,23 @@ int pipeline_symbolic(bhs_handle* h)
     h->stats[ep->stat].launches += 3;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
-    if (noUpperBound) {                                  // product count: the symbolic kernel's 64 partial sums
+    if (useClass) {
+        const int* cs = hs + S_CT_SLOTS;
+        if (cs[CS_FLAGS] || cs[CS_CLASSES] == 0) {
+            // a row without a class, or a class beyond the tables: this data set is for the general pipeline
+            h->classState = -1;
+            if (h->verbose > 1) printf("  [row classes: flags %d, %d classes: general pipeline]\n", cs[CS_FLAGS], cs[CS_CLASSES]);
+            return pipeline_symbolic(h, true);
+        }
+        unsigned long long t = 0, v;
+        for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, cs + CS_SUMS + 2 * i, 8); t += v; }
+        h->nnzCt = (long long)t;
+        h->ps.useClass = true;
+        h->ps.classMaxP = cs[CS_MAXP];
+        h->ps.classMaxNnz = cs[CS_MAXNNZ];
+        h->ps.classMaxNA = cs[CS_MAXNA];
+        if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; %d table probes]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[7]);
+    } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
         for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
         h->nnzCt = (long long)t;
@@ -1041,7 +1207,7 @@ int pipeline_symbolic(bhs_handle* h)
         if (!noUpperBound || h->specFailed) return BHS_ERR_INTERNAL;
         h->specFailed = true;
         if (h->verbose > 1) printf("  [speculative direct launch refuted on the device: general pipeline]\n");
-        return pipeline_symbolic(h);
+        return pipeline_symbolic(h, true);
     }
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
     if (nnzC > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
@@ -1052,7 +1218,7 @@ int pipeline_symbolic(bhs_handle* h)
     h->ps.laneK = laneK;
     h->ps.numSpec = numSpec;
     h->ps.maxCnt = hs[S_MAXCNT];
-    h->ps.hubRows = noUpperBound ? 0 : symCount[kHubBin];
+    h->ps.hubRows = sc.hubRows;
     h->ps.rankOvf = useRank ? hs[S_OVF] : 0;
     for (int b = 0; b < kMaxBins; ++b) h->ps.fullCount[b] = hs[S_NUM_COUNT + b];
     memcpy(h->ps.symSums, hs + S_SYM_SUMS, sizeof(h->ps.symSums));
@@ -1099,6 +1265,16 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     const bool useRank = h->ps.useRank;
     int (&numStat)[kMaxBins] = h->ps.numStat;
     h->ls = h->stream;
+    if (h->ps.useClass) {
+        h->ps.rangesRun++;
+        BHS_TRY(timed_begin(h, "numeric_class", &ep));
+        BHS_TRY(launch_class_numeric(h, r0, r1));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += r1 - r0;
+        if (full) { h->stats[ep->stat].products += h->nnzCt; h->stats[ep->stat].nnz_out += h->nnzC; h->stats[ep->stat].nnzA_rows += h->nnzA; }
+        return BHS_SUCCESS;
+    }
     // overflow rows of the rank path carry absolute row numbers: all of them with the first range
     if (useRank && h->ps.rankOvf > 0 && !h->ps.overflowDone) {
         h->ps.overflowDone = true;
@@ -1378,6 +1554,7 @@ int finish_set_data(bhs_handle* h)
     h->cmpState = 0;
     h->specFailed = false;
     h->rankState = 0;
+    h->classState = 0;
     if (h->nnzB > 1 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
@@ -1544,6 +1721,8 @@ int bhs_destroy(bhs_handle* h)
     release(h->small);
     release(h->spaRank);
     release(h->longList); release(h->longPart);
+    release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
+    release(h->classMap); release(h->classRel);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -1817,6 +1996,9 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_path")) { h->classPath = value != 0; h->classState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_slots")) { h->hubMaxSlots = (int)value; return BHS_SUCCESS; }

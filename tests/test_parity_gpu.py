@@ -20,10 +20,22 @@ REL_TOL = 1e-6
 
 
 def _check(oracle, m, k, n, A, B, exact=True, options=None):
+    """One multiply against the oracle.  Unless the caller decides about the row-class path (bhs_class.hip.h) itself,
+    the multiply runs twice: with the library's defaults -- structured inputs then take the class kernels -- and with
+    class_path = 0, the general pipeline whose kernels most tests here are about; the second run's results and
+    kernel list are returned, and both must agree with the oracle."""
     Ap, Aj, Ax = A
     Bp, Bj, Bx = B
-    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=options)
     ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    if options is None or "class_path" not in options:
+        Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=options)
+        assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp) and info["nnzC"] == ref[0][-1]
+        res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=REL_TOL)
+        assert res["ok"], ("class path / defaults", res)
+        if exact:
+            assert np.array_equal(Cx, ref[2])
+        options = dict(options or {}, class_path=0)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=options)
     assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp)
     assert info["nnzC"] == ref[0][-1]
     res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=REL_TOL)
@@ -854,35 +866,160 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
     """Lane-first / wave-first launches are chosen from the row bounds seen at bhs_set_data time; the multiply
     verifies them itself.  Borrowed device arrays are changed AFTER bhs_set_data_device so that one row of A is
     far longer than the longest row seen then: the kernels must refute the speculation and the multiply must
-    still be right (general pipeline), on this call and the next."""
+    still be right (general pipeline), on this call and the next.  The row-class path takes its hints from
+    bhs_set_data time too and classifies every row on the device: with it the multiply must be right as well, on
+    the class kernels (the merged row still has <= 64 entries: poisson5pt) or back on the general pipeline."""
     import torch
     dev = torch.device("cuda", 0)
     m, rp, col, val = poisson_case(stencil, *dims)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    Bp, Bj, Bx = t(rp), t(col), t(val)
-    Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+    for class_path in (0, 1):
+        Bp, Bj, Bx = t(rp), t(col), t(val)
+        Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+        plats = [False] * bhmod.NUM_PLATFORMS
+        plats[bhmod.BHSPARSE_HIP] = True
+        bh = bhmod.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        assert bh.set_option("class_path", class_path) == 0
+        assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
+        assert bh.spgemm() == 0
+        first = {s["name"] for s in bh.kernel_stats()}
+        assert "upper_bound" not in first            # the direct path (or the class path) ran
+        assert ("numeric_class" in first) == bool(class_path)
+        # row 5 of A swallows rows 5..11 (same arrays, same nnz): 7 rows' worth of entries in one row
+        rp2 = rp.copy()
+        rp2[6:12] = rp[12]
+        Ap.copy_(t(rp2))
+        torch.cuda.synchronize()
+        ref = oracle.spgemm(m, m, m, rp2, col, val, rp, col, val)
+        for _ in range(2):
+            assert bh.spgemm() == 0
+            names = {s["name"] for s in bh.kernel_stats()}
+            if class_path and stencil == "poisson5pt":
+                assert "numeric_class" in names                                  # 35 entries: still classifiable
+            else:
+                assert "upper_bound" in names and "numeric_class" not in names   # general pipeline
+            Cp = bh.get_rowptrC()
+            nnzC = bh.get_nnzC()
+            Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+            assert bh.get_C(Cj, Cx) == 0
+            assert bh.nnzCt == oracle.nnzCt(rp2, col, rp)
+            assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+def _toeplitz(m, n, offsets, rng, holes=()):
+    """m x n matrix whose row i has the columns i + o for o in offsets (those inside the matrix): every interior row
+    has the same relative pattern.  `holes`: rows left empty."""
+    rows = []
+    for i in range(m):
+        c = np.array([i + o for o in offsets if 0 <= i + o < n], np.int64)
+        rows.append(np.empty(0, np.int64) if i in holes else c)
+    rp = np.zeros(m + 1, np.int32)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.int32) if rp[-1] else np.empty(0, np.int32)
+    return rp, col, rng.integers(1, 10, len(col)).astype(np.float64)
+
+
+@pytest.mark.parametrize("case", ["p27", "p5", "p7", "p9", "rect_toeplitz", "holes", "float_values", "f32_build",
+                                  "unsorted_b"])
+def test_row_class_path(oracle, case):
+    """Row classes (bhs_class.hip.h): inputs whose rows repeat one another's relative pattern take the class kernels --
+    classify_rows / class_patterns / numeric_class instead of upper bound, symbolic and numeric bins -- and give the
+    oracle's C: rowPtr and colInd bit-exact, values exact for integer-valued inputs."""
+    rng = np.random.default_rng(31)
+    value_dtype = np.float32 if case == "f32_build" else np.float64
+    opts = {}
+    if case in ("p27", "float_values", "f32_build"):
+        m, rp, col, val = poisson_case("poisson27pt", 13, 12, 11); k = n = m
+        A = B = (rp, col, val)
+    elif case in ("p5", "p7", "p9"):
+        dims = {"p5": (70, 61, 1), "p7": (17, 16, 15), "p9": (45, 52, 1)}[case]
+        m, rp, col, val = poisson_case({"p5": "poisson5pt", "p7": "poisson7pt", "p9": "poisson9pt"}[case], *dims); k = n = m
+        A = B = (rp, col, val)
+    elif case == "rect_toeplitz":
+        m, k, n = 3000, 3500, 5000          # relative columns far from 0, rows cut off at every border
+        A = _toeplitz(m, k, (-40, -3, 0, 1, 2, 500, 501, 3400), rng)
+        B = _toeplitz(k, n, (-700, -1, 0, 1, 5, 6, 7, 1499), rng)
+    elif case == "holes":
+        m = k = n = 4000
+        A = _toeplitz(m, k, (-64, -1, 0, 1, 64), rng, holes={0, 17, 2000, 3999})
+        B = _toeplitz(k, n, (-64, -2, 0, 2, 64), rng, holes={1, 18, 1999})
+    else:                                    # rows of B stored in descending order: the class pattern is sorted anyway
+        m = k = n = 2500
+        A = _toeplitz(m, k, (-50, -1, 0, 1, 50), rng)
+        Bp, Bj, Bx = _toeplitz(k, n, (-50, -1, 0, 1, 50), rng)
+        for j in range(k):
+            Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][::-1]
+            Bx[Bp[j]:Bp[j + 1]] = Bx[Bp[j]:Bp[j + 1]][::-1]
+        B = (Bp, Bj, Bx)
+        opts = {"sort_b": 0}
+    Ax, Bx = A[2], B[2]
+    if case == "float_values":
+        Ax = rng.standard_normal(len(Ax)); Bx = Ax if B is A else rng.standard_normal(len(Bx))
+    ref = oracle.spgemm(m, k, n, A[0], A[1], Ax, B[0], B[1], Bx)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, A[0], A[1], Ax.astype(value_dtype), B[0], B[1], Bx.astype(value_dtype),
+                                  options=opts, value_dtype=value_dtype)
+    names = _kernel_names(info)
+    assert {"classify_rows", "class_patterns", "numeric_class"} <= names and "upper_bound" not in names, names
+    assert not any(nm.startswith("symbolic_") or nm.startswith("numeric_w") for nm in names), names
+    assert info["nnzCt"] == oracle.nnzCt(A[0], A[1], B[0]) and info["nnzC"] == ref[0][-1]
+    assert np.array_equal(Cp, ref[0]) and np.array_equal(Cj, ref[1])
+    if case == "float_values":
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=REL_TOL)["ok"]
+    else:
+        assert np.array_equal(Cx.astype(np.float64), ref[2])
+    check_csr_invariants(m, n, Cp, Cj)
+    numc = [kk for kk in info["kernels"] if kk["name"] == "numeric_class"][0]
+    assert numc["rows"] == m and numc["products"] == info["nnzCt"] and numc["nnz_out"] == info["nnzC"]
+
+
+@pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
+def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
+    """Inputs the class tables cannot take: more classes than table slots (unstructured rows), a class with more than
+    1024 products or 512 entries per row, a row with more than 64 entries.  The multiply starts over on the general
+    pipeline (same call, right answer) and the data set stays there: the next multiply does not classify again."""
+    rng = np.random.default_rng(32)
+    if case == "random_short_rows":
+        m, k, n = 12000, 12000, 12000
+        A = random_csr(m, k, 8.0 / k, rng)
+        B = random_csr(k, n, 8.0 / n, rng)
+        tried = True
+    elif case == "too_many_products":
+        m = k = n = 3000                       # 40 x 40 = 1600 products per row
+        offs = tuple(range(-20, 20))
+        A = _toeplitz(m, k, offs, rng)
+        B = _toeplitz(k, n, tuple(7 * o for o in offs), rng)
+        tried = True
+    elif case == "too_many_entries":
+        m = k = n = 3000                       # 24 x 30 = 720 products, 24 * 30 distinct columns > 512
+        A = _toeplitz(m, k, tuple(100 * o for o in range(-12, 12)), rng)
+        B = _toeplitz(k, n, tuple(range(-15, 15)), rng)
+        tried = True
+    else:
+        m = k = n = 2000
+        rp, col, val = _toeplitz(m, k, (-1, 0, 1), rng)
+        rows = [col[rp[i]:rp[i + 1]] for i in range(m)]
+        rows[700] = np.arange(600, 700)        # 100 entries: the hint from bhs_set_data keeps the class path away
+        rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
+        col = np.concatenate(rows).astype(np.int32)
+        A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+        tried = False
+    ref = oracle.spgemm(m, k, n, *A, *B)
     plats = [False] * bhmod.NUM_PLATFORMS
     plats[bhmod.BHSPARSE_HIP] = True
     bh = bhmod.bhsparse()
     assert bh.initPlatform(plats) == 0
-    assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
-    assert bh.spgemm() == 0
-    first = {s["name"] for s in bh.kernel_stats()}
-    assert "upper_bound" not in first            # the direct path ran
-    # row 5 of A swallows rows 5..11 (same arrays, same nnz): 7 rows' worth of entries in one row
-    rp2 = rp.copy()
-    rp2[6:12] = rp[12]
-    Ap.copy_(t(rp2))
-    torch.cuda.synchronize()
-    ref = oracle.spgemm(m, m, m, rp2, col, val, rp, col, val)
-    for _ in range(2):
+    Cp = np.zeros(m + 1, np.int32)
+    assert bh.initData(m, k, n, len(A[1]), A[2], A[0], A[1], len(B[1]), B[2], B[0], B[1], Cp) == 0
+    for it in range(2):
         assert bh.spgemm() == 0
-        assert "upper_bound" in {s["name"] for s in bh.kernel_stats()}       # general pipeline
-        Cp = bh.get_rowptrC()
-        nnzC = bh.get_nnzC()
-        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        names = {s["name"] for s in bh.kernel_stats() if s["launches"]}
+        assert "numeric_class" not in names
+        assert ("classify_rows" in names) == (tried and it == 0), (it, names)
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
         assert bh.get_C(Cj, Cx) == 0
-        assert bh.nnzCt == oracle.nnzCt(rp2, col, rp)
+        assert bh.nnzCt == oracle.nnzCt(A[0], A[1], B[0])
         assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
