@@ -230,7 +230,11 @@ def main():
         ks = kstats[kname]
         avg_ms = ks["ms"] / max(1, ks["launches"])
         rows_k, nnzA_k, out_k = ks["rows"], ks["nnzA_rows"], ks["nnz_out"]
-        if kname.startswith("numeric"):
+        if kname == "numeric_class":
+            # row classes (bhs_class.hip.h): A rows (col+val) + rowPtrA, the class of every row, rowPtrB and B's VALUES
+            # once (the kernel never reads colIndB), C rows written once + rowPtrC read
+            alg = 12 * nnzA_k + 4 * rows_k + 4 * rows_k + 8 * nnzB + 4 * (m + 1) + 12 * out_k + 4 * rows_k
+        elif kname.startswith("numeric"):
             # A rows (col+val) + their rowPtr pairs, B once (col+val+rowPtr), C rows written once + rowPtrC read
             alg = 12 * nnzA_k + 8 * rows_k + 12 * nnzB + 4 * (m + 1) + 12 * out_k + 4 * rows_k
         elif kname.startswith("symbolic"):
@@ -303,13 +307,13 @@ def main():
             cpu["mismatch"] = chk
 
     # ---- second headline: the same multiply with every launch shortcut that rests on per-dataset row bounds
-    # switched off (no lane-first / wave-first / numeric-first: upper-bound pass, host round trip and queues as for
-    # an arbitrary matrix).  The shortcuts are verified on the device inside the timed multiply (a refuted bound
+    # switched off (no row classes, no lane-first / wave-first / numeric-first: upper-bound pass, host round trip and
+    # queues as for an arbitrary matrix).  The shortcuts are verified on the device inside the timed multiply (a refuted bound
     # re-runs the general pipeline), but their choice comes from bhs_set_data's scans -- `setup_ms` -- so both
     # figures are printed.
     general = None
     if world == 1 and not args.no_general:
-        for key in ("wave_first", "lane_first", "direct_bins"):
+        for key in ("class_path", "wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 0) == 0
         for _ in range(2):
             assert bh.spgemm() == 0
@@ -319,9 +323,9 @@ def main():
             tq = time.perf_counter()
             assert bh.spgemm() == 0
             tg.append((time.perf_counter() - tq) * 1e3)
-        general = {"options": "wave_first=0 lane_first=0 direct_bins=0", "ms_median": round(float(np.median(tg)), 4),
+        general = {"options": "class_path=0 wave_first=0 lane_first=0 direct_bins=0", "ms_median": round(float(np.median(tg)), 4),
                    "ms_min": round(float(np.min(tg)), 4), "gflops_median": round(2.0 * bh.nnzCt / (float(np.median(tg)) * 1e6), 2)}
-        for key in ("wave_first", "lane_first", "direct_bins"):
+        for key in ("class_path", "wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 1) == 0
 
     # ---- the other single-GPU configurations of BASELINE.json, short runs, reported beside the headline

@@ -84,125 +84,144 @@ __global__ __launch_bounds__(256) void k_class_rows(int nrows, const int* __rest
     __syncthreads();
     const int leaderLane = lane - g;                               // first lane of this lane's group
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << leaderLane;
-    const long long span = ((long long)nrows + RPB - 1) / RPB * RPB;     // whole blocks take part in the shuffles
-    for (long long row = (long long)blockIdx.x * RPB + tid / G; row < span; row += (long long)gridDim.x * RPB) {
-        int cls = -1;
-        const bool live = row < nrows;
-        int a0 = 0, len = 0;
-        if (live) { a0 = Rp[row]; len = Rp[row + 1] - a0; }
-        bool ok = live && len <= kClassMaxRow;
-        // all loads of the row first, without predicates (a position past the row's end re-reads its last entry), so
-        // that they are in flight together; then the gather of the B classes, likewise; then the hash
-        int el[E], cb[E], cc[E];
-        unsigned hp = 0;
-        bool bad = false;
-        const int lastPos = ok && len > 0 ? a0 + len - 1 : 0;
+    // R row sets per pass and lane group: their load chains (rowPtr -> colInd -> B class) are independent, so the
+    // three memory round trips of a pass are shared by R rows per group instead of paid per row
+    constexpr int R = 2;
+    const long long span = ((long long)nrows + RPB * R - 1) / (RPB * R) * (RPB * R);   // whole blocks take part in the shuffles
+    for (long long row0 = (long long)blockIdx.x * RPB * R + tid / G; row0 < span; row0 += (long long)gridDim.x * RPB * R) {
+        long long rowv[R];
+        bool live[R], ok[R];
+        int a0[R], len[R], el[R][E], cb[R][E], cc[R][E];
+        unsigned h[R];
 #pragma unroll
-        for (int e = 0; e < E; ++e) cc[e] = Rj[min(a0 + e * G + g, lastPos)];
+        for (int r = 0; r < R; ++r) {
+            rowv[r] = row0 + (long long)r * RPB;
+            live[r] = rowv[r] < nrows;
+            a0[r] = 0;
+            len[r] = 0;
+            if (live[r]) { a0[r] = Rp[rowv[r]]; len[r] = Rp[rowv[r] + 1] - a0[r]; }
+            ok[r] = live[r] && len[r] <= kClassMaxRow;
+        }
+        // all loads of the rows first, without predicates (a position past the row's end re-reads its last entry), so
+        // that they are in flight together; then the gather of the B classes, likewise; then the hashes
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int lastPos = ok[r] && len[r] > 0 ? a0[r] + len[r] - 1 : 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) cc[r][e] = Rj[min(a0[r] + e * G + g, lastPos)];
+        }
         if (IS_A) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) cb[e] = classB[cc[e]];
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < E; ++e) cb[r][e] = classB[cc[r][e]];
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int pos = e * G + g;
-            const bool in = ok && pos < len;
-            el[e] = in ? cc[e] - (int)row : 0;
-            if (!IS_A || !in) cb[e] = 0;
-            unsigned hh = class_mix(0x85EBCA6Bu * (unsigned)(pos + 1), (unsigned)el[e]);
-            if (IS_A) {
-                bad = bad || cb[e] < 0;
-                hh = class_mix(hh, (unsigned)cb[e]);
+        for (int r = 0; r < R; ++r) {
+            unsigned hp = 0;
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pos = e * G + g;
+                const bool in = ok[r] && pos < len[r];
+                el[r][e] = in ? cc[r][e] - (int)rowv[r] : 0;
+                if (!IS_A || !in) cb[r][e] = 0;
+                unsigned hh = class_mix(0x85EBCA6Bu * (unsigned)(pos + 1), (unsigned)el[r][e]);
+                if (IS_A) {
+                    bad = bad || cb[r][e] < 0;
+                    hh = class_mix(hh, (unsigned)cb[r][e]);
+                }
+                hp += in ? hh : 0u;
             }
-            hp += in ? hh : 0u;
+            if (IS_A && (__ballot(bad) & gmask)) ok[r] = false;    // a B row without a class: none for this row either
+            h[r] = group_sum_u32<G>(hp) + (unsigned)len[r] * 0x9E3779B1u + 1u;
         }
-        if (IS_A && (__ballot(bad) & gmask)) ok = false;           // a B row without a class: none for this row either
-        const unsigned h = group_sum_u32<G>(hp) + (unsigned)len * 0x9E3779B1u + 1u;
-        // does this row equal row `rep` entry by entry?  (one entry per lane and pass; the group votes)
-        auto equals = [&](bool cand, int rep) {
-            bool same = true;
-            if (cand && rep != (int)row) {
-                const int r0 = Rp[rep];
-                same = Rp[rep + 1] - r0 == len;
-                if (same) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int pos = e * G + g;
-                        if (pos < len) {
-                            const int cr = Rj[r0 + pos];
-                            same = same && el[e] == cr - rep;
-                            if (IS_A) same = same && cb[e] == classB[cr];
+        for (int r = 0; r < R; ++r) {
+            const long long row = rowv[r];
+            const unsigned hr = h[r];
+            const int lenr = len[r];
+            int cls = -1;
+            // does this row equal row `rep` entry by entry?  (one entry per lane and pass; the group votes)
+            auto equals = [&](bool cand, int rep) {
+                bool same = true;
+                if (cand && rep != (int)row) {
+                    const int r0 = Rp[rep];
+                    same = Rp[rep + 1] - r0 == lenr;
+                    if (same) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int pos = e * G + g;
+                            if (pos < lenr) {
+                                const int cr = Rj[r0 + pos];
+                                same = same && el[r][e] == cr - rep;
+                                if (IS_A) same = same && cb[r][e] == classB[cr];
+                            }
                         }
                     }
                 }
-            }
-            return cand && !(__ballot(cand && !same) & gmask);
-        };
-        bool searching = ok;
-        const int ci = (int)(h & (NC - 1));
-        {
-            unsigned tg = 0xFFFFFFFFu;
-            if (searching && g == 0) tg = ctag[ci];
-            tg = (unsigned)__shfl((int)tg, leaderLane, 64);
-            const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (h >> 12);
-            bool same = true;
+                return cand && !(__ballot(cand && !same) & gmask);
+            };
+            bool searching = ok[r];
+            const int ci = (int)(hr & (NC - 1));
             {
-                same = cpat[ci][kClassMaxRow - 1] == len || len == kClassMaxRow;      // (the last cell holds the length of shorter rows)
+                unsigned tg = 0xFFFFFFFFu;
+                if (searching && g == 0) tg = ctag[ci];
+                tg = (unsigned)__shfl((int)tg, leaderLane, 64);
+                const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (hr >> 12);
+                bool same = cpat[ci][kClassMaxRow - 1] == lenr || lenr == kClassMaxRow;   // (the last cell holds the length of shorter rows)
                 int pc[E], pb[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { pc[e] = cpat[ci][e * G + g]; pb[e] = IS_A ? cpatB[ci][e * G + g] : 0; }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const bool in = e * G + g < len;
-                    same = same && (!in || (el[e] == pc[e] && (!IS_A || cb[e] == pb[e])));
+                    const bool in = e * G + g < lenr;
+                    same = same && (!in || (el[r][e] == pc[e] && (!IS_A || cb[r][e] == pb[e])));
                 }
+                if (cand && !(__ballot(cand && !same) & gmask)) { cls = (int)(tg >> 20); searching = false; }
             }
-            if (cand && !(__ballot(cand && !same) & gmask)) { cls = (int)(tg >> 20); searching = false; }
-        }
-        const unsigned long long mine = ((unsigned long long)h << 32) | (unsigned)row;
-        int s = (int)(h & (kClassSlots - 1));
-        for (int probe = 0; probe < kClassProbe; ++probe) {
-            if (!__any(searching)) break;
-#ifdef BHS_CLS_DEBUG
-            if (lane == 0) atomicAdd(&stats[7], 1);
-#endif
-            // An entry changes once (empty -> final).  The load is device-coherent: a plain one could keep returning
-            // the "empty" line this XCD's L2 cached before another XCD claimed the slot.
-            unsigned long long v = kClassEmpty;
-            if (searching && g == 0) {
-                v = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v == kClassEmpty) {
-                    const unsigned long long old = atomicCAS(&table[s], kClassEmpty, mine);
-                    v = old == kClassEmpty ? mine : old;
-                }
-            }
-            v = (unsigned long long)__shfl((long long)v, leaderLane, 64);
-            const int rep = (int)(unsigned)v;
-            if (equals(searching && (unsigned)(v >> 32) == h, rep)) {
-                cls = s;
-                searching = false;
-                // publish in the block's cache if its cell is still free
-                unsigned won = 0;
-                if (g == 0) won = atomicCAS(&ctag[ci], 0xFFFFFFFFu, kBusy) == 0xFFFFFFFFu ? 1u : 0u;
-                won = (unsigned)__shfl((int)won, leaderLane, 64);
-                if (won) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int pos = e * G + g;
-                        if (pos < len) {
-                            cpat[ci][pos] = el[e];
-                            if (IS_A) cpatB[ci][pos] = cb[e];
-                        }
+            const unsigned long long mine = ((unsigned long long)hr << 32) | (unsigned)row;
+            int s = (int)(hr & (kClassSlots - 1));
+            for (int probe = 0; probe < kClassProbe; ++probe) {
+                if (!__any(searching)) break;
+                // An entry changes once (empty -> final).  The load is device-coherent: a plain one could keep
+                // returning the "empty" line this XCD's L2 cached before another XCD claimed the slot.
+                unsigned long long v = kClassEmpty;
+                if (searching && g == 0) {
+                    v = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == kClassEmpty) {
+                        const unsigned long long old = atomicCAS(&table[s], kClassEmpty, mine);
+                        v = old == kClassEmpty ? mine : old;
                     }
-                    if (g == 0 && len < kClassMaxRow) cpat[ci][kClassMaxRow - 1] = len;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (g == 0) ctag[ci] = ((unsigned)s << 20) | (h >> 12);
                 }
+                v = (unsigned long long)__shfl((long long)v, leaderLane, 64);
+                const int rep = (int)(unsigned)v;
+                if (equals(searching && (unsigned)(v >> 32) == hr, rep)) {
+                    cls = s;
+                    searching = false;
+                    // publish in the block's cache if its cell is still free
+                    unsigned won = 0;
+                    if (g == 0) won = atomicCAS(&ctag[ci], 0xFFFFFFFFu, kBusy) == 0xFFFFFFFFu ? 1u : 0u;
+                    won = (unsigned)__shfl((int)won, leaderLane, 64);
+                    if (won) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int pos = e * G + g;
+                            if (pos < lenr) {
+                                cpat[ci][pos] = el[r][e];
+                                if (IS_A) cpatB[ci][pos] = cb[r][e];
+                            }
+                        }
+                        if (g == 0 && lenr < kClassMaxRow) cpat[ci][kClassMaxRow - 1] = lenr;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (g == 0) ctag[ci] = ((unsigned)s << 20) | (hr >> 12);
+                    }
+                }
+                s = (s + 1) & (kClassSlots - 1);
             }
-            s = (s + 1) & (kClassSlots - 1);
+            if (live[r] && g == 0) classOut[row] = cls;
+            if (__any(live[r] && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
         }
-        if (live && g == 0) classOut[row] = cls;
-        if (__any(live && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
     }
 }
 
@@ -448,6 +467,7 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
 #pragma unroll
             for (int u = 0; u < MAXU; ++u) {
                 if (BHS_CLS_ABL & 2) { if (axv[u] * bv[u] == 12345.678) acc[0] = 1.0; }
+                else if (BHS_CLS_ABL & 32) { acc[mp[u] >> 16] += axv[u] * bv[u]; __builtin_amdgcn_wave_barrier(); }
                 else unsafeAtomicAdd(&acc[mp[u] >> 16], axv[u] * bv[u]);
             }
             wave_sync();

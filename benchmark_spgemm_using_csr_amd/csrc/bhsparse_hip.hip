@@ -138,8 +138,8 @@ struct bhs_handle {
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
-    int classGridMul = 8, classPerLane = 4;   // tuning hooks of k_class_rows
-    int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries, until one multiply finds
+    int classGridMul = 8, classPerLane = 4, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
     DevBuf classB, classC, classTab, classInfo, classMap, classRel;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
@@ -1151,8 +1151,11 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     SymChoices sc;
     // Row classes first, for data sets whose rows are short on both sides (the hint from bhs_set_data time is
     // verified on the device row by row)
+    // ... and long enough for the classification passes to pay: poisson27pt (729 products per row) runs 4.85 -> 3.1 ms
+    // on the class kernels, poisson9pt (81) 0.58 -> 0.88 ms -- its whole general pipeline costs less than classifying
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
-                          h->maxRowA <= kClassMaxRow && h->maxRowB <= kClassMaxRow;
+                          h->maxRowA <= kClassMaxRow && h->maxRowB <= kClassMaxRow &&
+                          (h->classPath == 2 || h->avgRowA * h->avgRowB >= (double)h->classMinProducts);
     if (useClass) {
         BHS_TRY(symbolic_class(h));
         sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)
@@ -1998,7 +2001,8 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
-    if (!strcmp(key, "class_path")) { h->classPath = value != 0; h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_slots")) { h->hubMaxSlots = (int)value; return BHS_SUCCESS; }

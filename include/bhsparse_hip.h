@@ -221,6 +221,13 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)
+ *   "class_path"      row classes (bhs_class.hip.h): rows that repeat one another's relative pattern -- stencils, anything
+ *                     assembled on a regular grid -- get their structure (sorted columns, entry count, product ->
+ *                     position map) worked out once per class instead of once per row.  1 (default): tried on data
+ *                     sets whose rows of A and B have at most 64 entries and, on average, at least
+ *                     "class_min_products" (default 256) products per row of C; every row is classified and verified
+ *                     on the device, and a data set with rows that find no class goes back to the general pipeline
+ *                     for good.  2: tried whatever the average; 0: never.
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),

@@ -28,7 +28,7 @@ def _check(oracle, m, k, n, A, B, exact=True, options=None):
     Bp, Bj, Bx = B
     ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
     if options is None or "class_path" not in options:
-        Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=options)
+        Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=dict(options or {}, class_path=2))
         assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp) and info["nnzC"] == ref[0][-1]
         res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=REL_TOL)
         assert res["ok"], ("class path / defaults", res)
@@ -880,7 +880,7 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
         plats[bhmod.BHSPARSE_HIP] = True
         bh = bhmod.bhsparse()
         assert bh.initPlatform(plats) == 0
-        assert bh.set_option("class_path", class_path) == 0
+        assert bh.set_option("class_path", 2 * class_path) == 0
         assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
         assert bh.spgemm() == 0
         first = {s["name"] for s in bh.kernel_stats()}
@@ -929,7 +929,7 @@ def test_row_class_path(oracle, case):
     oracle's C: rowPtr and colInd bit-exact, values exact for integer-valued inputs."""
     rng = np.random.default_rng(31)
     value_dtype = np.float32 if case == "f32_build" else np.float64
-    opts = {}
+    opts = {"class_path": 2}                  # (whatever the average number of products per row)
     if case in ("p27", "float_values", "f32_build"):
         m, rp, col, val = poisson_case("poisson27pt", 13, 12, 11); k = n = m
         A = B = (rp, col, val)
@@ -953,7 +953,7 @@ def test_row_class_path(oracle, case):
             Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][::-1]
             Bx[Bp[j]:Bp[j + 1]] = Bx[Bp[j]:Bp[j + 1]][::-1]
         B = (Bp, Bj, Bx)
-        opts = {"sort_b": 0}
+        opts = {"sort_b": 0, "class_path": 2}
     Ax, Bx = A[2], B[2]
     if case == "float_values":
         Ax = rng.standard_normal(len(Ax)); Bx = Ax if B is A else rng.standard_normal(len(Bx))
@@ -972,6 +972,11 @@ def test_row_class_path(oracle, case):
     check_csr_invariants(m, n, Cp, Cj)
     numc = [kk for kk in info["kernels"] if kk["name"] == "numeric_class"][0]
     assert numc["rows"] == m and numc["products"] == info["nnzCt"] and numc["nnz_out"] == info["nnzC"]
+    if case in ("p27", "p5", "p9"):
+        # left to itself (class_path = 1) the library takes the class kernels where they pay: rows with a few hundred
+        # products (poisson27pt: 729), not the small stencils whose whole general pipeline is cheaper than classifying
+        _, _, _, info1 = spgemm_csr(m, k, n, A[0], A[1], Ax, B[0], B[1], Bx)
+        assert ("numeric_class" in _kernel_names(info1)) == (case == "p27")
 
 
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
@@ -1011,6 +1016,7 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     bh = bhmod.bhsparse()
     assert bh.initPlatform(plats) == 0
     Cp = np.zeros(m + 1, np.int32)
+    assert bh.set_option("class_path", 2) == 0
     assert bh.initData(m, k, n, len(A[1]), A[2], A[0], A[1], len(B[1]), B[2], B[0], B[1], Cp) == 0
     for it in range(2):
         assert bh.spgemm() == 0

@@ -24,6 +24,10 @@ def stat_name(k):
     mt = re.search(r"k_row_wave<(\d+), \d+, (true|false)", k)
     if mt:
         return "%s_wave<%s>" % ("numeric" if mt.group(2) == "true" else "symbolic", mt.group(1))
+    if "k_class_numeric" in k:
+        return "numeric_class"
+    if "k_class_rows" in k:
+        return None                      # (two launches, rows of B and of A, under one statistics name)
     if "k_num_rank" in k:
         return "numeric_rank"
     if "k_sym_sorted" in k:
