@@ -15,7 +15,7 @@ elif name == "denserows":
     val = gallery.fill_values(len(col))
     Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 else:
-    st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
+    st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p27_256": ("poisson27pt", (256, 256, 256)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
                 "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1)),
                 "p27_slab16": ("poisson27pt", (16, 16, 8192)), "p27_slab32": ("poisson27pt", (32, 32, 2048)),
                 "p27_slab64": ("poisson27pt", (64, 64, 512))}[name]
