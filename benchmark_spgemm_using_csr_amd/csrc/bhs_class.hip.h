@@ -61,14 +61,15 @@ __device__ __forceinline__ unsigned group_sum_u32(unsigned v)
     return v;
 }
 
+constexpr int kClassRowsBlock = 1024;      // large blocks: fewer block-local class caches to warm up
 template <bool IS_A, int G>
-__global__ __launch_bounds__(256) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
+__global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                     const int* __restrict__ classB,
                                                     unsigned long long* __restrict__ table,
                                                     int* __restrict__ classOut, int* __restrict__ stats)
 {
     constexpr int E = kClassMaxRow / G;                            // entries per lane
-    constexpr int RPB = 256 / G;                                   // rows per block and pass
+    constexpr int RPB = kClassRowsBlock / G;                       // rows per block and pass
     // Block-local cache of the table, indexed by the hash: {slot, 20 bits of the hash} and the class's pattern (the
     // relative columns, for A rows also the B classes) -- a row whose class is here is recognised without touching
     // the representative row in memory.  The blocks are persistent and a stretch of rows has few classes; the
@@ -97,9 +98,16 @@ __global__ __launch_bounds__(256) void k_class_rows(int nrows, const int* __rest
         for (int r = 0; r < R; ++r) {
             rowv[r] = row0 + (long long)r * RPB;
             live[r] = rowv[r] < nrows;
-            a0[r] = 0;
-            len[r] = 0;
-            if (live[r]) { a0[r] = Rp[rowv[r]]; len[r] = Rp[rowv[r] + 1] - a0[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                               // (unpredicated: both row sets' loads in flight)
+            const long long rr = live[r] ? rowv[r] : 0;
+            a0[r] = Rp[rr];
+            len[r] = Rp[rr + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            len[r] = live[r] ? len[r] - a0[r] : 0;
             ok[r] = live[r] && len[r] <= kClassMaxRow;
         }
         // all loads of the rows first, without predicates (a position past the row's end re-reads its last entry), so
@@ -145,20 +153,24 @@ __global__ __launch_bounds__(256) void k_class_rows(int nrows, const int* __rest
             // does this row equal row `rep` entry by entry?  (one entry per lane and pass; the group votes)
             auto equals = [&](bool cand, int rep) {
                 bool same = true;
-                if (cand && rep != (int)row) {
-                    const int r0 = Rp[rep];
-                    same = Rp[rep + 1] - r0 == lenr;
-                    if (same) {
+                if (__any(cand && rep != (int)row)) {               // (rare: a class this block meets for the first time)
+                    const int rp = cand ? rep : 0;
+                    const int r0 = Rp[rp], r1 = Rp[rp + 1];
+                    const int lastR = r1 > r0 ? r1 - 1 : 0;
+                    int cr[E], cbr[E];
 #pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            const int pos = e * G + g;
-                            if (pos < lenr) {
-                                const int cr = Rj[r0 + pos];
-                                same = same && el[r][e] == cr - rep;
-                                if (IS_A) same = same && cb[r][e] == classB[cr];
-                            }
-                        }
+                    for (int e = 0; e < E; ++e) cr[e] = Rj[min(r0 + e * G + g, lastR)];
+                    if (IS_A) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) cbr[e] = classB[cr[e]];
                     }
+                    same = r1 - r0 == lenr;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool in = e * G + g < lenr;
+                        same = same && (!in || (el[r][e] == cr[e] - rp && (!IS_A || cb[r][e] == cbr[e])));
+                    }
+                    same = same || rep == (int)row;
                 }
                 return cand && !(__ballot(cand && !same) & gmask);
             };
@@ -374,11 +386,14 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
 #ifndef BHS_CLS_ABL
 #define BHS_CLS_ABL 0
 #endif
+#ifndef BHS_CLS_PARTS
+#define BHS_CLS_PARTS 1
+#endif
 constexpr unsigned kClassIdle = 1u << 12;     // product triple of a lane without a product
 constexpr int kClassRun = 8;
 constexpr int kClassWaves = 4;
 
-template <int MAXU, int MAXV>
+template <int MAXU, int MAXV, int SE>            // SE: 64-entry passes that stage a run's A entries (<= kClassRun)
 __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, const int* __restrict__ classC,
@@ -399,7 +414,6 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
     const int xcd = blockIdx.x & 7, perX = (nRuns + 7) / 8;
     const int wavesPerX = (gridDim.x >> 3) * kClassWaves;
     const int wIdx = (blockIdx.x >> 3) * kClassWaves + wv;
-    constexpr int SE = kClassRun;                                  // staging passes: kClassRun rows x <= 64 entries
 
     int cur = -2, P = 0, nnz = 0;
     unsigned mp[MAXU];
@@ -450,25 +464,34 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
                 for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
             }
-            // every lane, every batch: the loads carry no predicate, so all MAXU of them are in flight at once
-            int bpv[MAXU];
-            acc_t bv[MAXU], axv[MAXU];
+            // every lane, every batch: the loads carry no predicate, so the MAXU / BHS_CLS_PARTS of a part are in flight
+            // at once (all MAXU at once keep 4 * MAXU registers live and cost two waves per SIMD)
+            constexpr int UP = (MAXU + BHS_CLS_PARTS - 1) / BHS_CLS_PARTS;
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) bpv[u] = sBp[off + (int)(mp[u] & 63u)];
+            for (int u0 = 0; u0 < MAXU; u0 += UP) {
+                int bpv[UP];
+                acc_t bv[UP], axv[UP];
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) {
-                const unsigned e = mp[u];
-                const int valid = (int)((e >> 12) & 1u) - 1;         // idle lane: 0, else all ones
-                const long long idx = (long long)((bpv[u] + (int)((e >> 6) & 63u)) & valid);
-                bv[u] = (BHS_CLS_ABL & 1) ? (acc_t)idx : (acc_t)Bx[idx];
-            }
+                for (int i = 0; i < UP; ++i) if (u0 + i < MAXU) bpv[i] = sBp[off + (int)(mp[u0 + i] & 63u)];
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) axv[u] = sAx[off + (int)(mp[u] & 63u)];
+                for (int i = 0; i < UP; ++i) {
+                    if (u0 + i < MAXU) {
+                        const unsigned e = mp[u0 + i];
+                        const int valid = (int)((e >> 12) & 1u) - 1;     // idle lane: 0, else all ones
+                        const long long idx = (long long)((bpv[i] + (int)((e >> 6) & 63u)) & valid);
+                        bv[i] = (BHS_CLS_ABL & 1) ? (acc_t)idx : (acc_t)Bx[idx];
+                    }
+                }
 #pragma unroll
-            for (int u = 0; u < MAXU; ++u) {
-                if (BHS_CLS_ABL & 2) { if (axv[u] * bv[u] == 12345.678) acc[0] = 1.0; }
-                else if (BHS_CLS_ABL & 32) { acc[mp[u] >> 16] += axv[u] * bv[u]; __builtin_amdgcn_wave_barrier(); }
-                else unsafeAtomicAdd(&acc[mp[u] >> 16], axv[u] * bv[u]);
+                for (int i = 0; i < UP; ++i) if (u0 + i < MAXU) axv[i] = sAx[off + (int)(mp[u0 + i] & 63u)];
+#pragma unroll
+                for (int i = 0; i < UP; ++i) {
+                    if (u0 + i < MAXU) {
+                        if (BHS_CLS_ABL & 2) { if (axv[i] * bv[i] == 12345.678) acc[0] = 1.0; }
+                        else unsafeAtomicAdd(&acc[mp[u0 + i] >> 16], axv[i] * bv[i]);
+                    }
+                }
+                if (BHS_CLS_PARTS > 1) __builtin_amdgcn_sched_barrier(0);
             }
             wave_sync();
 #pragma unroll

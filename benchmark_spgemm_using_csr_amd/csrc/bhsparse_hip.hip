@@ -138,7 +138,7 @@ struct bhs_handle {
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
-    int classGridMul = 8, classPerLane = 4, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classGridMul = 4, classPerLane = 4, classMinProducts = 256;   // tuning hooks of k_class_rows
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
     DevBuf classB, classC, classTab, classInfo, classMap, classRel;
@@ -410,10 +410,10 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
 }
 
 // Numeric pass by row classes on the rows [r0, r1)
-template <int MAXU, int MAXV>
+template <int MAXU, int MAXV, int SE>
 int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
 {
-    auto kern = k_class_numeric<MAXU, MAXV>;
+    auto kern = k_class_numeric<MAXU, MAXV, SE>;
     const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
     // staging area of a run: its rows' A entries (rounded up to whole 64-entry passes) and 64 entries of slack
     const int stageCap = ((kClassRun * h->ps.classMaxNA + 63) & ~63) + 64;
@@ -434,15 +434,24 @@ int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
     return BHS_SUCCESS;
 }
 
+template <int MAXU, int MAXV>
+int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
+{
+    const int passes = (kClassRun * h->ps.classMaxNA + 63) / 64;   // 64-entry passes that stage the A entries of a run
+    if (passes <= 2) return launch_class_numeric_impl<MAXU, MAXV, 2>(h, r0, r1);
+    if (passes <= 4) return launch_class_numeric_impl<MAXU, MAXV, 4>(h, r0, r1);
+    return launch_class_numeric_impl<MAXU, MAXV, kClassRun>(h, r0, r1);
+}
+
 int launch_class_numeric(bhs_handle* h, int r0, int r1)
 {
     const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
-    if (U <= 1 && V <= 1) return launch_class_numeric_impl<1, 1>(h, r0, r1);
-    if (U <= 2 && V <= 1) return launch_class_numeric_impl<2, 1>(h, r0, r1);
-    if (U <= 4 && V <= 2) return launch_class_numeric_impl<4, 2>(h, r0, r1);
-    if (U <= 8 && V <= 4) return launch_class_numeric_impl<8, 4>(h, r0, r1);
-    if (U <= 12 && V <= 2) return launch_class_numeric_impl<12, 2>(h, r0, r1);
-    return launch_class_numeric_impl<16, 8>(h, r0, r1);
+    if (U <= 1 && V <= 1) return launch_class_numeric_uv<1, 1>(h, r0, r1);
+    if (U <= 2 && V <= 1) return launch_class_numeric_uv<2, 1>(h, r0, r1);
+    if (U <= 4 && V <= 2) return launch_class_numeric_uv<4, 2>(h, r0, r1);
+    if (U <= 8 && V <= 4) return launch_class_numeric_uv<8, 4>(h, r0, r1);
+    if (U <= 12 && V <= 2) return launch_class_numeric_uv<12, 2>(h, r0, r1);
+    return launch_class_numeric_uv<16, 8>(h, r0, r1);
 }
 
 // Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
@@ -1075,9 +1084,9 @@ int symbolic_class(bhs_handle* h)
     const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
     // lanes per row: the average row, rounded up to a power of two
 #define BHS_CLASS_ROWS(ISA, G, grid, n, Rp, Rj, cb, tab, out)                                                  \
-    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(256), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats)
+    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats)
     auto rows_grid = [&](int n, int G) {
-        return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + 256 / G - 1) / (256 / G), (long long)h->numCU * h->classGridMul));
+        return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
     const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
     switch (GB) {
@@ -1155,7 +1164,10 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     // on the class kernels, poisson9pt (81) 0.58 -> 0.88 ms -- its whole general pipeline costs less than classifying
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
                           h->maxRowA <= kClassMaxRow && h->maxRowB <= kClassMaxRow &&
-                          (h->classPath == 2 || h->avgRowA * h->avgRowB >= (double)h->classMinProducts);
+                          (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
+                                                 // ... and enough of them: every block of the classifier meets every class once
+                                                 // (poisson27pt 51^3, 90 M products: 0.46 ms general, 0.50 ms by classes)
+                                                 (double)h->m * h->avgRowA * h->avgRowB >= 2.5e8));
     if (useClass) {
         BHS_TRY(symbolic_class(h));
         sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)

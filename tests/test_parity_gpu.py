@@ -974,9 +974,17 @@ def test_row_class_path(oracle, case):
     assert numc["rows"] == m and numc["products"] == info["nnzCt"] and numc["nnz_out"] == info["nnzC"]
     if case in ("p27", "p5", "p9"):
         # left to itself (class_path = 1) the library takes the class kernels where they pay: rows with a few hundred
-        # products (poisson27pt: 729), not the small stencils whose whole general pipeline is cheaper than classifying
+        # products (poisson27pt: 729) and at least 2.5e8 products in all -- not the small stencils, whose whole general
+        # pipeline is cheaper than classifying, and not small matrices
         _, _, _, info1 = spgemm_csr(m, k, n, A[0], A[1], Ax, B[0], B[1], Bx)
-        assert ("numeric_class" in _kernel_names(info1)) == (case == "p27")
+        assert "numeric_class" not in _kernel_names(info1)
+        if case == "p27":
+            m2, rp2, col2, val2 = poisson_case("poisson27pt", 72, 72, 72)
+            Cp2, Cj2, Cx2, info2 = spgemm_csr(m2, m2, m2, rp2, col2, val2, rp2, col2, val2)
+            assert "numeric_class" in _kernel_names(info2)
+            assert info2["nnzCt"] == oracle.nnzCt(rp2, col2, rp2)
+            Cp3, Cj3, Cx3, info3 = spgemm_csr(m2, m2, m2, rp2, col2, val2, rp2, col2, val2, options={"class_path": 0})
+            assert np.array_equal(Cp2, Cp3) and np.array_equal(Cj2, Cj3) and np.array_equal(Cx2, Cx3)
 
 
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
