@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     constexpr unsigned kBusy = 0xFFFFFFFEu;
     __shared__ unsigned ctag[NC];
     __shared__ int cpat[NC][kClassMaxRow];
+    __shared__ int clen[NC];
     __shared__ int cpatB[IS_A ? NC : 1][kClassMaxRow];
     const int tid = threadIdx.x, lane = tid & 63, g = tid % G;
     if (tid < NC) ctag[tid] = 0xFFFFFFFFu;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
                 if (searching && g == 0) tg = ctag[ci];
                 tg = (unsigned)__shfl((int)tg, leaderLane, 64);
                 const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (hr >> 12);
-                bool same = cpat[ci][kClassMaxRow - 1] == lenr || lenr == kClassMaxRow;   // (the last cell holds the length of shorter rows)
+                bool same = clen[ci] == lenr;
                 int pc[E], pb[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { pc[e] = cpat[ci][e * G + g]; pb[e] = IS_A ? cpatB[ci][e * G + g] : 0; }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
                                 if (IS_A) cpatB[ci][pos] = cb[r][e];
                             }
                         }
-                        if (g == 0 && lenr < kClassMaxRow) cpat[ci][kClassMaxRow - 1] = lenr;
+                        if (g == 0) clen[ci] = lenr;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (g == 0) ctag[ci] = ((unsigned)s << 20) | (hr >> 12);
                     }
