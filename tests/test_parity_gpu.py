@@ -1147,7 +1147,7 @@ def _phase_cases():
     yield "rect", A, B
 
 
-@pytest.mark.parametrize("rank_path", [0, 1])
+@pytest.mark.parametrize("rank_path", [0, 1, "classes"])
 @pytest.mark.parametrize("nranges", [1, 3, 7])
 def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
     """bhs_spgemm_symbolic / bhs_spgemm_numeric(row range) / bhs_spgemm_finish == bhs_spgemm, for every kernel family
@@ -1169,7 +1169,11 @@ def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
         plats[bhmod.BHSPARSE_HIP] = True
         bh = bhmod.bhsparse()
         assert bh.initPlatform(plats) == 0
-        assert bh.set_option("rank_path", rank_path) == 0          # (only the wave-first class takes it)
+        if rank_path == "classes":                                 # row classes whenever the rows classify (p27, p5)
+            assert bh.set_option("class_path", 2) == 0
+        else:
+            assert bh.set_option("class_path", 0) == 0
+            assert bh.set_option("rank_path", rank_path) == 0      # (only the wave-first class takes it)
         assert bh.initData_device(m, k, n, len(Aj), dA[2], dA[0], dA[1], len(Bj), dB[2], dB[0], dB[1]) == 0
         L, h = bh._lib, bh._h
         for external in (False, True):
@@ -1199,18 +1203,25 @@ def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
             assert res["ok"], (tag, external, res)
         # and an ordinary multiply on the same handle afterwards
         assert bh.spgemm() == 0 and bh.get_nnzC() == ref[0][-1]
+        if rank_path == "classes" and tag in ("p27", "p5"):
+            assert "numeric_class" in {s["name"] for s in bh.kernel_stats() if s["launches"]}, tag
         assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
 @pytest.mark.parametrize("sub_blocks", [1, 4])
-def test_native_allgatherv_world_size_1(oracle, sub_blocks):
+@pytest.mark.parametrize("kind", ["powerlaw", "stencil_classes"])
+def test_native_allgatherv_world_size_1(oracle, sub_blocks, kind):
     """libbhsparse_dist.so on one GPU (world_size 1: communicator, size exchange, in-place output, row-pointer rebase,
-    numeric half in row ranges; no peers to send to): the assembled CSR equals the oracle's, twice in a row."""
+    numeric half in row ranges; no peers to send to): the assembled CSR equals the oracle's, twice in a row.  Once on
+    the general pipeline (power-law rows) and once on the row-class kernels (what poisson27pt 256^3 takes per rank)."""
     import torch
     from benchmark_spgemm_using_csr_amd import dist as bdist, gallery
     dev = torch.device("cuda", 0)
-    rp, col = gallery.powerlaw_csr(20000, 20000, 80000, 2000, hubs=3)
-    val = gallery.fill_values(len(col))
+    if kind == "powerlaw":
+        rp, col = gallery.powerlaw_csr(20000, 20000, 80000, 2000, hubs=3)
+        val = gallery.fill_values(len(col))
+    else:
+        _, rp, col, val = poisson_case("poisson27pt", 17, 16, 15)
     m = len(rp) - 1
     ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -1219,6 +1230,7 @@ def test_native_allgatherv_world_size_1(oracle, sub_blocks):
     plats[bhmod.BHSPARSE_HIP] = True
     bh = bhmod.bhsparse()
     assert bh.initPlatform(plats) == 0
+    assert bh.set_option("class_path", 2 if kind == "stencil_classes" else 0) == 0
     assert bh.initData_device(m, m, m, len(col), dx, dp, dj, len(col), dx, dp, dj) == 0
     nd = bdist.NativeDist(bh, world=1, rank=0)
     cap = int(ref[0][-1]) + 17
@@ -1238,5 +1250,6 @@ def test_native_allgatherv_world_size_1(oracle, sub_blocks):
     with pytest.raises(RuntimeError):
         nd.spgemm_allgatherv(m, m, frp, small_c, small_v, sub_blocks=sub_blocks)
     assert bh.spgemm() == 0                       # the handle is usable afterwards
+    assert ("numeric_class" in {s["name"] for s in bh.kernel_stats() if s["launches"]}) == (kind == "stencil_classes")
     nd.close()
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
