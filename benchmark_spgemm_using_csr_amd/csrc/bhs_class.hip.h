@@ -39,7 +39,8 @@ constexpr unsigned long long kClassEmpty = ~0ull;
 constexpr int kClassSumSlots = 32;
 enum { CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
-       CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_INTS = 8 + 2 * kClassSumSlots };
+       CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
+       CS_INTS = 8 + 2 * kClassSumSlots + 2 };
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 {
@@ -53,6 +54,27 @@ __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 // G lanes share a row (coalesced loads of its entries, one entry per lane and pass); the row's hash is the sum of
 // its position-keyed element hashes, the comparison with the class's representative row is one entry per lane too.
 // ---------------------------------------------------------------------------
+// Smallest and largest column of A: when A is a row block of a larger product (multi-GPU: m rows of A against all k
+// rows of B) only the rows of B that A points at need a class.  range[0] = min (preset INT_MAX), range[1] = max (-1).
+__global__ __launch_bounds__(256) void k_class_col_range(long long nnzA, const int* __restrict__ Aj, int* __restrict__ range)
+{
+    __shared__ int smin[4], smax[4];
+    int lo = 0x7fffffff, hi = -1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nnzA; i += (long long)gridDim.x * 256) {
+        const int c = Aj[i];
+        lo = min(lo, c);
+        hi = max(hi, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&range[0], min(min(smin[0], smin[1]), min(smin[2], smin[3])));
+        atomicMax(&range[1], max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
+}
+
 template <int G>
 __device__ __forceinline__ unsigned group_sum_u32(unsigned v)
 {
@@ -66,7 +88,8 @@ template <bool IS_A, int G>
 __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                     const int* __restrict__ classB,
                                                     unsigned long long* __restrict__ table,
-                                                    int* __restrict__ classOut, int* __restrict__ stats)
+                                                    int* __restrict__ classOut, int* __restrict__ stats,
+                                                    const int* __restrict__ range)     // rows [range[0], range[1]] only (nullptr: all)
 {
     constexpr int E = kClassMaxRow / G;                            // entries per lane
     constexpr int RPB = kClassRowsBlock / G;                       // rows per block and pass
@@ -89,8 +112,14 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     // R row sets per pass and lane group: their load chains (rowPtr -> colInd -> B class) are independent, so the
     // three memory round trips of a pass are shared by R rows per group instead of paid per row
     constexpr int R = 2;
-    const long long span = ((long long)nrows + RPB * R - 1) / (RPB * R) * (RPB * R);   // whole blocks take part in the shuffles
-    for (long long row0 = (long long)blockIdx.x * RPB * R + tid / G; row0 < span; row0 += (long long)gridDim.x * RPB * R) {
+    long long first = 0;
+    if (range != nullptr) {                                        // (wave-uniform values)
+        const int lo = range[0], hi = range[1];
+        first = lo <= hi ? lo : 0;
+        nrows = lo <= hi ? min(nrows, hi + 1) : 0;
+    }
+    const long long span = first + ((long long)nrows - first + RPB * R - 1) / (RPB * R) * (RPB * R);   // whole blocks take part in the shuffles
+    for (long long row0 = first + (long long)blockIdx.x * RPB * R + tid / G; row0 < span; row0 += (long long)gridDim.x * RPB * R) {
         long long rowv[R];
         bool live[R], ok[R];
         int a0[R], len[R], el[R][E], cb[R][E], cc[R][E];

@@ -1083,25 +1083,35 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(timed_begin(h, "classify_rows", &ep));
     const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
     // lanes per row: the average row, rounded up to a power of two
-#define BHS_CLASS_ROWS(ISA, G, grid, n, Rp, Rj, cb, tab, out)                                                  \
-    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats)
+#define BHS_CLASS_ROWS(ISA, G, grid, n, Rp, Rj, cb, tab, out, rng)                                                  \
+    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng)
     auto rows_grid = [&](int n, int G) {
         return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
+    // A as a row block of a larger product (multi-GPU): only the rows of B that A points at need a class
+    const int* bRange = nullptr;
+    if ((long long)m * 2 <= (long long)k) {
+        int* rg = cstats + CS_RANGE;
+        BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)rg, 0x7fffffff, 1, h->stream));
+        BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)(rg + 1), -1, 1, h->stream));
+        const unsigned gr = (unsigned)std::max<long long>(1, std::min<long long>(((long long)h->nnzA + 255) / 256, (long long)h->numCU * 8));
+        hipLaunchKernelGGL(k_class_col_range, dim3(gr), dim3(256), 0, h->stream, (long long)h->nnzA, h->dAj, rg);
+        bRange = rg;
+    }
     const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
     switch (GB) {
-        case 4: BHS_CLASS_ROWS(false, 4, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
-        case 8: BHS_CLASS_ROWS(false, 8, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
-        case 16: BHS_CLASS_ROWS(false, 16, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
-        case 32: BHS_CLASS_ROWS(false, 32, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
-        default: BHS_CLASS_ROWS(false, 64, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p); break;
+        case 4: BHS_CLASS_ROWS(false, 4, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 8: BHS_CLASS_ROWS(false, 8, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 16: BHS_CLASS_ROWS(false, 16, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 32: BHS_CLASS_ROWS(false, 32, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        default: BHS_CLASS_ROWS(false, 64, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
     }
     switch (GA) {
-        case 4: BHS_CLASS_ROWS(true, 4, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
-        case 8: BHS_CLASS_ROWS(true, 8, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
-        case 16: BHS_CLASS_ROWS(true, 16, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
-        case 32: BHS_CLASS_ROWS(true, 32, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
-        default: BHS_CLASS_ROWS(true, 64, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p); break;
+        case 4: BHS_CLASS_ROWS(true, 4, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 8: BHS_CLASS_ROWS(true, 8, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 16: BHS_CLASS_ROWS(true, 16, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 32: BHS_CLASS_ROWS(true, 32, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        default: BHS_CLASS_ROWS(true, 64, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
     }
 #undef BHS_CLASS_ROWS
     BHS_HIP(hipGetLastError());

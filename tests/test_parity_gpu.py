@@ -922,7 +922,7 @@ def _toeplitz(m, n, offsets, rng, holes=()):
 
 
 @pytest.mark.parametrize("case", ["p27", "p5", "p7", "p9", "rect_toeplitz", "holes", "float_values", "f32_build",
-                                  "unsorted_b"])
+                                  "unsorted_b", "row_block"])
 def test_row_class_path(oracle, case):
     """Row classes (bhs_class.hip.h): inputs whose rows repeat one another's relative pattern take the class kernels --
     classify_rows / class_patterns / numeric_class instead of upper bound, symbolic and numeric bins -- and give the
@@ -937,6 +937,14 @@ def test_row_class_path(oracle, case):
         dims = {"p5": (70, 61, 1), "p7": (17, 16, 15), "p9": (45, 52, 1)}[case]
         m, rp, col, val = poisson_case({"p5": "poisson5pt", "p7": "poisson7pt", "p9": "poisson9pt"}[case], *dims); k = n = m
         A = B = (rp, col, val)
+    elif case == "row_block":
+        # A = rows [r0, r1) of a stencil matrix (what a rank of the multi-GPU layer multiplies): m << k, so only the
+        # rows of B between A's smallest and largest column are classified
+        k, rp, col, val = poisson_case("poisson27pt", 14, 13, 12); n = k
+        r0, r1 = 700, 1100
+        m = r1 - r0
+        A = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], val[rp[r0]:rp[r1]])
+        B = (rp, col, val)
     elif case == "rect_toeplitz":
         m, k, n = 3000, 3500, 5000          # relative columns far from 0, rows cut off at every border
         A = _toeplitz(m, k, (-40, -3, 0, 1, 2, 500, 501, 3400), rng)
