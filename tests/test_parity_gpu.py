@@ -995,6 +995,55 @@ def test_row_class_path(oracle, case):
             assert np.array_equal(Cp2, Cp3) and np.array_equal(Cj2, Cj3) and np.array_equal(Cx2, Cx3)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_row_class_path_randomized(oracle, seed):
+    """Randomised structured inputs against the oracle with the class kernels forced on: random offset lists (a few to
+    64 entries per row), rectangular shapes, rows cut off at the borders, a sprinkling of rows with extra or missing
+    entries (more classes, some met once), empty rows, B rows stored in random order, values of either sign."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(200, 3000)); k = int(rng.integers(200, 3000)); n = int(rng.integers(200, 4000))
+    na = int(rng.choice([1, 2, 5, 9, 17, 31, 64])); nb = int(rng.choice([1, 3, 7, 15, 16, 33]))
+
+    def structured(rows, cols, cnt, noise):
+        offs = np.unique(rng.integers(-cols // 3, cols // 3 + 1, cnt))
+        out = []
+        for i in range(rows):
+            c = i * cols // rows + offs
+            c = c[(c >= 0) & (c < cols)]
+            u = rng.random()
+            if u < noise / 2 and len(c) > 1:
+                c = np.delete(c, rng.integers(0, len(c)))
+            elif u < noise:
+                c = np.unique(np.append(c, rng.integers(0, cols)))
+            elif u < noise * 1.2:
+                c = c[:0]
+            out.append(np.unique(c)[:64])
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum([len(r) for r in out])
+        col = np.concatenate(out).astype(np.int32) if rp[-1] else np.empty(0, np.int32)
+        return rp, col
+
+    Ap, Aj = structured(m, k, na, 0.02)
+    Bp, Bj = structured(k, n, nb, 0.02)
+    if len(Aj) == 0 or len(Bj) == 0:
+        pytest.skip("degenerate draw")
+    Ax = rng.integers(-9, 10, len(Aj)).astype(np.float64)
+    Bx = rng.integers(-9, 10, len(Bj)).astype(np.float64)
+    opts = {"class_path": 2}
+    if seed % 3 == 0:                              # rows of B in random stored order, multiplied as they are
+        for j in range(k):
+            pm = rng.permutation(Bp[j + 1] - Bp[j])
+            Bj[Bp[j]:Bp[j + 1]] = Bj[Bp[j]:Bp[j + 1]][pm]
+            Bx[Bp[j]:Bp[j + 1]] = Bx[Bp[j]:Bp[j + 1]][pm]
+        opts["sort_b"] = 0
+    ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options=opts)
+    assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp) and info["nnzC"] == ref[0][-1]
+    res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+    assert res["ok"], (seed, res, sorted(_kernel_names(info)))
+    check_csr_invariants(m, n, Cp, Cj)
+
+
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
 def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     """Inputs the class tables cannot take: more classes than table slots (unstructured rows), a class with more than
