@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A "step" is one bhsparse::spgemm() (upper bound + binning -> symbolic -> scan ->
-numeric) over the synthetic matrix, inputs already resident in HBM; at N > 1 each
+A "step" is one bhsparse::spgemm() over the synthetic matrix, inputs already resident in HBM: for the stencil
+workloads here that is the row-class pipeline (classify the rows of B and A -> class patterns -> scan -> numeric,
+all of it inside the step, nothing kept between steps; `general_path` in the output line is the same multiply on the
+general pipeline: upper bound + binning -> symbolic -> scan -> numeric, every per-dataset shortcut off); at N > 1 each
 rank multiplies its row block of A by the replicated B and the step ends with the
 RCCL all-gatherv that assembles the full CSR of C on every rank.
 
