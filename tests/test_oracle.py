@@ -1,8 +1,9 @@
 """CPU tests (-m "not gpu"): pin the oracle against the golden vectors.
 
-The reference holds no expected outputs; the pins are the
-hand-derived answers for its two fixed inputs, scipy-generated fixtures
-(tests/golden/make_golden.py) and the Poisson closed forms.
+The reference holds no expected outputs.  Since round 3 the first pin is the REFERENCE ITSELF:
+tests/golden/ref_opencl_*.npz and ref_opencl_digests.json are outputs of its OpenCL branch (compiled unmodified,
+oracle/Makefile `_ref`, run on an MI355X by oracle/make_ref_golden.py).  Beside them: the hand-derived answers for
+the reference's two fixed inputs, scipy-generated fixtures (tests/golden/make_golden.py), the Poisson closed forms.
 """
 import json
 import os
@@ -146,3 +147,73 @@ def test_webbase_standin_matches_published_shape():
     d = np.diff(col.astype(np.int64))
     starts = np.zeros(len(col), bool); starts[rp[1:-1][rp[1:-1] < len(col)]] = True
     assert np.all((d > 0) | starts[1:])                             # rows sorted, duplicate-free
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Pins against outputs of the reference itself (SpGEMM_opencl on MI355X; generator: oracle/make_ref_golden.py).
+# Structure bit-exact; values bit-exact for the integer-valued inputs, 1e-6 relative (north_star) for cage4's reals.
+# ---------------------------------------------------------------------------------------------------------------
+REF_FULL = ["small_test", "p5_16", "p27_6", "p9_12", "p7_7", "rect_rand", "cage4", "cage4_ones", "p27_12",
+            "rand_bins", "cancel", "powerlaw_3k"]
+
+
+def _sorted_rows(Cp, Cj, Cx):
+    row = np.repeat(np.arange(len(Cp) - 1, dtype=np.int64), np.diff(Cp.astype(np.int64)))
+    order = np.lexsort((Cj, row))
+    return Cj[order], Cx[order]
+
+
+@pytest.mark.parametrize("tag", REF_FULL)
+def test_oracle_equals_reference_opencl_output(oracle, tag):
+    g = load_golden("ref_opencl_%s.npz" % tag)
+    Cp, Cj, Cx = _run(oracle, g)
+    rCj, rCx = _sorted_rows(g["Cp"], g["Cj"], g["Cx"])
+    assert bool(g["rows_sorted"])                      # the reference's kernels leave every row ascending
+    assert np.array_equal(Cp, g["Cp"].astype(np.int64))
+    assert np.array_equal(Cj, rCj)
+    if tag == "cage4":
+        assert np.all(np.abs(Cx - rCx) <= 1e-6 * np.abs(rCx))
+    else:
+        assert np.array_equal(Cx, rCx)
+    assert oracle.nnzCt(g["Ap"], g["Aj"], g["Bp"]) == int(g["nnzCt"])
+
+
+def test_reference_keeps_structural_zeros(oracle):
+    # SURVEY.md §8b "explicit zeros retained": pinned by the reference's own output for the cancellation case
+    g = load_golden("ref_opencl_cancel.npz")
+    assert int((g["Cx"] == 0.0).sum()) == 168
+    _, _, Cx = _run(oracle, g)
+    assert int((Cx == 0.0).sum()) == 168
+
+
+def test_reference_bins_are_all_exercised(oracle):
+    # rand_bins / powerlaw_3k were built to reach every bin of bhsparse.h:373-406 incl. the EM re-queue rounds
+    for tag, need in (("rand_bins", (0, 1, 2, 32, 33, 128, 129, 256, 257, 512, 513)), ("powerlaw_3k", (513, 2305, 9217))):
+        g = load_golden("ref_opencl_%s.npz" % tag)
+        _, ub = oracle.nnzCt(g["Ap"], g["Aj"], g["Bp"], want_ub=True)
+        for lo in need:
+            assert (ub >= lo).any(), (tag, lo)
+        if tag == "rand_bins":
+            assert (ub == 0).any() and ((ub >= 2) & (ub <= 32)).any() and ((ub >= 33) & (ub <= 512)).any()
+
+
+@pytest.mark.parametrize("tag,gen", [
+    ("p5_256", lambda: gallery.poisson_csr("poisson5pt", 256, 256, 1)),
+    ("p27_51", lambda: gallery.poisson_csr("poisson27pt", 51, 51, 51)),
+    ("powerlaw_20k", lambda: gallery.powerlaw_csr(20000, 20000, 90000, 3000)),
+])
+def test_oracle_equals_reference_opencl_digests(oracle, tag, gen):
+    # the reference's default benchmark sizes (main.cu:32-51) and a power-law case with rows of up to 67 k products:
+    # digests of the reference's C (the full comparison ran beside the reference on the GPU box: *_equal flags)
+    ref = json.load(open(os.path.join(GOLDEN, "ref_opencl_digests.json")))[tag]
+    assert ref["oracle_rowptr_equal"] and ref["oracle_col_equal"] and ref["oracle_val_bit_equal"]
+    rp, col = gen()
+    val = gallery.fill_values(len(col))
+    m = len(rp) - 1
+    assert m == ref["m"] and len(col) == ref["nnzA"]
+    Cp, Cj, Cx = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    t = np.arange(len(Cj), dtype=np.uint64) % np.uint64(8191) + np.uint64(1)
+    assert len(Cj) == ref["nnzC"] and int(Cp.astype(np.uint64).sum()) == ref["sum_rowptr"]
+    assert int((Cj.astype(np.uint64) * t).sum()) == ref["wsum_col"]
+    assert float(Cx.sum()) == ref["sum_val"] and float((Cx * t.astype(np.float64)).sum()) == ref["wsum_val"]
+    assert oracle.nnzCt(rp, col, rp) == ref["nnzCt"]

@@ -101,6 +101,31 @@ def test_golden_fixtures(oracle, name):
     assert info["nnzCt"] == int(g["nnzCt"])
 
 
+REF_OPENCL_CASES = ["small_test", "p5_16", "p27_6", "p9_12", "p7_7", "rect_rand", "cage4", "cage4_ones", "p27_12",
+                    "rand_bins", "cancel", "powerlaw_3k"]
+
+
+@pytest.mark.parametrize("class_path", [0, 2])
+@pytest.mark.parametrize("tag", REF_OPENCL_CASES)
+def test_hip_equals_reference_opencl_output(tag, class_path):
+    """The HIP path against outputs of the REFERENCE ITSELF (its OpenCL branch run on an MI355X,
+    oracle/make_ref_golden.py -> tests/golden/ref_opencl_*.npz) -- no oracle in between.  rowPtr / colInd bit-exact,
+    values bit-exact for the integer-valued inputs, 1e-6 relative for cage4's reals; every bin of the reference's
+    table (rand_bins), its multi-round EM merge (powerlaw_3k) and retained structural zeros (cancel)."""
+    g = load_golden("ref_opencl_%s.npz" % tag)
+    assert bool(g["rows_sorted"])
+    Cp, Cj, Cx, info = spgemm_csr(int(g["m"]), int(g["k"]), int(g["n"]), g["Ap"], g["Aj"], g["Ax"],
+                                  g["Bp"], g["Bj"], g["Bx"], options={"class_path": class_path})
+    assert info["nnzCt"] == int(g["nnzCt"]) and info["nnzC"] == len(g["Cj"])
+    assert np.array_equal(Cp, g["Cp"]) and np.array_equal(Cj, g["Cj"])
+    if tag == "cage4":
+        assert np.all(np.abs(Cx - g["Cx"]) <= REL_TOL * np.abs(g["Cx"]))
+    else:
+        assert np.array_equal(Cx, g["Cx"])
+    if tag == "cancel":
+        assert int((Cx == 0.0).sum()) == 168
+
+
 @pytest.mark.parametrize("stencil,dims", [("poisson5pt", (256, 256, 1)), ("poisson9pt", (256, 256, 1)),
                                           ("poisson7pt", (51, 51, 51)), ("poisson27pt", (51, 51, 51))])
 def test_reference_default_datasets(oracle, stencil, dims):
