@@ -17,10 +17,12 @@
 //   k_class_patterns     per class: the products of the representative row, sorted and made unique -> relative column
 //                        list, entry count, and for every product its {A entry, B entry, position} triple
 //   k_class_counts       rowPtrC counts: the class's entry count
-//   k_class_numeric      per row: 1 load of A's entries and rowPtrB, then every product is one load of B's value, one
-//                        multiply and one ds_add_f64 into its known position; the row is written out with its columns
-//                        (class list + row number) in ascending order.  No column of B is read, nothing is hashed,
-//                        compacted or sorted.
+//   k_class_numeric      per row: 1 load of A's entries and rowPtrB, then every product is one load of B's value and
+//                        one fma into a REGISTER: a lane holds consecutive products of the class's position-sorted
+//                        product list, so the products of one entry of C meet in one lane; the running sums go to
+//                        the entry's slot with plain LDS stores and the row is written out with its columns (class
+//                        list + row number) in ascending order.  No column of B is read, nothing is hashed,
+//                        compacted or sorted, and no LDS atomic runs per product.
 // Rows the tables cannot take (more than kClassMaxRow entries in a row of A or B, more than kClassMaxP products or
 // kClassMaxNnz entries per row, a full table) send the whole multiply back to the general pipeline, and the data set
 // stays there.  Replaces, for the matrices that qualify, all of SpGEMM_cuda/bhsparse_cuda.h:210-2780.
@@ -37,7 +39,7 @@ constexpr unsigned long long kClassEmpty = ~0ull;
 
 // `stats` block written by k_class_rows / k_class_patterns (ints)
 constexpr int kClassSumSlots = 32;
-enum { CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
+enum { CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
        CS_INTS = 8 + 2 * kClassSumSlots + 2 };
@@ -270,14 +272,35 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 // ---------------------------------------------------------------------------
 // Pattern of every class of A rows: one 256-lane workgroup per table slot.
 // classInfo[s] = {entries of the A row, products, entries of the C row (-1: beyond the limits), representative row}
-// classMap[s * kClassMaxP + p] = A entry | B entry << 6 | position << 16   for product p (A-entry-major order)
 // classRel[s * kClassMaxNnz + e] = column of entry e minus the row number, ascending
+// classMapA[s * kClassMaxP + p] = A entry | B entry << 6 | position << 16 for product p in A-entry-major order
+//   (k_class_numeric_atomic)
+// classMap[s * kClassMaxP + u * 64 + L] = product descriptor of lane L, step u of the workgroup numeric kernel.  The class's P
+//   products are sorted by (position in the row of C, product number) and dealt out in that order, U = ceil(P / 64)
+//   consecutive products per lane: the products that sum into one entry of C sit in ONE lane, one after the other
+//   (a few entries straddle a lane boundary).  Descriptor = A entry | B entry << 6 | kClassStart (first product of
+//   an entry within this lane: the running sum restarts) | kClassIdleBit (no product) | slot << 16, where slot is
+//   the entry's position, or kClassDump when the entry goes on in the NEXT lane (then the lane's sum at the end of
+//   its list is a partial sum that it adds to that entry's position, classLane[.. + L] below).  A lane with fewer
+//   than U products has its idle steps FIRST (the sum it carries at the end of the list is that of real products).
+// classLane[s * kClassLaneInts + ..]: [L] = tail position of lane L (-1: none); [64 + L] = chains of the A row --
+//   maximal stretches of A entries with consecutive columns, whose B rows are therefore one contiguous stretch of
+//   B's arrays, also across consecutive rows of the class: as A entry L: chain number (bits 0-5); as chain L
+//   (bit 31 set): first A entry (bits 8-13), last A entry (16-21), length of the last entry's B row (24-30);
+//   [128 + L] = length of the B row of A entry L; [192] = sum of the chains' last-entry lengths (what one more row of
+//   the class adds to the staged B values).
 // ---------------------------------------------------------------------------
+constexpr int kClassLaneInts = 256;
+constexpr unsigned kClassStart = 1u << 12, kClassIdleBit = 1u << 13, kClassDump = 1023u;
+constexpr unsigned kClassIdle = kClassStart | kClassIdleBit | (kClassDump << 16);   // descriptor of a lane without a product
+
 __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long* __restrict__ tableA,
                                                         const int* __restrict__ Ap, const int* __restrict__ Aj,
                                                         const int* __restrict__ Bp, const int* __restrict__ Bj,
                                                         int4* __restrict__ classInfo, unsigned* __restrict__ classMap,
-                                                        int* __restrict__ classRel, int* __restrict__ stats)
+                                                        unsigned* __restrict__ classMapA,
+                                                        int* __restrict__ classRel, int* __restrict__ classLane,
+                                                        int* __restrict__ stats)
 {
     __shared__ int keys[kClassMaxP], srt[kClassMaxP], pk[kClassMaxP];
     __shared__ int sIncl[kClassMaxRow], sB0[kClassMaxRow], scan[256];
@@ -308,6 +331,20 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
     }
     int N2 = 1;
     while (N2 < P) N2 <<= 1;
+    auto bitonic = [&]() {                                           // ascending sort of srt[0, N2)
+        for (int kk = 2; kk <= N2; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < N2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const int x = srt[i], y = srt[ixj];
+                        const bool up = (i & kk) == 0;
+                        if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+    };
     for (int p = tid; p < N2; p += 256) {
         int key = 0x7fffffff, code = 0;
         if (p < P) {
@@ -321,18 +358,7 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         pk[p] = code;
     }
     __syncthreads();
-    for (int kk = 2; kk <= N2; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const int x = srt[i], y = srt[ixj];
-                    const bool up = (i & kk) == 0;
-                    if ((x > y) == up) { srt[i] = y; srt[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
+    bitonic();
     // distinct keys: thread t owns srt[t * per .. (t + 1) * per)
     const int per = (N2 + 255) / 256;
     int heads = 0;
@@ -356,11 +382,68 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         if (i == 0 || srt[i] != srt[i - 1]) ulist[at++] = srt[i];
     __syncthreads();
     for (int e = tid; e < nnz; e += 256) classRel[(size_t)s * kClassMaxNnz + e] = ulist[e];
-    for (int p = tid; p < P; p += 256) {
-        const int key = keys[p];
-        int l = 0, r = nnz - 1;
-        while (l < r) { const int mid = (l + r) >> 1; if (ulist[mid] < key) l = mid + 1; else r = mid; }
-        classMap[(size_t)s * kClassMaxP + p] = (unsigned)pk[p] | ((unsigned)l << 16);
+    // second sort: the products by (position, product number) -- position << 10 | product
+    for (int p = tid; p < N2; p += 256) {
+        int sv = 0x7fffffff;
+        if (p < P) {
+            const int key = keys[p];
+            int l = 0, r = nnz - 1;
+            while (l < r) { const int mid = (l + r) >> 1; if (ulist[mid] < key) l = mid + 1; else r = mid; }
+            sv = (l << 10) | p;
+            classMapA[(size_t)s * kClassMaxP + p] = (unsigned)pk[p] | ((unsigned)l << 16);   // k_class_numeric_atomic's form
+        }
+        srt[p] = sv;
+    }
+    __syncthreads();
+    bitonic();
+    const int U = (P + 63) >> 6;
+    for (int idx = tid; idx < U * 64; idx += 256) {
+        const int L = idx & 63, u = idx >> 6;
+        const int first = L * U, last = min(P, first + U) - 1;      // ranks this lane holds
+        const int r = last - (U - 1 - u);                           // (right-aligned: idle steps first)
+        unsigned d = kClassIdle;
+        if (r >= first) {
+            const int sv = srt[r], l = sv >> 10;
+            const bool start = r == first || (srt[r - 1] >> 10) != l;
+            const bool goesOn = l == (srt[last] >> 10) && last + 1 < P && (srt[last + 1] >> 10) == l;
+            d = (unsigned)pk[sv & 1023] | (start ? kClassStart : 0u) | ((goesOn ? kClassDump : (unsigned)l) << 16);
+        }
+        classMap[(size_t)s * kClassMaxP + idx] = d;
+    }
+    if (tid < 64) {
+        const int first = tid * U, last = min(P, first + U) - 1;
+        int tail = -1;
+        if (first <= last && last + 1 < P && (srt[last + 1] >> 10) == (srt[last] >> 10)) tail = srt[last] >> 10;
+        classLane[(size_t)s * kClassLaneInts + tid] = tail;
+        // chains of the A row (stored order): entry k opens one unless its column follows entry k - 1's
+        const int col = tid < nA ? Aj[a0 + tid] : 0;
+        const int prev = __shfl_up(col, 1, 64);
+        const bool opens = tid < nA && (tid == 0 || col != prev + 1);
+        const unsigned long long om = __ballot(opens);
+        const int chain = __popcll(om & ((2ull << tid) - 1ull)) - 1;          // chain of entry tid
+        const int opened = 63 - __clzll((long long)(om & ((2ull << tid) - 1ull)));   // ... and the entry that opened it
+        int aux = tid < nA ? (chain | ((tid - opened) << 6)) : 0;
+        const int nCh = __popcll(om);
+        int lastLen = 0;
+        if (tid < nCh) {                                                       // as chain tid: its first / last entry
+            unsigned long long rest = om;
+            for (int i = 0; i < tid; ++i) rest &= rest - 1;                   // (<= 63 steps, once per class)
+            const int kf = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const int kl = (rest ? __ffsll((long long)rest) - 1 : nA) - 1;
+            lastLen = sIncl[kl] - (kl ? sIncl[kl - 1] : 0);
+            aux |= (int)(0x80000000u | ((unsigned)kf << 12) | ((unsigned)kl << 18) | ((unsigned)lastLen << 24));
+        }
+        classLane[(size_t)s * kClassLaneInts + 64 + tid] = aux;
+        const int myLen = tid < nA ? sIncl[tid] - (tid ? sIncl[tid - 1] : 0) : 0;
+        classLane[(size_t)s * kClassLaneInts + 128 + tid] = myLen;
+        int mx = myLen;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        if (tid == 0) atomicMax(&stats[CS_MAXLB], mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lastLen += __shfl_xor(lastLen, o, 64);
+        if (tid == 0) classLane[(size_t)s * kClassLaneInts + 192] = lastLen;
     }
     if (tid == 0) {
         classInfo[s] = make_int4(nA, P, nnz, rep);
@@ -398,7 +481,8 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
 }
 
 // ---------------------------------------------------------------------------
-// Numeric pass.  A wave takes runs of kClassRun consecutive rows (neighbouring rows share their B rows: L1 / L2 hits,
+// Numeric pass, round 2's form (kept as the default until the workgroup form of bhs_class_wg.hip.h beats it
+// everywhere; option class_numeric).  A wave takes runs of kClassRunA consecutive rows (neighbouring rows share their B rows: L1 / L2 hits,
 // and the rows of C they write are adjacent); blocks are dealt to the XCDs so that each XCD's L2 sees one contiguous
 // band of rows.
 //   per run   the A entries of its rows are one contiguous stretch of colIndA / valA: loaded with coalesced loads,
@@ -413,18 +497,15 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
 // with plain read-fma-write accumulation (3.5 ms: 56 partial-lane LDS instructions per row), the same with four
 // accumulator copies (3.9 ms), the same with atomics (4.0 ms).
 // ---------------------------------------------------------------------------
-#ifndef BHS_CLS_ABL
-#define BHS_CLS_ABL 0
-#endif
 #ifndef BHS_CLS_PARTS
 #define BHS_CLS_PARTS 1
 #endif
-constexpr unsigned kClassIdle = 1u << 12;     // product triple of a lane without a product
-constexpr int kClassRun = 8;
-constexpr int kClassWaves = 4;
+constexpr unsigned kClassIdleA = 1u << 12;     // product triple of a lane without a product
+constexpr int kClassRunA = 8;
+constexpr int kClassWavesA = 4;
 
-template <int MAXU, int MAXV, int SE>            // SE: 64-entry passes that stage a run's A entries (<= kClassRun)
-__global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
+template <int MAXU, int MAXV, int SE>            // SE: 64-entry passes that stage a run's A entries (<= kClassRunA)
+__global__ __launch_bounds__(64 * kClassWavesA) void k_class_numeric_atomic(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classMap, const int* __restrict__ classRel,
@@ -436,14 +517,14 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
     // per wave: acc[accStride] and sAx[stageCap] doubles; then, after all waves' doubles, sBp[stageCap] ints per wave
     acc_t* acc = reinterpret_cast<acc_t*>(smemRaw) + (size_t)wv * (accStride + stageCap);
     acc_t* sAx = acc + accStride;
-    int* sBp = reinterpret_cast<int*>(reinterpret_cast<acc_t*>(smemRaw) + (size_t)kClassWaves * (accStride + stageCap)) + wv * stageCap;
+    int* sBp = reinterpret_cast<int*>(reinterpret_cast<acc_t*>(smemRaw) + (size_t)kClassWavesA * (accStride + stageCap)) + wv * stageCap;
     for (int i = lane; i < accStride; i += 64) acc[i] = 0.0;
 
-    const int nRuns = (m + kClassRun - 1) / kClassRun;
+    const int nRuns = (m + kClassRunA - 1) / kClassRunA;
     // XCD-aware: block b runs on XCD b % 8; XCD x takes the runs [x * perX, (x + 1) * perX)
     const int xcd = blockIdx.x & 7, perX = (nRuns + 7) / 8;
-    const int wavesPerX = (gridDim.x >> 3) * kClassWaves;
-    const int wIdx = (blockIdx.x >> 3) * kClassWaves + wv;
+    const int wavesPerX = (gridDim.x >> 3) * kClassWavesA;
+    const int wIdx = (blockIdx.x >> 3) * kClassWavesA + wv;
 
     int cur = -2, P = 0, nnz = 0;
     unsigned mp[MAXU];
@@ -451,8 +532,8 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
     for (int rr = wIdx; rr < perX; rr += wavesPerX) {
         const int run = xcd * perX + rr;
         if (run >= nRuns) break;
-        const int row0 = run * kClassRun;
-        const int nr = min(kClassRun, m - row0);
+        const int row0 = run * kClassRunA;
+        const int nr = min(kClassRunA, m - row0);
         // row pointers and classes of the run: one lane per row (lane nr holds the end of the last row)
         int myAp = 0, myCp = 0, myCls = -1;
         if (lane <= nr) { myAp = Ap[row0 + lane]; myCp = Cp[row0 + lane]; }
@@ -489,7 +570,7 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
                 // lanes past the class's last product get a harmless triple: entry 0 of B, the spare slot
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u)
-                    mp[u] = u * 64 + lane < P ? classMap[(size_t)cls * kClassMaxP + u * 64 + lane] : (kClassIdle | ((unsigned)(accStride - 1) << 16));
+                    mp[u] = u * 64 + lane < P ? classMap[(size_t)cls * kClassMaxP + u * 64 + lane] : (kClassIdleA | ((unsigned)(accStride - 1) << 16));
 #pragma unroll
                 for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
@@ -509,7 +590,7 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
                         const unsigned e = mp[u0 + i];
                         const int valid = (int)((e >> 12) & 1u) - 1;     // idle lane: 0, else all ones
                         const long long idx = (long long)((bpv[i] + (int)((e >> 6) & 63u)) & valid);
-                        bv[i] = (BHS_CLS_ABL & 1) ? (acc_t)idx : (acc_t)Bx[idx];
+                        bv[i] = (acc_t)Bx[idx];
                     }
                 }
 #pragma unroll
@@ -517,8 +598,7 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
 #pragma unroll
                 for (int i = 0; i < UP; ++i) {
                     if (u0 + i < MAXU) {
-                        if (BHS_CLS_ABL & 2) { if (axv[i] * bv[i] == 12345.678) acc[0] = 1.0; }
-                        else unsafeAtomicAdd(&acc[mp[u0 + i] >> 16], axv[i] * bv[i]);
+                        unsafeAtomicAdd(&acc[mp[u0 + i] >> 16], axv[i] * bv[i]);
                     }
                 }
                 if (BHS_CLS_PARTS > 1) __builtin_amdgcn_sched_barrier(0);
@@ -530,10 +610,8 @@ __global__ __launch_bounds__(64 * kClassWaves) void k_class_numeric(
                 if (s < nnz) {
                     const acc_t val = acc[s];
                     acc[s] = 0.0;
-                    if (!(BHS_CLS_ABL & 4) || val == 12345.678) {
                     Cj[(long long)out + s] = rel[v] + row + rowBase;
                     Cx[(long long)out + s] = (value_t)val;
-                    }
                 }
             }
             wave_sync();

@@ -30,7 +30,10 @@
 #ifndef BHS_PHASES_SPA
 #define BHS_PHASES_SPA 0
 #endif
-#if BHS_PHASES || BHS_PHASES_SPA
+#ifndef BHS_PHASES_CLS
+#define BHS_PHASES_CLS 0
+#endif
+#if BHS_PHASES || BHS_PHASES_SPA || BHS_PHASES_CLS
 __device__ unsigned long long g_phase_cycles[16];
 #endif
 #if BHS_PHASES_SPA

@@ -17,13 +17,16 @@
 #include "bhs_rank.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
+#include "bhs_class_wg.hip.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -139,9 +142,10 @@ struct bhs_handle {
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 4, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classNumeric = 0;                // numeric kernel of the class path: 0 k_class_numeric_atomic (round 2), 1 k_class_numeric (bhs_class_wg.hip.h)
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
-    DevBuf classB, classC, classTab, classInfo, classMap, classRel;
+    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -204,7 +208,8 @@ struct bhs_handle {
     // per-handle (hence per-device) launch cache: resident workgroups per CU of every kernel instantiation, filled
     // by kernel_occupancy(), which also raises the dynamic-LDS limit of kernels that need more than 48 KB.  Both
     // are properties of (kernel, device): a process-wide static would hand a second device the first one's answers.
-    std::unordered_map<const void*, int> occ;
+    std::map<std::tuple<const void*, int, size_t>, int> occ;
+    std::unordered_map<const void*, size_t> occLds;   // largest dynamic-LDS size a kernel was granted so far
     // state handed from the symbolic half of a multiply (stages 1-3) to the numeric half (stage 4), which may be
     // run in row ranges (bhs_spgemm_symbolic / bhs_spgemm_numeric / bhs_spgemm_finish)
     struct PipeState {
@@ -212,7 +217,7 @@ struct bhs_handle {
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
         bool useClass = false;            // numeric half: k_class_numeric
-        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0;
+        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0;
         int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
@@ -276,14 +281,17 @@ void release(DevBuf& b)
 // 48 KB of dynamic LDS get their limit raised here, once per handle
 int kernel_occupancy(bhs_handle* h, const void* kern, int block, size_t smem, int* out)
 {
-    auto it = h->occ.find(kern);
+    const auto key = std::make_tuple(kern, block, smem);              // (a kernel's dynamic LDS can depend on the data set)
+    auto it = h->occ.find(key);
     if (it != h->occ.end()) { *out = it->second; return BHS_SUCCESS; }
-    if (smem > 48 * 1024)
+    if (smem > 48 * 1024 && smem > h->occLds[kern]) {
         BHS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        h->occLds[kern] = smem;
+    }
     int nb = 0;
     BHS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, block, smem));
     nb = std::max(1, nb);
-    h->occ.emplace(kern, nb);
+    h->occ.emplace(key, nb);
     *out = nb;
     return BHS_SUCCESS;
 }
@@ -409,27 +417,70 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     return BHS_SUCCESS;
 }
 
-// Numeric pass by row classes on the rows [r0, r1)
+// Numeric pass by row classes on the rows [r0, r1): round 2's kernel (one LDS atomic per product)
 template <int MAXU, int MAXV, int SE>
-int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
+int launch_class_numeric_atomic_impl(bhs_handle* h, int r0, int r1)
 {
-    auto kern = k_class_numeric<MAXU, MAXV, SE>;
+    auto kern = k_class_numeric_atomic<MAXU, MAXV, SE>;
     const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
     // staging area of a run: its rows' A entries (rounded up to whole 64-entry passes) and 64 entries of slack
-    const int stageCap = ((kClassRun * h->ps.classMaxNA + 63) & ~63) + 64;
-    const size_t smem = (size_t)kClassWaves * ((size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int));
+    const int stageCap = ((kClassRunA * h->ps.classMaxNA + 63) & ~63) + 64;
+    const size_t smem = (size_t)kClassWavesA * ((size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int));
     int perCU = 1;
-    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * kClassWaves, smem, &perCU));
-    perCU = std::max(1, std::min(perCU, 32 / kClassWaves));
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * kClassWavesA, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32 / kClassWavesA));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    const int mR = r1 - r0;
+    const long long nRuns = ((long long)mR + kClassRunA - 1) / kClassRunA;
+    long long grid = std::min<long long>((nRuns + kClassWavesA - 1) / kClassWavesA, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kClassWavesA), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+                       h->dBp, h->dBx, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
+                       (const unsigned*)h->classMapA.p, (const int*)h->classRel.p, (const int*)h->Cp.p + r0, out_cj(h),
+                       out_cx(h), accStride, stageCap, r0);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <int MAXU, int MAXV>
+int launch_class_numeric_atomic_uv(bhs_handle* h, int r0, int r1)
+{
+    const int passes = (kClassRunA * h->ps.classMaxNA + 63) / 64;   // 64-entry passes that stage the A entries of a run
+    if (passes <= 2) return launch_class_numeric_atomic_impl<MAXU, MAXV, 2>(h, r0, r1);
+    if (passes <= 4) return launch_class_numeric_atomic_impl<MAXU, MAXV, 4>(h, r0, r1);
+    return launch_class_numeric_atomic_impl<MAXU, MAXV, kClassRunA>(h, r0, r1);
+}
+
+int launch_class_numeric_atomic(bhs_handle* h, int r0, int r1)
+{
+    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
+    if (U <= 1 && V <= 1) return launch_class_numeric_atomic_uv<1, 1>(h, r0, r1);
+    if (U <= 2 && V <= 1) return launch_class_numeric_atomic_uv<2, 1>(h, r0, r1);
+    if (U <= 4 && V <= 2) return launch_class_numeric_atomic_uv<4, 2>(h, r0, r1);
+    if (U <= 8 && V <= 4) return launch_class_numeric_atomic_uv<8, 4>(h, r0, r1);
+    if (U <= 12 && V <= 2) return launch_class_numeric_atomic_uv<12, 2>(h, r0, r1);
+    return launch_class_numeric_atomic_uv<16, 8>(h, r0, r1);
+}
+
+
+// Numeric pass by row classes on the rows [r0, r1): the workgroup kernel (bhs_class_wg.hip.h)
+template <int MAXU, int MAXV, int LP>
+int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
+{
+    auto kern = k_class_numeric<MAXU, MAXV, LP>;
+    const size_t smem = (size_t)ClassLds<LP, 64 * MAXV>::kBytes;
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32));
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     const int mR = r1 - r0;
     const long long nRuns = ((long long)mR + kClassRun - 1) / kClassRun;
-    long long grid = std::min<long long>((nRuns + kClassWaves - 1) / kClassWaves, (long long)h->numCU * useCU);
+    long long grid = std::min<long long>(nRuns, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kClassWaves), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
-                       h->dBp, h->dBx, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
-                       (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->Cp.p + r0, out_cj(h),
-                       out_cx(h), accStride, stageCap, r0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+                       h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
+                       (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
+                       out_cx(h), r0);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -437,21 +488,23 @@ int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
 template <int MAXU, int MAXV>
 int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
 {
-    const int passes = (kClassRun * h->ps.classMaxNA + 63) / 64;   // 64-entry passes that stage the A entries of a run
-    if (passes <= 2) return launch_class_numeric_impl<MAXU, MAXV, 2>(h, r0, r1);
-    if (passes <= 4) return launch_class_numeric_impl<MAXU, MAXV, 4>(h, r0, r1);
-    return launch_class_numeric_impl<MAXU, MAXV, kClassRun>(h, r0, r1);
+    const int longest = std::max(h->ps.classMaxNA, h->ps.classMaxLB);   // slots per staged row of A / of B
+    if (longest <= 8) return launch_class_numeric_impl<MAXU, MAXV, 8>(h, r0, r1);
+    if (longest <= 16) return launch_class_numeric_impl<MAXU, MAXV, 16>(h, r0, r1);
+    if (longest <= 32) return launch_class_numeric_impl<MAXU, MAXV, 32>(h, r0, r1);
+    return launch_class_numeric_impl<MAXU, MAXV, 64>(h, r0, r1);
 }
 
 int launch_class_numeric(bhs_handle* h, int r0, int r1)
 {
-    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
+    // steps per lane, and 64-slot groups per row of C (one slot more than its entries: the strays' slot)
+    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 1 + 63) / 64;
     if (U <= 1 && V <= 1) return launch_class_numeric_uv<1, 1>(h, r0, r1);
     if (U <= 2 && V <= 1) return launch_class_numeric_uv<2, 1>(h, r0, r1);
     if (U <= 4 && V <= 2) return launch_class_numeric_uv<4, 2>(h, r0, r1);
     if (U <= 8 && V <= 4) return launch_class_numeric_uv<8, 4>(h, r0, r1);
     if (U <= 12 && V <= 2) return launch_class_numeric_uv<12, 2>(h, r0, r1);
-    return launch_class_numeric_uv<16, 8>(h, r0, r1);
+    return launch_class_numeric_uv<16, 9>(h, r0, r1);
 }
 
 // Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
@@ -1072,7 +1125,9 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->classTab, sizeof(unsigned long long) * 2 * kClassSlots));
     BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * kClassSlots));
     BHS_TRY(ensure(h, h->classMap, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
+    BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
+    BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * CS_INTS, h->stream));
     BHS_HIP(hipMemsetAsync(h->classTab.p, 0xFF, sizeof(unsigned long long) * 2 * kClassSlots, h->stream));
@@ -1122,7 +1177,7 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(timed_begin(h, "class_patterns", &ep));
     hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
                        h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
-                       (unsigned*)h->classMap.p, (int*)h->classRel.p, cstats);
+                       (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p, cstats);
     hipLaunchKernelGGL(k_class_counts, dim3(gA), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
                        (const int4*)h->classInfo.p, (int*)h->Cp.p, cstats);
     BHS_HIP(hipGetLastError());
@@ -1217,6 +1272,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxP = cs[CS_MAXP];
         h->ps.classMaxNnz = cs[CS_MAXNNZ];
         h->ps.classMaxNA = cs[CS_MAXNA];
+        h->ps.classMaxLB = cs[CS_MAXLB];
         if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; %d table probes]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[7]);
     } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
@@ -1293,7 +1349,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (h->ps.useClass) {
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
-        BHS_TRY(launch_class_numeric(h, r0, r1));
+        BHS_TRY(h->classNumeric ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += r1 - r0;
@@ -1747,7 +1803,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->spaRank);
     release(h->longList); release(h->longPart);
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
-    release(h->classMap); release(h->classRel);
+    release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -2024,6 +2080,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }
@@ -2069,7 +2126,7 @@ const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type flo
 const char* bhs_version(void) { return "bhsparse_hip 0.1 (gfx950, value_type double)"; }
 #endif
 
-#if BHS_PHASES || BHS_PHASES_SPA
+#if BHS_PHASES || BHS_PHASES_SPA || BHS_PHASES_CLS
 // measurement-only builds (tools/build_variants.sh -DBHS_PHASES=1): read and reset the phase counters
 __attribute__((visibility("default"))) int bhs_debug_phases(unsigned long long* out)
 {
