@@ -86,14 +86,14 @@ __device__ __forceinline__ unsigned group_sum_u32(unsigned v)
 }
 
 constexpr int kClassRowsBlock = 1024;      // large blocks: fewer block-local class caches to warm up
-template <bool IS_A, int G>
+template <bool IS_A, int G, int E>         // G lanes per row, E entries per lane: rows of up to G * E entries
 __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                     const int* __restrict__ classB,
                                                     unsigned long long* __restrict__ table,
                                                     int* __restrict__ classOut, int* __restrict__ stats,
                                                     const int* __restrict__ range)     // rows [range[0], range[1]] only (nullptr: all)
 {
-    constexpr int E = kClassMaxRow / G;                            // entries per lane
+    static_assert(G * E <= kClassMaxRow, "the block's class cache holds kClassMaxRow entries per pattern");
     constexpr int RPB = kClassRowsBlock / G;                       // rows per block and pass
     // Block-local cache of the table, indexed by the hash: {slot, 20 bits of the hash} and the class's pattern (the
     // relative columns, for A rows also the B classes) -- a row whose class is here is recognised without touching
@@ -112,8 +112,10 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     const int leaderLane = lane - g;                               // first lane of this lane's group
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << leaderLane;
     // R row sets per pass and lane group: their load chains (rowPtr -> colInd -> B class) are independent, so the
-    // three memory round trips of a pass are shared by R rows per group instead of paid per row
-    constexpr int R = 2;
+    // three memory round trips of a pass are shared by R rows per group instead of paid per row.  The pass is bound
+    // by those round trips (SQ_WAIT_ANY 60-80 % of the wave cycles), so short rows -- few entries per lane -- take
+    // more row sets: R * E = 16 entries per lane in flight.
+    constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);
     long long first = 0;
     if (range != nullptr) {                                        // (wave-uniform values)
         const int lo = range[0], hi = range[1];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             len[r] = live[r] ? len[r] - a0[r] : 0;
-            ok[r] = live[r] && len[r] <= kClassMaxRow;
+            ok[r] = live[r] && len[r] <= G * E;                   // (longer: no class, the multiply goes to the general pipeline)
         }
         // all loads of the rows first, without predicates (a position past the row's end re-reads its last entry), so
         // that they are in flight together; then the gather of the B classes, likewise; then the hashes

@@ -141,7 +141,7 @@ struct bhs_handle {
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
-    int classGridMul = 4, classPerLane = 4, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classGridMul = 4, classPerLane = 2, classMinProducts = 256;   // tuning hooks of k_class_rows
     int classNumeric = 0;                // numeric kernel of the class path: 0 k_class_numeric_atomic (round 2), 1 k_class_numeric (bhs_class_wg.hip.h)
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
@@ -1138,8 +1138,16 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(timed_begin(h, "classify_rows", &ep));
     const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
     // lanes per row: the average row, rounded up to a power of two
-#define BHS_CLASS_ROWS(ISA, G, grid, n, Rp, Rj, cb, tab, out, rng)                                                  \
-    hipLaunchKernelGGL((k_class_rows<ISA, G>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng)
+#define BHS_CLASS_ROWS(ISA, G, E, grid, n, Rp, Rj, cb, tab, out, rng)                                               \
+    hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng)
+    // entries per lane: the longest row (a hint from bhs_set_data; a longer row finds no class and sends the multiply
+    // to the general pipeline) over the G lanes, as a quarter, a half or all of what the block's class cache holds
+#define BHS_CLASS_ROWS_G(ISA, G, maxRow, grid, n, Rp, Rj, cb, tab, out, rng)                                          \
+    do {                                                                                                              \
+        if (kClassMaxRow / G >= 4 && (maxRow) <= kClassMaxRow / 4) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 4 ? kClassMaxRow / G / 4 : 1), grid, n, Rp, Rj, cb, tab, out, rng); \
+        else if (kClassMaxRow / G >= 2 && (maxRow) <= kClassMaxRow / 2) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 2 ? kClassMaxRow / G / 2 : 1), grid, n, Rp, Rj, cb, tab, out, rng); \
+        else BHS_CLASS_ROWS(ISA, G, kClassMaxRow / G, grid, n, Rp, Rj, cb, tab, out, rng);                            \
+    } while (0)
     auto rows_grid = [&](int n, int G) {
         return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
@@ -1155,19 +1163,20 @@ int symbolic_class(bhs_handle* h)
     }
     const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
     switch (GB) {
-        case 4: BHS_CLASS_ROWS(false, 4, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 8: BHS_CLASS_ROWS(false, 8, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 16: BHS_CLASS_ROWS(false, 16, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 32: BHS_CLASS_ROWS(false, 32, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        default: BHS_CLASS_ROWS(false, 64, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 4: BHS_CLASS_ROWS_G(false, 4, h->maxRowB, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 8: BHS_CLASS_ROWS_G(false, 8, h->maxRowB, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 16: BHS_CLASS_ROWS_G(false, 16, h->maxRowB, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 32: BHS_CLASS_ROWS_G(false, 32, h->maxRowB, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        default: BHS_CLASS_ROWS_G(false, 64, h->maxRowB, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
     }
     switch (GA) {
-        case 4: BHS_CLASS_ROWS(true, 4, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 8: BHS_CLASS_ROWS(true, 8, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 16: BHS_CLASS_ROWS(true, 16, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 32: BHS_CLASS_ROWS(true, 32, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        default: BHS_CLASS_ROWS(true, 64, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 4: BHS_CLASS_ROWS_G(true, 4, h->maxRowA, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 8: BHS_CLASS_ROWS_G(true, 8, h->maxRowA, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 16: BHS_CLASS_ROWS_G(true, 16, h->maxRowA, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 32: BHS_CLASS_ROWS_G(true, 32, h->maxRowA, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        default: BHS_CLASS_ROWS_G(true, 64, h->maxRowA, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
     }
+#undef BHS_CLASS_ROWS_G
 #undef BHS_CLASS_ROWS
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));

@@ -33,3 +33,25 @@ def hiplib():
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name))
     return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(autouse=True)
+def _extra_library_options(monkeypatch):
+    """BHS_TEST_OPTS=key=value,..: extra library options for every multiply of the parity tests (e.g.
+    class_numeric=1 runs the whole suite on the workgroup form of the class kernel)."""
+    extra = os.environ.get("BHS_TEST_OPTS", "")
+    if not extra:
+        yield
+        return
+    from benchmark_spgemm_using_csr_amd import facade
+    add = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in extra.split(",") if kv}
+    real = facade.bhsparse.initPlatform
+
+    def init(self, *a, **kw):
+        err = real(self, *a, **kw)
+        if err == 0:
+            for k_, v_ in add.items():
+                self.set_option(k_, v_)
+        return err
+    monkeypatch.setattr(facade.bhsparse, "initPlatform", init)
+    yield
