@@ -91,7 +91,10 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
                                                     const int* __restrict__ classB,
                                                     unsigned long long* __restrict__ table,
                                                     int* __restrict__ classOut, int* __restrict__ stats,
-                                                    const int* __restrict__ range)     // rows [range[0], range[1]] only (nullptr: all)
+                                                    const int* __restrict__ range,     // rows [range[0], range[1]] only (nullptr: all)
+                                                    const int* __restrict__ rowList,   // nullptr: all rows; else the rows to classify: segment
+                                                    const int* __restrict__ rowCount,  //   blockIdx.y of kClassHeadSegs lists (k_class_heads),
+                                                    int segCap)                        //   segCap slots apart, its length at rowCount[16 * segment]
 {
     static_assert(G * E <= kClassMaxRow, "the block's class cache holds kClassMaxRow entries per pattern");
     constexpr int RPB = kClassRowsBlock / G;                       // rows per block and pass
@@ -117,7 +120,10 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     // more row sets: R * E = 16 entries per lane in flight.
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);
     long long first = 0;
-    if (range != nullptr) {                                        // (wave-uniform values)
+    if (rowList != nullptr) {                                      // (positions in the segment's list from here on)
+        rowList += (size_t)blockIdx.y * segCap;
+        nrows = rowCount[16 * blockIdx.y];
+    } else if (range != nullptr) {                                 // (wave-uniform values)
         const int lo = range[0], hi = range[1];
         first = lo <= hi ? lo : 0;
         nrows = lo <= hi ? min(nrows, hi + 1) : 0;
@@ -132,6 +138,10 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
         for (int r = 0; r < R; ++r) {
             rowv[r] = row0 + (long long)r * RPB;
             live[r] = rowv[r] < nrows;
+        }
+        if (rowList != nullptr) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) rowv[r] = rowList[live[r] ? rowv[r] : 0];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {                               // (unpredicated: both row sets' loads in flight)
@@ -268,6 +278,176 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
             if (live[r] && g == 0) classOut[row] = cls;
             if (__any(live[r] && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rows that look like the row before them.  On a matrix assembled on a grid a row is, almost always, its predecessor
+// shifted by one column -- the same relative pattern (and, for rows of A, the same classes of B rows behind it).
+// Such a row needs no hash and no table: it has its predecessor's class.  k_class_heads streams the rows once (every
+// lane group takes R CONSECUTIVE rows, so a row's predecessor is in the same lanes' registers, or one group to the
+// left; a wave takes one contiguous piece of kClassHeadPiece rows), compares, lists the rows that differ ("heads":
+// poisson27pt 128^3 has one in fifty) and leaves in classOut of every other row the head it follows, as -2 - head.
+// k_class_rows then classifies the listed rows only, and k_class_propagate hands the classes on.  The comparison is
+// entry by entry, like the table's.  The heads go to kClassHeadSegs lists, a block's with one atomic (a single
+// counter bumped once per wave queues for most of a millisecond).
+// ---------------------------------------------------------------------------
+constexpr int kClassHeadSegs = 8;
+constexpr int kClassHeadsBlock = 1024;
+constexpr int kClassHeadPiece = 256;                               // rows per wave: its first is a head by decree
+template <bool IS_A, int G, int E>
+__global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
+                                                     const int* __restrict__ classB, int* __restrict__ classOut,
+                                                     int* __restrict__ headList, int* __restrict__ headCount, int segCap,
+                                                     const int* __restrict__ range)     // rows [range[0], range[1]] only (nullptr: all)
+{
+    constexpr int GPW = 64 / G;                                    // lane groups per wave
+    constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);               // consecutive rows per lane group
+    constexpr int RPW = GPW * R;                                   // consecutive rows per wave and pass
+    constexpr int WPB = kClassHeadsBlock / 64;
+    __shared__ int sList[WPB * kClassHeadPiece], sCount, sBase;    // the block's heads
+    const int lane = threadIdx.x & 63, g = lane % G, grp = lane / G;
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (lane - g);
+    long long first = 0;
+    if (range != nullptr) {                                        // (wave-uniform values)
+        const int lo = range[0], hi = range[1];
+        first = lo <= hi ? lo : 0;
+        nrows = lo <= hi ? min(nrows, hi + 1) : 0;
+    }
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const long long wave = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const long long pieceBegin = first + wave * kClassHeadPiece;
+    const long long pieceEnd = min((long long)nrows, pieceBegin + kClassHeadPiece);
+    bool okP = false;                                              // the pass before's last row (lane g of every group)
+    int lenP = 0, elP[E], cbP[E], followP = -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { elP[e] = 0; cbP[e] = 0; }
+    for (long long base = pieceBegin; base < pieceEnd; base += RPW) {
+        const bool firstPass = base == pieceBegin;
+        long long rowv[R];
+        bool live[R], ok[R];
+        int a0[R], len[R], el[R][E], cb[R][E], cc[R][E];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rowv[r] = base + (long long)grp * R + r;
+            live[r] = rowv[r] < pieceEnd;
+            const long long rr = live[r] ? rowv[r] : 0;
+            a0[r] = Rp[rr];
+            len[r] = Rp[rr + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            len[r] = live[r] ? len[r] - a0[r] : 0;
+            ok[r] = live[r] && len[r] <= G * E;
+            const int lastPos = ok[r] && len[r] > 0 ? a0[r] + len[r] - 1 : 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) cc[r][e] = Rj[min(a0[r] + e * G + g, lastPos)];
+        }
+        if (IS_A) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < E; ++e) cb[r][e] = classB[cc[r][e]];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool in = ok[r] && e * G + g < len[r];
+                el[r][e] = in ? cc[r][e] - (int)rowv[r] : 0;
+                if (!IS_A || !in) cb[r][e] = 0;
+                bad = bad || (IS_A && cb[r][e] < 0);
+            }
+            if (IS_A && (__ballot(bad) & gmask)) ok[r] = false;
+        }
+        // same as the row before?
+        bool head[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool differs;
+            if (r == 0) {                                         // (group 0: the pass before's last row)
+                const int src = max(lane - G, 0);
+                const bool okB = grp ? (bool)__shfl((int)ok[R - 1], src, 64) : okP;
+                const int lenB = grp ? __shfl(len[R - 1], src, 64) : lenP;
+                differs = (grp == 0 && firstPass) || !ok[0] || !okB || len[0] != lenB;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int elB = __shfl(el[R - 1][e], src, 64);
+                    differs = differs || el[0][e] != (grp ? elB : elP[e]);
+                    if (IS_A) {
+                        const int cbB = __shfl(cb[R - 1][e], src, 64);
+                        differs = differs || cb[0][e] != (grp ? cbB : cbP[e]);
+                    }
+                }
+            } else {
+                differs = !ok[r] || !ok[r - 1] || len[r] != len[r - 1];
+#pragma unroll
+                for (int e = 0; e < E; ++e) differs = differs || el[r][e] != el[r - 1][e] || (IS_A && cb[r][e] != cb[r - 1][e]);
+            }
+            head[r] = live[r] && (__ballot(differs) & gmask) != 0;
+        }
+        // the head every row follows: the last head at or before it in the wave's piece
+        int lastIn = -1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) lastIn = head[r] ? (int)rowv[r] : lastIn;
+        int incl = lastIn;                                         // inclusive running maximum over the groups
+#pragma unroll
+        for (int o = G; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            incl = lane >= o ? max(incl, up) : incl;
+        }
+        int follow = __shfl_up(incl, G, 64);                       // the groups before this one, or the passes before this one
+        follow = grp ? max(follow, followP) : followP;
+        // the block's list: one LDS atomic per wave and pass that met a head
+        int nBefore = 0, nHeads = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned long long hm = __ballot(head[r] && g == 0);
+            nBefore += __popcll(hm & ((1ull << lane) - 1ull));
+            nHeads += __popcll(hm);
+        }
+        int slot0 = 0;
+        if (lane == 0 && nHeads) slot0 = atomicAdd(&sCount, nHeads);
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        if (g == 0) {
+            int at = slot0 + nBefore;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (head[r]) {
+                    sList[at++] = (int)rowv[r];                   // (the list need not be sorted, only complete)
+                    follow = (int)rowv[r];
+                } else if (live[r]) classOut[rowv[r]] = -2 - follow;
+            }
+        }
+        // hand the pass's last row to the next pass's group 0 (lane g takes lane (GPW - 1) * G + g's)
+        const int from = (GPW - 1) * G + g;
+        okP = (bool)__shfl((int)ok[R - 1], from, 64);
+        lenP = __shfl(len[R - 1], from, 64);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { elP[e] = __shfl(el[R - 1][e], from, 64); if (IS_A) cbP[e] = __shfl(cb[R - 1][e], from, 64); }
+        followP = max(followP, __builtin_amdgcn_readlane(incl, 63));
+    }
+    // the block's heads go to list blockIdx.x % kClassHeadSegs: one global atomic per block
+    __syncthreads();
+    const int seg = blockIdx.x % kClassHeadSegs, cnt = sCount;
+    if (threadIdx.x == 0) sBase = cnt ? atomicAdd(&headCount[16 * seg], cnt) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += kClassHeadsBlock) headList[(size_t)seg * segCap + sBase + i] = sList[i];
+}
+
+__global__ __launch_bounds__(256) void k_class_propagate(int nrows, int* __restrict__ classOut, const int* __restrict__ range)
+{
+    long long first = 0;
+    if (range != nullptr) {
+        const int lo = range[0], hi = range[1];
+        first = lo <= hi ? lo : 0;
+        nrows = lo <= hi ? min(nrows, hi + 1) : 0;
+    }
+    for (long long i = first + (long long)blockIdx.x * 256 + threadIdx.x; i < nrows; i += (long long)gridDim.x * 256) {
+        const int v = classOut[i];
+        if (v <= -2) classOut[i] = classOut[-2 - v];               // (a head's entry is its class, or -1: never <= -2)
     }
 }
 

@@ -142,10 +142,11 @@ struct bhs_handle {
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
     int classNumeric = 0;                // numeric kernel of the class path: 0 k_class_numeric_atomic (round 2), 1 k_class_numeric (bhs_class_wg.hip.h)
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
-    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane;
+    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -1128,6 +1129,9 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
     BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
+    BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
+    BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
+    BHS_HIP(hipMemsetAsync(h->classHeadCnt.p, 0, sizeof(int) * 2 * 16 * kClassHeadSegs, h->stream));
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * CS_INTS, h->stream));
     BHS_HIP(hipMemsetAsync(h->classTab.p, 0xFF, sizeof(unsigned long long) * 2 * kClassSlots, h->stream));
@@ -1138,19 +1142,31 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(timed_begin(h, "classify_rows", &ep));
     const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
     // lanes per row: the average row, rounded up to a power of two
-#define BHS_CLASS_ROWS(ISA, G, E, grid, n, Rp, Rj, cb, tab, out, rng)                                               \
-    hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng)
+    // Three launches per matrix: k_class_heads lists the rows that differ from the row before them (and notes for
+    // every other row which head it follows), k_class_rows classifies the listed rows, k_class_propagate hands the
+    // classes on.  (class_heads = 0: k_class_rows over all rows, round 2's form.)
+#define BHS_CLASS_ROWS(ISA, G, E, grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads)                                  \
+    do {                                                                                                              \
+        if (h->classHeadsOn) {                                                                                        \
+            hipLaunchKernelGGL((k_class_heads<ISA, G, E>), dim3(heads_grid(n)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out, heads, nheads, heads_cap(n), rng); \
+            hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3((unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs)), kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, (const int*)nullptr, (const int*)heads, (const int*)nheads, heads_cap(n)); \
+            hipLaunchKernelGGL(k_class_propagate, dim3((unsigned)std::max<long long>(1, std::min<long long>(((long long)(n) + 255) / 256, (long long)h->numCU * 8))), dim3(256), 0, h->stream, n, out, rng); \
+        } else                                                                                                        \
+            hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng, (const int*)nullptr, (const int*)nullptr, 0); \
+    } while (0)
     // entries per lane: the longest row (a hint from bhs_set_data; a longer row finds no class and sends the multiply
     // to the general pipeline) over the G lanes, as a quarter, a half or all of what the block's class cache holds
-#define BHS_CLASS_ROWS_G(ISA, G, maxRow, grid, n, Rp, Rj, cb, tab, out, rng)                                          \
+#define BHS_CLASS_ROWS_G(ISA, G, maxRow, grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads)                          \
     do {                                                                                                              \
-        if (kClassMaxRow / G >= 4 && (maxRow) <= kClassMaxRow / 4) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 4 ? kClassMaxRow / G / 4 : 1), grid, n, Rp, Rj, cb, tab, out, rng); \
-        else if (kClassMaxRow / G >= 2 && (maxRow) <= kClassMaxRow / 2) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 2 ? kClassMaxRow / G / 2 : 1), grid, n, Rp, Rj, cb, tab, out, rng); \
-        else BHS_CLASS_ROWS(ISA, G, kClassMaxRow / G, grid, n, Rp, Rj, cb, tab, out, rng);                            \
+        if (kClassMaxRow / G >= 4 && (maxRow) <= kClassMaxRow / 4) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 4 ? kClassMaxRow / G / 4 : 1), grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads); \
+        else if (kClassMaxRow / G >= 2 && (maxRow) <= kClassMaxRow / 2) BHS_CLASS_ROWS(ISA, G, (kClassMaxRow / G >= 2 ? kClassMaxRow / G / 2 : 1), grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads); \
+        else BHS_CLASS_ROWS(ISA, G, kClassMaxRow / G, grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads);            \
     } while (0)
     auto rows_grid = [&](int n, int G) {
         return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
+    auto heads_grid = [&](int n) { const long long perBlock = (long long)(kClassHeadsBlock / 64) * kClassHeadPiece; return (unsigned)std::max<long long>(1, ((long long)n + perBlock - 1) / perBlock); };
+    auto heads_cap = [&](int n) { return (int)(((long long)heads_grid(n) + kClassHeadSegs - 1) / kClassHeadSegs) * (kClassHeadsBlock / 64) * kClassHeadPiece; };    // slots per list
     // A as a row block of a larger product (multi-GPU): only the rows of B that A points at need a class
     const int* bRange = nullptr;
     if ((long long)m * 2 <= (long long)k) {
@@ -1161,26 +1177,30 @@ int symbolic_class(bhs_handle* h)
         hipLaunchKernelGGL(k_class_col_range, dim3(gr), dim3(256), 0, h->stream, (long long)h->nnzA, h->dAj, rg);
         bRange = rg;
     }
+    int* headsL = (int*)h->classHeads.p;
+    int* nHeadsB = (int*)h->classHeadCnt.p;
+    int* nHeadsA = nHeadsB + 16 * kClassHeadSegs;
     const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
     switch (GB) {
-        case 4: BHS_CLASS_ROWS_G(false, 4, h->maxRowB, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 8: BHS_CLASS_ROWS_G(false, 8, h->maxRowB, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 16: BHS_CLASS_ROWS_G(false, 16, h->maxRowB, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        case 32: BHS_CLASS_ROWS_G(false, 32, h->maxRowB, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
-        default: BHS_CLASS_ROWS_G(false, 64, h->maxRowB, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange); break;
+        case 4: BHS_CLASS_ROWS_G(false, 4, h->maxRowB, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
+        case 8: BHS_CLASS_ROWS_G(false, 8, h->maxRowB, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
+        case 16: BHS_CLASS_ROWS_G(false, 16, h->maxRowB, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
+        case 32: BHS_CLASS_ROWS_G(false, 32, h->maxRowB, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
+        default: BHS_CLASS_ROWS_G(false, 64, h->maxRowB, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
     }
     switch (GA) {
-        case 4: BHS_CLASS_ROWS_G(true, 4, h->maxRowA, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 8: BHS_CLASS_ROWS_G(true, 8, h->maxRowA, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 16: BHS_CLASS_ROWS_G(true, 16, h->maxRowA, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        case 32: BHS_CLASS_ROWS_G(true, 32, h->maxRowA, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
-        default: BHS_CLASS_ROWS_G(true, 64, h->maxRowA, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr); break;
+        case 4: BHS_CLASS_ROWS_G(true, 4, h->maxRowA, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
+        case 8: BHS_CLASS_ROWS_G(true, 8, h->maxRowA, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
+        case 16: BHS_CLASS_ROWS_G(true, 16, h->maxRowA, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
+        case 32: BHS_CLASS_ROWS_G(true, 32, h->maxRowA, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
+        default: BHS_CLASS_ROWS_G(true, 64, h->maxRowA, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
     }
+#undef BHS_CLASS_ROWS
 #undef BHS_CLASS_ROWS_G
 #undef BHS_CLASS_ROWS
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
-    h->stats[ep->stat].launches += 2;
+    h->stats[ep->stat].launches += h->classHeadsOn ? 6 : 2;
     h->stats[ep->stat].rows += (int64_t)m + k;
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
     BHS_TRY(timed_begin(h, "class_patterns", &ep));
@@ -1812,7 +1832,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->spaRank);
     release(h->longList); release(h->longPart);
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
-    release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
+    release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -2089,6 +2109,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_heads")) { h->classHeadsOn = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
