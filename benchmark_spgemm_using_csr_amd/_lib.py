@@ -22,6 +22,7 @@ BHS_ERR_LAUNCH = -4
 BHS_ERR_NNZ_OVERFLOW = -5
 BHS_ERR_NOT_READY = -6
 BHS_ERR_INTERNAL = -7
+BHS_ERR_PEER = -8
 
 
 class KernelStat(C.Structure):

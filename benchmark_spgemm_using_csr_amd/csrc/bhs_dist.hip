@@ -24,6 +24,8 @@ struct bhs_dist {
     hipEvent_t evRange = nullptr, evDone = nullptr;
     long long* dSizes = nullptr;        // device: world x kSizeSlots int64 (sizes exchange)
     long long* hSizes = nullptr;        // pinned mirror
+    long long* dStatus = nullptr;       // device: 2 x int64 (agreements)
+    bool dead = false;                  // the communicator was aborted after a failed send / receive group
     double linkFloorMs = 0.0;
     // assembled C owned by this object (the host-pointer entry points): grow-only
     int *ownRp = nullptr, *ownCj = nullptr;
@@ -35,7 +37,7 @@ struct bhs_dist {
 namespace {
 
 constexpr int kMaxSub = 16;
-constexpr int kSizeSlots = kMaxSub + 3;   // m_local, nnzCt, cut[0..S]
+constexpr int kSizeSlots = kMaxSub + 4;   // m_local (or an error code < 0), nnzCt, capacity (-1: own), cut[0..S]
 
 #define DIST_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); return (int)BHS_ERR_LAUNCH; } } while (0)
 #define DIST_NCCL(call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { fprintf(stderr, "[bhsparse_dist] %s: %s\n", #call, ncclGetErrorString(r__)); return (int)BHS_ERR_LAUNCH; } } while (0)
@@ -68,9 +70,9 @@ static int build_plan(int W, int me, int S, const long long* sizes /* W x kSizeS
     std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0);
     for (int r = 0; r < W; ++r) {
         rowOff[r + 1] = rowOff[r] + sizes[(size_t)r * kSizeSlots];
-        nnzOff[r + 1] = nnzOff[r] + sizes[(size_t)r * kSizeSlots + 2 + S];
+        nnzOff[r + 1] = nnzOff[r] + sizes[(size_t)r * kSizeSlots + 3 + S];
     }
-    auto cut_nnz = [&](int r, int s) { return sizes[(size_t)r * kSizeSlots + 2 + s]; };
+    auto cut_nnz = [&](int r, int s) { return sizes[(size_t)r * kSizeSlots + 3 + s]; };
     int n = 0;
     auto put = [&](long long kind, long long peer, long long array, long long off, long long cnt, long long grp) {
         if (n < cap) out[n] = PlanOp{kind, peer, array, off, cnt, grp};
@@ -136,6 +138,7 @@ int bhs_dist_create(bhs_dist** out, bhs_handle* h, int world, int rank, const ch
         hipEventCreateWithFlags(&d->evRange, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&d->dSizes, sizeof(long long) * kSizeSlots * (size_t)world) != hipSuccess ||
+        hipMalloc((void**)&d->dStatus, sizeof(long long) * 2) != hipSuccess ||
         hipHostMalloc((void**)&d->hSizes, sizeof(long long) * kSizeSlots * (size_t)world, hipHostMallocDefault) != hipSuccess) {
         bhs_dist_destroy(d);
         return BHS_ERR_ALLOC;
@@ -148,11 +151,12 @@ int bhs_dist_destroy(bhs_dist* d)
 {
     if (!d) return BHS_ERR_INVALID_ARG;
     if (d->cstream) (void)hipStreamSynchronize(d->cstream);
-    if (d->comm) (void)ncclCommDestroy(d->comm);
+    if (d->comm && !d->dead) (void)ncclCommDestroy(d->comm);
     if (d->cstream) (void)hipStreamDestroy(d->cstream);
     if (d->evRange) (void)hipEventDestroy(d->evRange);
     if (d->evDone) (void)hipEventDestroy(d->evDone);
     if (d->dSizes) (void)hipFree(d->dSizes);
+    if (d->dStatus) (void)hipFree(d->dStatus);
     if (d->hSizes) (void)hipHostFree(d->hSizes);
     if (d->ownRp) (void)hipFree(d->ownRp);
     if (d->ownCj) (void)hipFree(d->ownCj);
@@ -186,59 +190,120 @@ int bhs_dist_partition_rows(int m, const int* rowPtrA, const int* colIndA, const
     return BHS_SUCCESS;
 }
 
+// Error handling across ranks.  A rank that fails alone must not leave its peers waiting in a collective, so the call
+// is built from three agreements that EVERY rank reaches whatever happened to it locally:
+//   (1) the sizes all-gather carries a status word (slot 0 < 0: this rank's symbolic half failed) and each rank's
+//       capacity, so that everyone derives the same verdict on sizes, row totals and capacities from the same numbers;
+//   (2) a one-word all-reduce (max) after the output arrays are in place (own-mode allocation, binding);
+//   (3) the same after the numeric half -- a rank whose numeric kernels failed still posts every send / receive
+//       group (its peers get garbage they will not use) and everyone leaves with the error.
+// Inside a send / receive group nothing returns: the first RCCL error is remembered, the group is closed, and the
+// communicator is aborted (it cannot be trusted after a half-posted group; the object then refuses further calls).
+// Every exit finishes the open multiply and unbinds the caller's output arrays from the handle.
 int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_blocks, int* d_rowPtrC, int* d_colIndC,
                                bhs_value_t* d_valC, int64_t capacity, int64_t* nnzCt_total_out,
                                int64_t* nnzC_total_out, double ms_out[3])
 {
     if (!d || m_local < 0 || m_total < m_local || capacity < 0) return BHS_ERR_INVALID_ARG;
+    if (d->dead) return BHS_ERR_LAUNCH;
     const bool own = d_rowPtrC == nullptr;            // host-pointer callers: the assembled C lives in this object
-    if (own) {
-        if ((long long)m_total + 1 > d->ownRows) {
-            if (d->ownRp) (void)hipFree(d->ownRp);
-            d->ownRp = nullptr; d->ownRows = 0;
-            if (hipMalloc((void**)&d->ownRp, sizeof(int) * ((size_t)m_total + 1)) != hipSuccess) return BHS_ERR_ALLOC;
-            d->ownRows = (long long)m_total + 1;
-        }
-        d_rowPtrC = d->ownRp;
-    }
     const int S = std::max(1, std::min(sub_blocks, kMaxSub));
     const int W = d->world, me = d->rank;
     DIST_HIP(hipSetDevice(d->device));
     const double t0 = now_ms();
-    // the previous call's transfers read the arrays this multiply is about to overwrite
-    DIST_HIP(hipStreamWaitEvent(d->hstream, d->evDone, 0));
+    bool open = false;                                // a multiply is open on the handle (between its halves)
+    auto leave = [&](int rc) {                        // every exit: no open multiply, no borrowed output arrays left behind
+        if (open) (void)bhs_spgemm_finish(d->h, nullptr);
+        (void)bhs_set_output_device(d->h, nullptr, nullptr, 0);
+        return rc;
+    };
+    auto fatal = [&](const char* what, ncclResult_t r) {          // the communicator is unusable from here on
+        fprintf(stderr, "[bhsparse_dist] rank %d: %s: %s -- communicator aborted\n", me, what, ncclGetErrorString(r));
+        (void)ncclCommAbort(d->comm);
+        d->comm = nullptr;
+        d->dead = true;
+        return leave((int)BHS_ERR_LAUNCH);
+    };
+    auto agree = [&](int mine, int* all) -> ncclResult_t {        // max of one status word over the ranks (0 = fine everywhere)
+        *all = mine;
+        if (W == 1) return ncclSuccess;
+        d->hSizes[0] = mine;
+        if (hipMemcpyAsync(d->dStatus, d->hSizes, sizeof(long long), hipMemcpyHostToDevice, d->hstream) != hipSuccess) return ncclUnhandledCudaError;
+        const ncclResult_t r = ncclAllReduce(d->dStatus, d->dStatus + 1, 1, ncclInt64, ncclMax, d->comm, d->hstream);
+        if (r != ncclSuccess) return r;
+        if (hipMemcpyAsync(d->hSizes, d->dStatus + 1, sizeof(long long), hipMemcpyDeviceToHost, d->hstream) != hipSuccess ||
+            hipStreamSynchronize(d->hstream) != hipSuccess) return ncclUnhandledCudaError;
+        *all = (int)d->hSizes[0];
+        return ncclSuccess;
+    };
 
-    // ---- symbolic half: nnz(C) of the block and its rowPtrC are final afterwards
-    DIST_TRY(bhs_set_output_device(d->h, nullptr, nullptr, 0));
+    // ---- local work before the first agreement; errors are carried, not returned
+    int err = BHS_SUCCESS;
+    if (hipStreamWaitEvent(d->hstream, d->evDone, 0) != hipSuccess) err = BHS_ERR_LAUNCH;   // the previous call's transfers read what this multiply overwrites
+    if (!err && own && (long long)m_total + 1 > d->ownRows) {
+        if (d->ownRp) (void)hipFree(d->ownRp);
+        d->ownRp = nullptr; d->ownRows = 0;
+        if (hipMalloc((void**)&d->ownRp, sizeof(int) * ((size_t)m_total + 1)) != hipSuccess) { (void)hipGetLastError(); err = BHS_ERR_ALLOC; }
+        else d->ownRows = (long long)m_total + 1;
+    }
+    if (own) d_rowPtrC = d->ownRp;
+    // symbolic half: nnz(C) of the block and its rowPtrC are final afterwards (the library allocates no colIndC / valC
+    // of its own for it: the numeric half writes into the assembled arrays)
     int64_t nnzCt = 0;
     int nnzC = 0;
-    DIST_TRY(bhs_spgemm_symbolic(d->h, &nnzCt, &nnzC));
     const int* lp = nullptr;
-    DIST_TRY(bhs_get_C_device(d->h, &lp, nullptr, nullptr));
+    if (!err) err = bhs_set_output_device(d->h, nullptr, nullptr, 0);
+    if (!err) {
+        err = bhs_spgemm_symbolic(d->h, &nnzCt, &nnzC);
+        open = err == BHS_SUCCESS;
+    }
+    if (!err) err = bhs_get_C_device(d->h, &lp, nullptr, nullptr);
 
-    // ---- sizes of every rank: rows, products, rowPtrC at the sub-block boundaries (one small all-gather)
+    // ---- (1) sizes of every rank: status | rows, products, capacity, rowPtrC at the sub-block boundaries
     long long* mine = d->dSizes + (size_t)me * kSizeSlots;
     {
-        long long head[2] = {m_local, nnzCt};
+        // (error codes are negative: slot 0 < 0 tells the others that this rank's symbolic half failed, and how)
+        long long head[3] = {err ? (long long)(err < 0 ? err : -1) : (long long)m_local, (long long)nnzCt, own ? -1 : (long long)capacity};
         memcpy(d->hSizes, head, sizeof(head));
-        DIST_HIP(hipMemcpyAsync(mine, d->hSizes, sizeof(head), hipMemcpyHostToDevice, d->hstream));
-        hipLaunchKernelGGL(k_gather_cuts, dim3(1), dim3(64), 0, d->hstream, S, m_local, lp, mine + 2);
-        DIST_HIP(hipGetLastError());
+        bool okc = hipMemcpyAsync(mine, d->hSizes, sizeof(head), hipMemcpyHostToDevice, d->hstream) == hipSuccess;
+        if (okc && !err) {
+            hipLaunchKernelGGL(k_gather_cuts, dim3(1), dim3(64), 0, d->hstream, S, m_local, lp, mine + 3);
+            okc = hipGetLastError() == hipSuccess;
+        }
+        if (!okc && W == 1) return leave(BHS_ERR_LAUNCH);
+        if (!okc) return fatal("staging the sizes", ncclUnhandledCudaError);   // (cannot even tell the others)
     }
-    if (W > 1) DIST_NCCL(ncclAllGather(mine, d->dSizes, kSizeSlots, ncclInt64, d->comm, d->hstream));
-    DIST_HIP(hipMemcpyAsync(d->hSizes, d->dSizes, sizeof(long long) * kSizeSlots * (size_t)W, hipMemcpyDeviceToHost, d->hstream));
-    DIST_HIP(hipStreamSynchronize(d->hstream));
-    std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0);
+    if (W > 1) {
+        const ncclResult_t r = ncclAllGather(mine, d->dSizes, kSizeSlots, ncclInt64, d->comm, d->hstream);
+        if (r != ncclSuccess) return fatal("ncclAllGather(sizes)", r);
+    }
+    if (hipMemcpyAsync(d->hSizes, d->dSizes, sizeof(long long) * kSizeSlots * (size_t)W, hipMemcpyDeviceToHost, d->hstream) != hipSuccess ||
+        hipStreamSynchronize(d->hstream) != hipSuccess) {
+        if (W == 1) return leave(BHS_ERR_LAUNCH);
+        return fatal("reading the sizes", ncclUnhandledCudaError);
+    }
+    // the same verdict on every rank, from the same numbers
+    std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0), caps(W, 0);
+    std::vector<long long> sizes(d->hSizes, d->hSizes + (size_t)kSizeSlots * W);    // (hSizes is reused by agree())
     long long ctTotal = 0;
+    int verdict = BHS_SUCCESS;
     for (int r = 0; r < W; ++r) {
-        const long long* sz = d->hSizes + (size_t)r * kSizeSlots;
+        const long long* sz = sizes.data() + (size_t)r * kSizeSlots;
+        if (sz[0] < 0) { verdict = verdict ? verdict : (int)sz[0]; continue; }
         rowOff[r + 1] = rowOff[r] + sz[0];
-        nnzOff[r + 1] = nnzOff[r] + sz[2 + S];          // cut[S] = nnz(C) of the block
+        nnzOff[r + 1] = nnzOff[r] + sz[3 + S];          // cut[S] = nnz(C) of the block
         ctTotal += sz[1];
+        caps[r] = sz[2];
     }
-    if (rowOff[W] != m_total) return BHS_ERR_INVALID_ARG;
     const long long total = nnzOff[W];
-    if (total > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
+    if (!verdict && rowOff[W] != m_total) verdict = BHS_ERR_INVALID_ARG;
+    if (!verdict && total > 0x7fffffffLL) verdict = BHS_ERR_NNZ_OVERFLOW;
+    for (int r = 0; r < W && !verdict; ++r)
+        if (caps[r] >= 0 && total > caps[r]) verdict = BHS_ERR_ALLOC;          // some rank's arrays are too small
+    if (verdict) return leave(err ? err : verdict);
+
+    // ---- output arrays in place, then (2): everyone is ready, or nobody transfers
+    int ready = BHS_SUCCESS;
     if (own) {
         if (total > d->ownCap) {
             if (d->ownCj) (void)hipFree(d->ownCj);
@@ -246,8 +311,8 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
             d->ownCj = nullptr; d->ownCx = nullptr; d->ownCap = 0;
             const size_t cap = (size_t)std::max<long long>(total, 1);
             if (hipMalloc((void**)&d->ownCj, sizeof(int) * cap) != hipSuccess ||
-                hipMalloc((void**)&d->ownCx, sizeof(bhs_value_t) * cap) != hipSuccess) return BHS_ERR_ALLOC;
-            d->ownCap = (long long)cap;
+                hipMalloc((void**)&d->ownCx, sizeof(bhs_value_t) * cap) != hipSuccess) { (void)hipGetLastError(); ready = BHS_ERR_ALLOC; }
+            else d->ownCap = (long long)cap;
         }
         d_colIndC = d->ownCj;
         d_valC = d->ownCx;
@@ -255,41 +320,55 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
     }
     d->lastTotal = total;
     d->lastRows = m_total;
-    if (total > capacity || (total > 0 && (!d_colIndC || !d_valC))) return BHS_ERR_ALLOC;
+    if (!ready && total > 0 && (!d_colIndC || !d_valC)) ready = BHS_ERR_INVALID_ARG;
     // per-link floor: the largest block this rank receives over one link
     long long worst = 0;
     for (int r = 0; r < W; ++r)
         if (r != me) worst = std::max(worst, (nnzOff[r + 1] - nnzOff[r]) * (long long)(sizeof(int) + sizeof(bhs_value_t)) +
                                                  (rowOff[r + 1] - rowOff[r]) * (long long)sizeof(int));
     d->linkFloorMs = (double)worst / 153.0e9 * 1e3;
-    const double t1 = now_ms();
-
-    // ---- this rank's block is produced in place: the numeric kernels write into the assembled arrays
-    DIST_TRY(bhs_set_output_device(d->h, d_colIndC ? d_colIndC + nnzOff[me] : nullptr,
-                                   d_valC ? d_valC + nnzOff[me] : nullptr, nnzOff[me + 1] - nnzOff[me]));
-    if (m_local > 0) {
+    // this rank's block is produced in place: the numeric kernels write into the assembled arrays
+    if (!ready) ready = bhs_set_output_device(d->h, d_colIndC ? d_colIndC + nnzOff[me] : nullptr,
+                                              d_valC ? d_valC + nnzOff[me] : nullptr, nnzOff[me + 1] - nnzOff[me]);
+    if (!ready && m_local > 0) {
         const int grid = (int)std::min<long long>(((long long)m_local + 255) / 256, 1024);
         hipLaunchKernelGGL(k_rebase_rowptr, dim3(grid), dim3(256), 0, d->hstream, m_local, lp, nnzOff[me],
                            d_rowPtrC + rowOff[me]);
-        DIST_HIP(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) ready = BHS_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, d->hstream, d_rowPtrC + m_total, (int)total);
-    DIST_HIP(hipGetLastError());
+    if (!ready) {
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, d->hstream, d_rowPtrC + m_total, (int)total);
+        if (hipGetLastError() != hipSuccess) ready = BHS_ERR_LAUNCH;
+    }
+    {
+        int all = 0;
+        const ncclResult_t r = agree(ready ? 1 : 0, &all);
+        if (r != ncclSuccess) return fatal("agreement before the transfers", r);
+        if (all) return leave(ready ? ready : BHS_ERR_PEER);
+    }
+    const double t1 = now_ms();
+
     // ---- numeric half in row ranges; the transfers of range s ride the second stream while range s + 1 computes
     auto cut_row = [&](int r, int s) { return (int)((long long)(rowOff[r + 1] - rowOff[r]) * s / S); };
     std::vector<PlanOp> plan;
     if (W > 1) {
         plan.resize((size_t)S * (W - 1) * 6);
-        const int np = build_plan(W, me, S, d->hSizes, plan.data(), (int)plan.size());
+        const int np = build_plan(W, me, S, sizes.data(), plan.data(), (int)plan.size());
         plan.resize((size_t)np);
     }
     size_t next = 0;
+    int numErr = BHS_SUCCESS;
     for (int s = 0; s < S; ++s) {
-        DIST_TRY(bhs_spgemm_numeric(d->h, cut_row(me, s), cut_row(me, s + 1)));
+        if (!numErr) {
+            numErr = bhs_spgemm_numeric(d->h, cut_row(me, s), cut_row(me, s + 1));
+            if (numErr) open = false;                              // (the library closed the multiply)
+        }
         if (W == 1) continue;
-        DIST_HIP(hipEventRecord(d->evRange, d->hstream));
-        DIST_HIP(hipStreamWaitEvent(d->cstream, d->evRange, 0));
-        DIST_NCCL(ncclGroupStart());
+        // (after a local failure the groups are still posted, so that no peer waits for this rank)
+        if (hipEventRecord(d->evRange, d->hstream) != hipSuccess || hipStreamWaitEvent(d->cstream, d->evRange, 0) != hipSuccess)
+            numErr = numErr ? numErr : BHS_ERR_LAUNCH;
+        ncclResult_t first = ncclGroupStart();
+        if (first != ncclSuccess) return fatal("ncclGroupStart", first);
         for (; next < plan.size() && plan[next].group == s; ++next) {
             const PlanOp& op = plan[next];
             void* ptr;
@@ -298,20 +377,43 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
             if (op.array == 0) { ptr = d_colIndC + op.offset; count = (size_t)op.count; }
             else if (op.array == 1) { ptr = d_valC + op.offset; count = (size_t)op.count * sizeof(bhs_value_t); type = ncclInt8; }
             else { ptr = d_rowPtrC + op.offset; count = (size_t)op.count; }
-            if (op.kind == 0) DIST_NCCL(ncclSend(ptr, count, type, (int)op.peer, d->comm, d->cstream));
-            else DIST_NCCL(ncclRecv(ptr, count, type, (int)op.peer, d->comm, d->cstream));
+            const ncclResult_t r = op.kind == 0 ? ncclSend(ptr, count, type, (int)op.peer, d->comm, d->cstream)
+                                                : ncclRecv(ptr, count, type, (int)op.peer, d->comm, d->cstream);
+            if (r != ncclSuccess && first == ncclSuccess) first = r;   // remembered; the group is closed before anything else
         }
-        DIST_NCCL(ncclGroupEnd());
+        const ncclResult_t end = ncclGroupEnd();
+        if (first != ncclSuccess) return fatal("ncclSend / ncclRecv", first);
+        if (end != ncclSuccess) return fatal("ncclGroupEnd", end);
     }
-    const int rcFin = bhs_spgemm_finish(d->h, nullptr);
-    if (rcFin != BHS_SUCCESS) { (void)hipStreamSynchronize(d->cstream); return rcFin; }
+    if (open) {
+        const int rcFin = bhs_spgemm_finish(d->h, nullptr);
+        open = false;
+        if (rcFin != BHS_SUCCESS && !numErr) numErr = rcFin;
+    }
     const double t2 = now_ms();
-    DIST_HIP(hipEventRecord(d->evDone, d->cstream));
-    DIST_HIP(hipStreamSynchronize(d->cstream));
+    if (hipEventRecord(d->evDone, d->cstream) != hipSuccess || hipStreamSynchronize(d->cstream) != hipSuccess)
+        numErr = numErr ? numErr : BHS_ERR_LAUNCH;
+    // ---- (3) everyone's numeric half went through, or everyone knows it did not
+    {
+        int all = 0;
+        const ncclResult_t r = agree(numErr ? 1 : 0, &all);
+        if (r != ncclSuccess) return fatal("agreement after the transfers", r);
+        if (all) return leave(numErr ? numErr : BHS_ERR_PEER);
+    }
     const double t3 = now_ms();
     if (nnzCt_total_out) *nnzCt_total_out = ctTotal;
     if (nnzC_total_out) *nnzC_total_out = total;
     if (ms_out) { ms_out[0] = t1 - t0; ms_out[1] = t2 - t1; ms_out[2] = t3 - t2; }
+    return leave(BHS_SUCCESS);
+}
+
+int bhs_dist_nranks(bhs_dist* d, int* nranks_out)
+{
+    if (!d || !nranks_out) return BHS_ERR_INVALID_ARG;
+    if (d->dead || !d->comm) return BHS_ERR_LAUNCH;
+    int n = 0;
+    DIST_NCCL(ncclCommCount(d->comm, &n));
+    *nranks_out = n;
     return BHS_SUCCESS;
 }
 
@@ -323,7 +425,7 @@ int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t* rows, cons
     std::vector<long long> sizes((size_t)world * kSizeSlots, 0);
     for (int r = 0; r < world; ++r) {
         sizes[(size_t)r * kSizeSlots] = rows[r];
-        for (int s = 0; s <= sub_blocks; ++s) sizes[(size_t)r * kSizeSlots + 2 + s] = cuts[(size_t)r * (sub_blocks + 1) + s];
+        for (int s = 0; s <= sub_blocks; ++s) sizes[(size_t)r * kSizeSlots + 3 + s] = cuts[(size_t)r * (sub_blocks + 1) + s];
     }
     std::vector<PlanOp> plan((size_t)std::max(cap_ops, 0));
     const int n = build_plan(world, rank, sub_blocks, sizes.data(), plan.data(), (int)plan.size());

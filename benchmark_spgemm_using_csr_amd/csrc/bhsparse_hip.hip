@@ -194,6 +194,7 @@ struct bhs_handle {
     DevBuf cExt, cLen, cPair, symKey;    // per B row: pair extents, (entries, pairs); pairs; per A row: symbolic bin key
     hipEvent_t evScanDone = nullptr, evCopyDone = nullptr;
     bool wantHostRowPtr = false, rowPtrStaged = false;
+    bool lazyOut = false;                // bhs_spgemm_symbolic: the library's own colIndC / valC are allocated by the first numeric range that needs them
     // options
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
@@ -1336,7 +1337,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     if (useRank && (long long)h->ps.rankOvf * 50 > (long long)m) h->rankState = -1;
     if (h->extCj) {
         if (nnzC > h->extCap) return BHS_ERR_ALLOC;
-    } else {
+    } else if (!h->lazyOut) {
         BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
         BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     }
@@ -1522,7 +1523,7 @@ int pipeline_finish(bhs_handle* h)
 {
     if (!h->ps.open) return BHS_ERR_NOT_READY;
     h->ps.open = false;
-    if (h->ps.empty) return BHS_SUCCESS;
+    if (h->ps.empty) { for (int i = 0; i < 4; ++i) h->stageMs[i] = 0.0; return BHS_SUCCESS; }
     int* small = (int*)h->small.p;
     int* hs = h->hostSmall;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
@@ -1962,7 +1963,9 @@ int bhs_spgemm_symbolic(bhs_handle* h, int64_t* nnzCt_out, int* nnzC_out)
     if (h->useSpa && (h->spaDirty || h->spaCols != h->n)) BHS_TRY(ensure_spa(h));
     const long long savedCap = h->extCap;
     h->extCap = h->extCj ? (1LL << 62) : 0;          // the output arrays are (re)bound between the halves: no capacity check yet
+    h->lazyOut = true;                               // ... and a caller that binds its own never makes the library allocate C
     int rc = pipeline_symbolic(h);
+    h->lazyOut = false;
     h->extCap = savedCap;
     if (rc) { quiesce(h); h->ps.open = false; h->spaDirty = true; return rc; }
     if (nnzCt_out) *nnzCt_out = h->nnzCt;
@@ -1977,6 +1980,10 @@ int bhs_spgemm_numeric(bhs_handle* h, int row_begin, int row_end)
     if (row_begin < 0 || row_end > h->m || row_begin > row_end) return BHS_ERR_INVALID_ARG;   // (the multiply stays open)
     BHS_HIP(hipSetDevice(h->device));
     if (h->extCj && h->nnzC > h->extCap) return BHS_ERR_ALLOC;
+    if (!h->extCj && !h->ps.empty) {                               // the library's own output arrays (no-ops once they are large enough)
+        BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(h->nnzC, 1)));
+        BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(h->nnzC, 1)));
+    }
     const int rc = numeric_stage(h, row_begin, row_end);
     if (rc) { quiesce(h); h->ps.open = false; h->spaDirty = true; }
     return rc;
@@ -2034,7 +2041,7 @@ int bhs_get_C(bhs_handle* h, int* csrColIndC, bhs_value_t* csrValC)
 int bhs_get_rowptrC(bhs_handle* h, int* csrRowPtrC)
 {
     if (!h || !csrRowPtrC) return BHS_ERR_INVALID_ARG;
-    if (!h->hasC) return BHS_ERR_NOT_READY;
+    if (!h->hasC && !h->ps.open) return BHS_ERR_NOT_READY;         // (between the halves rowPtrC is already final)
     BHS_HIP(hipSetDevice(h->device));
     BHS_HIP(hipMemcpyAsync(csrRowPtrC, h->Cp.p, sizeof(int) * ((size_t)h->m + 1), hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
@@ -2146,6 +2153,7 @@ const char* bhs_strerror(int status)
         case BHS_ERR_NNZ_OVERFLOW: return "nnz(C) exceeds int32 index_type";
         case BHS_ERR_NOT_READY: return "call order violated (no data / no result yet)";
         case BHS_ERR_INTERNAL: return "accumulator overflow not resolved";
+        case BHS_ERR_PEER: return "another rank of the multi-GPU job failed";
         default: return "unknown bhsparse_hip status";
     }
 }

@@ -73,6 +73,8 @@ class NativeDist(object):
         L.bhs_dist_destroy.argtypes = [vp]
         L.bhs_dist_spgemm_allgatherv.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, i64, C.POINTER(i64),
                                                  C.POINTER(i64), C.POINTER(C.c_double)]
+        L.bhs_dist_nranks.argtypes = [vp, C.POINTER(C.c_int)]
+        L.bhs_dist_nranks.restype = C.c_int
         L.bhs_dist_last_link_floor_ms.argtypes = [vp]
         L.bhs_dist_last_link_floor_ms.restype = C.c_double
         idbuf = C.create_string_buffer(128)
@@ -106,6 +108,12 @@ class NativeDist(object):
             raise RuntimeError("bhs_dist_spgemm_allgatherv: %d (%s)" % (err, _lib.strerror(err)))
         self.ms = tuple(ms)
         return int(ct.value), int(cc.value)
+
+    def nranks(self):
+        """Ranks RCCL counts in the communicator (ncclCommCount)."""
+        n = self._C.c_int(0)
+        err = self._L.bhs_dist_nranks(self._d, self._C.byref(n))
+        return int(n.value) if err == 0 else -1
 
     def link_floor_ms(self):
         return float(self._L.bhs_dist_last_link_floor_ms(self._d))

@@ -53,8 +53,14 @@ BHS_API int bhs_dist_partition_rows(int m, const int *rowPtrA, const int *colInd
  *   ms_out                 [0] symbolic half + size exchange, [1] numeric half with the overlapped transfers,
  *                          [2] wait for the remaining transfers (host wall clock, ms); may be NULL
  * Returns after the assembled C is complete on this rank.  BHS_ERR_NNZ_OVERFLOW when nnz(C) of the job does not fit
- * the int32 index_type, BHS_ERR_ALLOC when it exceeds `capacity` -- pass the SAME capacity on every rank: both
- * conditions are then decided identically everywhere, before any transfer is posted.                                               */
+ * the int32 index_type, BHS_ERR_ALLOC when it exceeds some rank's `capacity`.
+ * Failures are collective: every rank reaches three agreements whatever happened to it locally -- the sizes all-gather
+ * (it carries each rank's status and capacity, so sizes, totals and capacities are judged identically everywhere
+ * before any transfer is posted), a one-word all-reduce once the output arrays are in place, and one after the numeric
+ * half (a rank whose kernels failed still posts its sends and receives).  A rank that failed returns its own error,
+ * the others BHS_ERR_PEER; nobody is left waiting.  Only an RCCL error inside a send / receive group is fatal: the
+ * group is closed, the communicator aborted, and this object refuses further calls (BHS_ERR_LAUNCH).  On every
+ * return the handle has no open multiply and no output arrays bound (a later bhs_spgemm on it uses its own).        */
 BHS_API int bhs_dist_spgemm_allgatherv(bhs_dist *d, int m_local, int m_total, int sub_blocks, int *d_rowPtrC,
                                        int *d_colIndC, bhs_value_t *d_valC, int64_t capacity,
                                        int64_t *nnzCt_total_out, int64_t *nnzC_total_out, double ms_out[3]);
@@ -78,6 +84,10 @@ BHS_API int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t *ro
 /* per-link lower bound of the all-gatherv in ms: bytes this rank receives from its largest peer / 153 GB/s (one xGMI
  * link; /opt/skills/guides/MI355X_MICROARCH.md), for the sizes of the last bhs_dist_spgemm_allgatherv               */
 BHS_API double bhs_dist_last_link_floor_ms(bhs_dist *d);
+
+/* Number of ranks RCCL itself counts in the communicator (ncclCommCount): the bench line reports it so that a scaling
+ * record shows that the collective really spanned N processes.  BHS_ERR_LAUNCH once the communicator was aborted. */
+BHS_API int bhs_dist_nranks(bhs_dist *d, int *nranks_out);
 
 #ifdef __cplusplus
 }

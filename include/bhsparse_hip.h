@@ -51,7 +51,8 @@ enum bhs_status {
                                       bhsparse_cuda.h:251-253)                   */
     BHS_ERR_NNZ_OVERFLOW   = -5,   /* nnz(C) does not fit index_type (int32)     */
     BHS_ERR_NOT_READY      = -6,   /* get_C before spgemm, spgemm before set_data */
-    BHS_ERR_INTERNAL       = -7    /* accumulator overflow that the retry logic could not resolve */
+    BHS_ERR_INTERNAL       = -7,   /* accumulator overflow that the retry logic could not resolve */
+    BHS_ERR_PEER           = -8    /* multi-GPU calls: another rank of the job failed (bhsparse_dist.h) */
 };
 
 /* ---- lifecycle -----------------------------------------------------------

@@ -893,7 +893,7 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
     far longer than the longest row seen then: the kernels must refute the speculation and the multiply must
     still be right (general pipeline), on this call and the next.  The row-class path takes its hints from
     bhs_set_data time too and classifies every row on the device: with it the multiply must be right as well, on
-    the class kernels (the merged row still has <= 64 entries: poisson5pt) or back on the general pipeline."""
+    the class kernels or back on the general pipeline (a row longer than the classifier was sized for finds no class)."""
     import torch
     dev = torch.device("cuda", 0)
     m, rp, col, val = poisson_case(stencil, *dims)
@@ -921,7 +921,9 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
             assert bh.spgemm() == 0
             names = {s["name"] for s in bh.kernel_stats()}
             if class_path and stencil == "poisson5pt":
-                assert "numeric_class" in names                                  # 35 entries: still classifiable
+                # 35 entries: within the tables, but beyond what the classifier was sized for from the longest row seen at
+                # bhs_set_data time (round 3: entries per lane follow that hint) -- class kernels or general pipeline
+                assert "numeric_class" in names or "upper_bound" in names
             else:
                 assert "upper_bound" in names and "numeric_class" not in names   # general pipeline
             Cp = bh.get_rowptrC()
