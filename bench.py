@@ -14,7 +14,9 @@ Workloads (BASELINE.json `configs`; values = gallery.fill_values, seed 20140519)
   p27_weak (default) poisson27pt, 128^3 rows per GPU: 128^3 at N=1 (configs[2]),
                      128x128x256 at N=2, 128x256x256 at N=4, 256^3 at N=8 (configs[4])
   p27_128 / p27_160 / p27_256 / p5_1024   fixed-size variants (strong scaling at N > 1)
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N=1 its `cpu_baseline` object holds the CPU oracle's figure on a bounded sample
+(kind "port") and, when oracle/_ref was built, `reference_opencl_same_gpu`: the reference's own OpenCL implementation
+run once on the same GPU and matrix, as timed by its own spgemm() timer.
 """
 import argparse
 import json
@@ -41,6 +43,38 @@ def workload_dims(name, world):
     return st, dims, "strong"
 
 
+def reference_opencl_leg(m, rp, col, val, nnzCt):
+    """One C = A^2 of the same matrix through oracle/_ref/ref_opencl_spgemm (the reference's SpGEMM_opencl, unmodified)."""
+    import re
+    import subprocess
+    import tempfile
+    import numpy as np
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    exe = os.path.join(ref_dir, "ref_opencl_spgemm")
+    if not os.path.exists(exe):
+        return None
+    if nnzCt >= 2 ** 31:
+        return {"skipped": "the reference counts products in int32 (bhsparse.h:367): %d overflow it" % nnzCt}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            fin = os.path.join(td, "in.bin")
+            with open(fin, "wb") as f:
+                np.array([m, m, m, len(col), len(col)], np.int32).tofile(f)
+                for a, dt in ((rp, np.int32), (col, np.int32), (rp, np.int32), (col, np.int32), (val, np.float64), (val, np.float64)):
+                    np.ascontiguousarray(a, dt).tofile(f)
+            env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND="-Dinline=static")     # see oracle/make_ref_golden.py
+            p = subprocess.run([exe, fin, "-"], cwd=ref_dir, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                               timeout=240, env=env)
+        mt = re.search(r"SpGEMM time: ([0-9.eE+-]+) ms\. Gflops = ([0-9.eE+-]+)", p.stdout)
+        mn = re.search(r"-> nnzC=(\d+)", p.stdout)
+        if p.returncode != 0 or not mt:
+            return {"error": "rc %d" % p.returncode, "stdout_tail": p.stdout.strip().splitlines()[-4:]}
+        return {"ms": float(mt.group(1)), "gflops": float(mt.group(2)), "nnzC": int(mn.group(1)) if mn else None,
+                "what": "SpGEMM_opencl's own timer around its spgemm() (stages 1-4, incl. its host statistics and buffer allocation)"}
+    except Exception as e:                                  # a baseline that cannot run must not take the bench line down
+        return {"error": str(e)[-300:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +83,7 @@ def main():
     ap.add_argument("--workload", default="p27_weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-reference", action="store_true", help="N=1: skip the run of the reference's own OpenCL build (oracle/_ref) on this GPU")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (compute-only)")
     ap.add_argument("--no-extra", action="store_true", help="N=1: skip the short runs of the other BASELINE configs")
     ap.add_argument("--no-general", action="store_true", help="N=1: skip the second headline (general pipeline)")
@@ -259,6 +294,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 5),
+                "measured_hbm_GBs": round(traffic / (avg_ms * 1e-3) / 1e9, 2) if traffic else None,
                 "launches_timed": ks["launches"], "build": facade._lib.source_digest(),
                 "traffic_from_build": traffic_build}
     # whole-pipeline compulsory-bytes model: read A, read B, write C once
@@ -307,6 +343,12 @@ def main():
                "sample_1thread": "rows [0,%d): %d products in %.2f s" % (one, ct1, dt1)}
         if not chk["ok"]:
             cpu["mismatch"] = chk
+        # Same baseline leg, second figure: the REFERENCE ITSELF -- its OpenCL branch, built unmodified into oracle/_ref
+        # (oracle/Makefile) -- on this same GPU and the same matrix, timed by its own spgemm() timer ("SpGEMM time").
+        # Its own process, after the timed steps above; skipped when the binary is absent.  Reported beside the CPU
+        # figure, never as `value`.
+        if not args.no_reference:
+            cpu["reference_opencl_same_gpu"] = reference_opencl_leg(m, hBp, hBj, hBx, bh.nnzCt)
 
     # ---- second headline: the same multiply with every launch shortcut that rests on per-dataset row bounds
     # switched off (no row classes, no lane-first / wave-first / numeric-first: upper-bound pass, host round trip and
@@ -380,6 +422,7 @@ def main():
         "host_ms_per_step_spgemm": round(t_compute / args.steps, 4),
         "gather_ms_per_step": round(ms_per_step - t_compute / args.steps, 4) if (world > 1 or force_gather) else 0.0,
         "gather_link_floor_ms": round(native.link_floor_ms(), 4) if native is not None else None,
+        "nranks_seen": native.nranks() if native is not None else None,
         "native_ms_per_step": [round(x / args.steps, 4) for x in gather_ms] if native is not None else None,
         "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),
         "pipeline_compulsory_bytes": int(bytes_alg_total),

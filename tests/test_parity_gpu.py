@@ -1333,7 +1333,16 @@ def test_native_allgatherv_world_size_1(oracle, sub_blocks, kind):
     small_v = torch.empty(10, dtype=torch.float64, device=dev)
     with pytest.raises(RuntimeError):
         nd.spgemm_allgatherv(m, m, frp, small_c, small_v, sub_blocks=sub_blocks)
-    assert bh.spgemm() == 0                       # the handle is usable afterwards
+    assert bh.spgemm() == 0                       # the handle is usable afterwards ...
     assert ("numeric_class" in {s["name"] for s in bh.kernel_stats() if s["launches"]}) == (kind == "stencil_classes")
+    # ... and writes into its OWN arrays again: the gather's destination is unbound on every exit of the call
+    frp.fill_(-7); fc.fill_(-7); fv.fill_(-7.0)
+    assert bh.spgemm() == 0
+    torch.cuda.synchronize()
+    assert int(fc.max()) == -7 and float(fv.max()) == -7.0
+    Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+    assert bh.get_C(Cj, Cx) == 0
+    assert oracle.compare(ref, (bh.get_rowptrC(), Cj, Cx), rel_tol=0.0)["ok"]
+    assert nd.nranks() == 1                       # what RCCL itself counts (bhs_dist_nranks)
     nd.close()
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
