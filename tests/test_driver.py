@@ -72,8 +72,8 @@ def test_driver_builds_and_fails_cleanly_without_gpu(driver):
     assert p.returncode == 1
 
 
-def _run(driver, *args):
-    p = subprocess.run([driver] + list(args), capture_output=True, text=True, timeout=300)
+def _run(driver, *args, timeout=300):
+    p = subprocess.run([driver] + list(args), capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout + p.stderr
     return p.stdout
 
@@ -143,6 +143,53 @@ def test_driver_two_different_rectangular_files(driver, tmp_path, oracle):
     # mismatched inner dimensions are refused like any other driver error
     p = subprocess.run([driver, "-hip", "-spgemm", str(b), str(b)], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "dimension mismatch" in p.stdout
+
+
+def _write_mtx(path, m, n, rp, col, val, symmetric=False, field="real"):
+    """Matrix Market coordinate file of a CSR matrix (1-based, entries shuffled); symmetric: lower triangle only."""
+    import numpy as np
+    rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(rp.astype(np.int64)))
+    cols = col.astype(np.int64)
+    vals = val
+    if symmetric:
+        keep = cols <= rows
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    perm = np.random.default_rng(3).permutation(len(rows))
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n%% written by tests/test_driver.py\n%d %d %d\n"
+                % (field, "symmetric" if symmetric else "general", m, n, len(rows)))
+        np.savetxt(f, np.column_stack([rows[perm] + 1, cols[perm] + 1, vals[perm]]), fmt="%d %d %d")
+    return len(rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["powerlaw_1m_general", "p27_51_symmetric", "p27_51_general"])
+def test_driver_real_size_matrix_market_files(driver, tmp_path, case):
+    """SURVEY.md 8(f3) / BASELINE configs[3]: what the reference is for is `spgemm -<backend> -spgemm file.mtx` on
+    SuiteSparse-size files (README.md:56-62, main.cu:56-64).  No SuiteSparse file is in the image, so files of that
+    size are written here -- the 1 M-row power-law stand-in for webbase-1M (3.0 M entries, general) and poisson27pt
+    51^3 (3.4 M entries; once as its lower triangle, `symmetric`, which the reader has to mirror) -- and go through the
+    driver exactly as a downloaded file would: Matrix Market reader, row sort, random 1..9 values, multiply on the GPU,
+    compData against the CPU oracle (PASS lines), counts."""
+    import numpy as np
+    from benchmark_spgemm_using_csr_amd import gallery
+    if case == "powerlaw_1m_general":
+        m = 1000005
+        rp, col = gallery.powerlaw_csr(m, m, 3105536, 4700)
+        sym = False
+    else:
+        rp, col = gallery.poisson_csr("poisson27pt", 51, 51, 51)
+        m = len(rp) - 1
+        sym = case.endswith("symmetric")
+    path = tmp_path / (case + ".mtx")
+    stored = _write_mtx(str(path), m, m, rp, col, np.ones(len(col)), symmetric=sym)
+    out = _run(driver, "-hip", "-spgemm", str(path), timeout=900)
+    assert " A: ( %d by %d, nnz = %d )" % (m, m, len(col)) in out, out[-1500:]     # (mirrored entries included)
+    assert stored == len(col) or sym
+    assert "Matrix Market reader:" in out and "[ HIP ] SpGEMM time:" in out
+    assert "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out, out[-1500:]
+    if not case.startswith("powerlaw"):
+        assert '"nnzCt": %d, "nnzC": %d, "pass": true' % ((9 * 51 - 10) ** 3, (5 * 51 - 6) ** 3) in out
 
 
 def test_host_code_under_address_and_ub_sanitizers(tmp_path, oracle):
