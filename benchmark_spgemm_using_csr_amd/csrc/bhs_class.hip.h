@@ -683,6 +683,27 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
 #define BHS_CLS_PARTS 1
 #endif
 constexpr unsigned kClassIdleA = 1u << 12;     // product triple of a lane without a product
+#ifndef BHS_CLS_STORE_SC1
+#define BHS_CLS_STORE_SC1 1
+#endif
+// Stores of C that do not stay in the XCD's L2 (sc1: write-through, the line is dropped).  The kernel writes 3.3 GB that
+// nobody reads again through a 4 MB L2 per XCD: with plain stores those lines push out the rows of B that the next
+// rows of A need again (measured: 5.2 GB read per launch where 1.2 GB is compulsory).
+__device__ __forceinline__ void class_store_c(double* p, double v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+__device__ __forceinline__ void class_store_c(float* p, float v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+__device__ __forceinline__ void class_store_c(int* p, int v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
 constexpr int kClassRunA = 8;
 constexpr int kClassWavesA = 4;
 
@@ -792,8 +813,8 @@ __global__ __launch_bounds__(64 * kClassWavesA) void k_class_numeric_atomic(
                 if (s < nnz) {
                     const acc_t val = acc[s];
                     acc[s] = 0.0;
-                    Cj[(long long)out + s] = rel[v] + row + rowBase;
-                    Cx[(long long)out + s] = (value_t)val;
+                    class_store_c(&Cj[(long long)out + s], rel[v] + row + rowBase);
+                    class_store_c(&Cx[(long long)out + s], (value_t)val);
                 }
             }
             wave_sync();

@@ -6,20 +6,19 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library; the product (libbhsparse_hip.so) never links or calls it.
  *
- * PARITY STATUS: **parity unpinned by the reference itself.**
- *   - The reference's own checker (SpGEMM_cuda/ref_spgemm.h:65-127) is not a
- *     CPU algorithm: it calls cusp::multiply on device COO (CUSP v0.4.0,
- *     README.md:91; un-vendored, absent from /root/reference) and cannot be
- *     built here (no nvcc, no CUSP, no helper_cuda.h).  The OpenCL branch has
- *     no checker at all (SpGEMM_opencl/main.cpp:273-274).
- *   - The repo holds no golden output vectors; it holds *inputs* only
- *     (test_small_spgemm, main.cu:153-205; cage4.mtx).
- *   What this oracle IS pinned against (tests/test_oracle.py):
- *     (i)  hand-derived known answers for those two inputs,
- *     (ii) scipy.sparse fixtures generated in the dev container by
- *          tests/golden/make_golden.py (valid second oracle because all
- *          driver values are strictly positive => no exact cancellation),
- *     (iii) closed forms for the Poisson stencils (nnzA/nnzCt/nnzC).
+ * PARITY STATUS: **pinned to the reference itself** (round 3).
+ *   - The reference's CUDA branch and its checker (cusp::multiply on device COO, CUSP v0.4.0, README.md:91,
+ *     un-vendored) cannot be built here (no nvcc, no CUSP, no helper_cuda.h).  Its OpenCL branch can: oracle/Makefile
+ *     `_ref` compiles SpGEMM_opencl/{bhsparse,bhsparse_opencl,basiccl}.cpp unmodified with g++ around a small dump
+ *     driver (oracle/ref_opencl_dump.cpp), and the MI355X boxes expose an OpenCL device (profiles/
+ *     r03_gpu_box_clinfo.txt).  oracle/make_ref_golden.py ran 15 inputs through it ON AN MI355X and compared this
+ *     oracle with the reference's C on the spot: rowPtr, colInd and values identical in all 15 (the reference's two
+ *     fixed inputs, the gallery stencils up to its default sizes poisson5pt 256^2 / poisson27pt 51^3, rectangular,
+ *     every bin of its table, its multi-round merge on power-law rows, exact cancellation -- 168 structural zeros
+ *     kept).  The reference's outputs are committed as tests/golden/ref_opencl_*.npz (+ digests of the three large
+ *     cases) and tests/test_oracle.py re-checks this file against them on every CPU run.
+ *   - Beside that: hand-derived known answers for the reference's two fixed inputs, scipy
+ *     fixtures (tests/golden/make_golden.py; valid because all driver values are > 0), the stencils' closed forms.
  *
  * What is restated, and from where:
  *   - result definition: for each row i the multiset {(colB, valA*valB)} over

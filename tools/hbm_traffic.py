@@ -3,16 +3,16 @@
 
     python tools/hbm_traffic.py gpurun_out/prof_<tag> [workload]
 
-Raw figures per launch of every bhs:: kernel: FETCH_SIZE / WRITE_SIZE (KB x 1024) and the L2's request counters
-(TCC_EA0_RDREQ / _32B, TCC_EA0_WRREQ / _64B).  The guide warns that FETCH_SIZE under-counts on gfx950 (128-byte
-requests tallied at 64), and round 2's file was contradicted by its own passes (k_check_sorted read 146 MB
-where it must read >= 231 MB).  So the read side is CALIBRATED PER RUN on passes whose byte count is known exactly:
-  k_check_sorted     reads colIndB + rowPtrB once                      4 * nnzB + 4 * (k + 1)
-  k_class_heads<B>   reads colIndB + rowPtrB once                      4 * nnzB + 4 * (k + 1)
-read factor = known / FETCH_SIZE of those kernels (mean).  WRITE_SIZE is taken as it is; the file records how it
-compares with the one write count that is known exactly (the class path's numeric kernel writes every entry of C once:
-12 * nnzC).  The file states the factor; `numeric_class` etc. are the calibrated bytes per launch (bench.py's
-roofline.traffic), stamped with the digest of the device sources so that bench.py only quotes them for that build."""
+Bytes per launch of every bhs:: kernel that left / entered the XCDs' L2s on the memory side, from the request
+counters BY SIZE: reads = 128 x TCC_EA0_RDREQ_128B + 64 x TCC_EA0_RDREQ_64B + 32 x TCC_EA0_RDREQ_32B, writes = 64 x
+TCC_EA0_WRREQ_64B + 32 x (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B).  FETCH_SIZE is NOT used for the figure: it tallies every
+read request at 64 bytes and so reads 0.5-0.65 x of what a streaming pass moves on gfx950 (the guide says
+the same).  The script checks the size-resolved figure where the truth is known exactly --
+  k_check_sorted, k_class_heads<false>   read colIndB + rowPtrB once:   4 * nnzB + 4 * (k + 1) bytes
+  k_class_numeric*                        writes every entry of C once:  12 * nnzC bytes
+-- and records the ratios under `check` (all within a few per cent of 1 or the file says so).  *_DRAM: requests that
+went on to HBM (the others were served by the Infinity Cache).  Stamped with the digest of the device sources:
+bench.py quotes `roofline.traffic` only for the build it was measured on."""
 import collections, csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,12 +20,13 @@ from benchmark_spgemm_using_csr_amd import _lib
 
 prof = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "p27_weak"
-WANT = ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
+WANT = ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum",
+        "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_DRAM_sum")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(prof + "/pmc*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         if "bhs::" in r["Kernel_Name"] and r["Counter_Name"] in WANT:
-            agg[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void bhs::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void bhs::", "").replace("bhs::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 bench = json.load(open(os.path.join(prof, "bench_stats.json")))
 cfg = bench["config"]
 nnzB, k, nnzC = cfg["nnzA_total"], cfg["m"], cfg["nnzC"]          # (C = A^2: B = A)
@@ -44,39 +45,37 @@ def stat_name(kk):
 
 
 mean = lambda v: sum(v) / len(v) if v else None
-raw = {}
+raw, out, check = {}, {}, {}
 for kk, d in sorted(agg.items()):
     e = {c: mean(d.get(c)) for c in WANT}
-    e["fetch_bytes"] = e["FETCH_SIZE"] * 1024 if e["FETCH_SIZE"] is not None else None
-    e["write_bytes"] = e["WRITE_SIZE"] * 1024 if e["WRITE_SIZE"] is not None else None
-    if e["TCC_EA0_RDREQ_sum"] is not None and e["TCC_EA0_RDREQ_32B_sum"] is not None:
-        e["rdreq_bytes_64_32"] = 64 * (e["TCC_EA0_RDREQ_sum"] - e["TCC_EA0_RDREQ_32B_sum"]) + 32 * e["TCC_EA0_RDREQ_32B_sum"]
-    if e["TCC_EA0_WRREQ_sum"] is not None and e["TCC_EA0_WRREQ_64B_sum"] is not None:
-        e["wrreq_bytes_64_32"] = 64 * e["TCC_EA0_WRREQ_64B_sum"] + 32 * (e["TCC_EA0_WRREQ_sum"] - e["TCC_EA0_WRREQ_64B_sum"])
+    g = lambda c: e.get(c) or 0.0
+    have_r = e["TCC_EA0_RDREQ_128B_sum"] is not None
+    have_w = e["TCC_EA0_WRREQ_sum"] is not None
+    e["read_bytes"] = 128 * g("TCC_EA0_RDREQ_128B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 32 * g("TCC_EA0_RDREQ_32B_sum") if have_r else None
+    e["write_bytes"] = 64 * g("TCC_EA0_WRREQ_64B_sum") + 32 * (g("TCC_EA0_WRREQ_sum") - g("TCC_EA0_WRREQ_64B_sum")) if have_w else None
+    e["fetch_size_bytes"] = e["FETCH_SIZE"] * 1024 if e["FETCH_SIZE"] is not None else None
+    e["write_size_bytes"] = e["WRITE_SIZE"] * 1024 if e["WRITE_SIZE"] is not None else None
+    if e["TCC_EA0_RDREQ_sum"]:
+        e["reads_to_dram_fraction"] = g("TCC_EA0_RDREQ_DRAM_sum") / e["TCC_EA0_RDREQ_sum"] if e["TCC_EA0_RDREQ_DRAM_sum"] is not None else None
     raw[kk] = e
-known_read = 4 * nnzB + 4 * (k + 1)
-cal_r = [known_read / e["fetch_bytes"] for kk, e in raw.items()
-         if e["fetch_bytes"] and ("k_check_sorted" in kk or "k_class_heads<false" in kk)]
-chk_w = [e["write_bytes"] / (12.0 * nnzC) for kk, e in raw.items() if e["write_bytes"] and "k_class_numeric" in kk]
-read_factor = mean(cal_r) if cal_r else 1.0
-write_factor = 1.0
-out = {}
-for kk, e in raw.items():
     n = stat_name(kk)
-    if n and e["fetch_bytes"] is not None and e["write_bytes"] is not None:
-        out[n] = int(e["fetch_bytes"] * read_factor + e["write_bytes"] * write_factor)
-        out[n + " (read, write)"] = [int(e["fetch_bytes"] * read_factor), int(e["write_bytes"] * write_factor)]
+    if n and have_r and have_w:
+        out[n] = int(e["read_bytes"] + e["write_bytes"])
+        out[n + " (read, write)"] = [int(e["read_bytes"]), int(e["write_bytes"])]
+    if have_r and ("k_check_sorted" in kk or "k_class_heads<false" in kk):
+        check[kk + ": read / (4 nnzB + 4 (k + 1))"] = round(e["read_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
+        if e["fetch_size_bytes"]:
+            check[kk + ": FETCH_SIZE / same"] = round(e["fetch_size_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
+    if have_w and "k_class_numeric" in kk:
+        check[kk + ": written / (12 nnzC)"] = round(e["write_bytes"] / (12.0 * nnzC), 4)
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-doc = {"_comment": "calibrated HBM bytes per launch (tools/hbm_traffic.py): FETCH_SIZE x read_factor + WRITE_SIZE x write_factor; "
-                   "factors from this same run's kernels of known traffic (see `calibration`); `raw` keeps every counter",
-       "build": _lib.source_digest(),
-       "calibration": {"read_factor": read_factor, "write_factor": write_factor, "known_read_bytes_colIndB_rowPtrB": known_read,
-                       "read_factor_per_kernel": cal_r, "write_size_over_known_12_nnzC_numeric_class": chk_w},
-       workload: out, "raw": raw}
+doc = {"_comment": "memory-side bytes per launch (tools/hbm_traffic.py): 128/64/32-byte read requests and 64/32-byte write requests "
+                   "of the L2s, separate --pmc passes (tools/prof.sh); `check` compares them with passes of exactly known traffic; "
+                   "`raw` keeps every counter incl. FETCH_SIZE / WRITE_SIZE",
+       "build": _lib.source_digest(), "check": check, workload: out, "raw": raw}
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps({kk: v for kk, v in doc.items() if kk != "raw"}, indent=1))
 for kk, e in raw.items():
-    print("%-60s fetch %8.1f MB  write %8.1f MB  rdreq(64/32) %s MB  wrreq(64/32) %s MB" % (
-        kk[:60], (e["fetch_bytes"] or 0) / 1e6, (e["write_bytes"] or 0) / 1e6,
-        "%.1f" % (e["rdreq_bytes_64_32"] / 1e6) if e.get("rdreq_bytes_64_32") else "-",
-        "%.1f" % (e["wrreq_bytes_64_32"] / 1e6) if e.get("wrreq_bytes_64_32") else "-"))
+    print("%-44s read %8.1f MB (FETCH_SIZE %8.1f)  write %8.1f MB (WRITE_SIZE %8.1f)  reads that went to DRAM: %s" % (
+        kk[:44], (e["read_bytes"] or 0) / 1e6, (e["fetch_size_bytes"] or 0) / 1e6, (e["write_bytes"] or 0) / 1e6,
+        (e["write_size_bytes"] or 0) / 1e6, "%.2f" % e["reads_to_dram_fraction"] if e.get("reads_to_dram_fraction") is not None else "-"))

@@ -12,8 +12,9 @@ timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -d $out/pmc2 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc2.err
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc3 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc3.err
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $out/pmc4 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc4.err
-# memory-side request counters of the L2 (what FETCH_SIZE / WRITE_SIZE are derived from): bytes = 64 x (RDREQ - RDREQ_32B)
-# + 32 x RDREQ_32B, likewise for writes -- and the per-kernel calibration against passes whose byte count is known
-timeout 120 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $out/pmc5 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc5.err
-timeout 120 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $out/pmc6 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc6.err
+# memory-side request counters of the L2 by request size (FETCH_SIZE tallies every request at 64 bytes: it under-counts
+# by up to 2x on gfx950, where a request can be 128 bytes): read bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B;
+# the second pass: write requests by size, and how many of either kind went on to DRAM (the rest hit the Infinity Cache)
+timeout 120 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $out/pmc5 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc5.err
+timeout 120 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum -d $out/pmc6 -o p --output-format csv -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $out/pmc6.err
 find $out -name "*.csv" | head -30
