@@ -2,6 +2,9 @@
 """Results table over the driver's gallery (README.md:40-54 of the reference: datasets 1-4), their full-size versions
 in BASELINE.json, and the stand-ins for the inputs that are not in the image (power-law web graph, 3-dof FEM):
 C = A^2, fp64, device-resident inputs, median of 10 multiplies after 3 warm-ups.  Prints a Markdown table.
+Last column: the REFERENCE ITSELF on the same GPU and matrix -- its OpenCL branch built unmodified into oracle/_ref
+(oracle/Makefile), one multiply in its own process, the time its own spgemm() timer prints (bench.reference_opencl_leg);
+"-" when the binary is absent, the reason when it cannot run the case.
 
     python tools/results_table.py > gpurun_out/results_table.md
 """
@@ -9,6 +12,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from benchmark_spgemm_using_csr_amd import gallery, facade
+import bench as benchmod
 
 dev = torch.device("cuda", 0)
 HBM = 8000.0e9
@@ -39,8 +43,8 @@ CASES = [
      lambda: tuple(torch.from_numpy(a).to(dev) for a in gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700))),
 ]
 
-print("| Workload (C = A^2, fp64) | rows | nnz(A) | products | nnz(C) | ms (median of 10) | GFLOP/s | compulsory bytes / t / 8 TB/s | dominant kernel |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| Workload (C = A^2, fp64) | rows | nnz(A) | products | nnz(C) | ms (median of 10) | GFLOP/s | compulsory bytes / t / 8 TB/s | dominant kernel | reference (SpGEMM_opencl) on this GPU, ms |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 plats = [False] * 9
 plats[3] = True
 for name, gen in CASES:
@@ -61,9 +65,16 @@ for name, gen in CASES:
     ms = float(np.median(ts))
     ks = max(bh.kernel_stats(), key=lambda s: s["ms"])
     alg = 2 * (4 * (m + 1) + 12 * Bj.numel()) + 4 * (m + 1) + 12 * bh.nnzC
-    print("| %s | %d | %d | %d | %d | %.3f | %.1f | %.1f %% | %s (%.3f ms) |" %
+    ref = benchmod.reference_opencl_leg(m, Bp.cpu().numpy(), Bj.cpu().numpy(), Bx.cpu().numpy(), bh.nnzCt) if "--no-reference" not in sys.argv else None
+    if ref is None:
+        refs = "-"
+    elif "ms" in ref:
+        refs = "%.1f (%.0fx)%s" % (ref["ms"], ref["ms"] / ms, "" if ref.get("nnzC") == bh.nnzC else " nnzC %s!" % ref.get("nnzC"))
+    else:
+        refs = ref.get("skipped") or ("failed: " + str(ref.get("error")) + " " + " / ".join(ref.get("stdout_tail", []))[:160])
+    print("| %s | %d | %d | %d | %d | %.3f | %.1f | %.1f %% | %s (%.3f ms) | %s |" %
           (name, m, Bj.numel(), bh.nnzCt, bh.nnzC, ms, 2.0 * bh.nnzCt / (ms * 1e6), 100.0 * alg / (ms * 1e-3) / HBM,
-           ks["name"], ks["ms"]))
+           ks["name"], ks["ms"], refs), flush=True)
     bh.free_mem(); bh.freePlatform()
     del Ap, Aj, Ax, Bp, Bj, Bx
     torch.cuda.empty_cache()
