@@ -30,6 +30,7 @@
 
 namespace bhs {
 
+constexpr int kClassEpl = 16 / (int)sizeof(value_t);   // values of B per lane of a 16-byte LDS-direct load
 constexpr int kClassSlots = 4096;          // slots of each hash table; a class id is a slot number
 constexpr int kClassProbe = 32;            // linear probes before a row counts as unclassified
 constexpr int kClassMaxRow = 64;           // entries per row of A / of B
@@ -39,7 +40,8 @@ constexpr unsigned long long kClassEmpty = ~0ull;
 
 // `stats` block written by k_class_rows / k_class_patterns (ints)
 constexpr int kClassSumSlots = 32;
-enum { CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
+enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_wg.hip.h), 0x7fffffff: some class cannot */,
+       CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
        CS_INTS = 8 + 2 * kClassSumSlots + 2 };
@@ -465,12 +467,13 @@ __global__ __launch_bounds__(256) void k_class_propagate(int nrows, int* __restr
 //   the entry's position, or kClassDump when the entry goes on in the NEXT lane (then the lane's sum at the end of
 //   its list is a partial sum that it adds to that entry's position, classLane[.. + L] below).  A lane with fewer
 //   than U products has its idle steps FIRST (the sum it carries at the end of the list is that of real products).
-// classLane[s * kClassLaneInts + ..]: [L] = tail position of lane L (-1: none); [64 + L] = chains of the A row --
-//   maximal stretches of A entries with consecutive columns, whose B rows are therefore one contiguous stretch of
-//   B's arrays, also across consecutive rows of the class: as A entry L: chain number (bits 0-5); as chain L
-//   (bit 31 set): first A entry (bits 8-13), last A entry (16-21), length of the last entry's B row (24-30);
-//   [128 + L] = length of the B row of A entry L; [192] = sum of the chains' last-entry lengths (what one more row of
-//   the class adds to the staged B values).
+// classLane[s * kClassLaneInts + ..]: [L] = tail position of lane L (-1: none).  The rest describes the CHAINS of the A
+//   row: maximal stretches of A entries with consecutive columns whose B rows have one length -- consecutive rows of
+//   B, also across consecutive rows of the class (row i + 1's entry k selects the B row after row i's).  A "slab" is
+//   one B row of every chain side by side, each padded to whole 16-byte lanes: what one more row of the class adds.
+//   [64 + L]  as A entry L: its chain's place in a slab (bits 0-15), its place in the chain (16-21), its B row's length (24-30)
+//   [128 + L] as chain L:   first A entry (0-5), entries (6-12), B row length (13-19), place in a slab (20-30)
+//   [192] chains (0-7), entries of the longest chain (8-15), values per slab (16-31)
 // ---------------------------------------------------------------------------
 constexpr int kClassLaneInts = 256;
 constexpr unsigned kClassStart = 1u << 12, kClassIdleBit = 1u << 13, kClassDump = 1023u;
@@ -597,35 +600,44 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         int tail = -1;
         if (first <= last && last + 1 < P && (srt[last + 1] >> 10) == (srt[last] >> 10)) tail = srt[last] >> 10;
         classLane[(size_t)s * kClassLaneInts + tid] = tail;
-        // chains of the A row (stored order): entry k opens one unless its column follows entry k - 1's
+        // chains of the A row (stored order): entry k opens one unless its column follows entry k - 1's and its B row is
+        // as long as that one's
         const int col = tid < nA ? Aj[a0 + tid] : 0;
-        const int prev = __shfl_up(col, 1, 64);
-        const bool opens = tid < nA && (tid == 0 || col != prev + 1);
+        const int myLen = tid < nA ? sIncl[tid] - (tid ? sIncl[tid - 1] : 0) : 0;
+        const int prev = __shfl_up(col, 1, 64), prevLen = __shfl_up(myLen, 1, 64);
+        const bool opens = tid < nA && (tid == 0 || col != prev + 1 || myLen != prevLen);
         const unsigned long long om = __ballot(opens);
-        const int chain = __popcll(om & ((2ull << tid) - 1ull)) - 1;          // chain of entry tid
-        const int opened = 63 - __clzll((long long)(om & ((2ull << tid) - 1ull)));   // ... and the entry that opened it
-        int aux = tid < nA ? (chain | ((tid - opened) << 6)) : 0;
+        const unsigned long long upTo = om & ((2ull << tid) - 1ull);
+        const int chain = __popcll(upTo) - 1;                                  // chain of entry tid
+        const int opened = tid < nA ? 63 - __clzll((long long)upTo) : 0;       // ... and the entry that opened it
         const int nCh = __popcll(om);
-        int lastLen = 0;
-        if (tid < nCh) {                                                       // as chain tid: its first / last entry
+        int kf = 0, len = 0, lc = 0;
+        if (tid < nCh) {                                                       // as chain tid: its first entry, entries, row length
             unsigned long long rest = om;
             for (int i = 0; i < tid; ++i) rest &= rest - 1;                   // (<= 63 steps, once per class)
-            const int kf = __ffsll((long long)rest) - 1;
+            kf = __ffsll((long long)rest) - 1;
             rest &= rest - 1;
-            const int kl = (rest ? __ffsll((long long)rest) - 1 : nA) - 1;
-            lastLen = sIncl[kl] - (kl ? sIncl[kl - 1] : 0);
-            aux |= (int)(0x80000000u | ((unsigned)kf << 12) | ((unsigned)kl << 18) | ((unsigned)lastLen << 24));
+            len = (rest ? __ffsll((long long)rest) - 1 : nA) - kf;
+            lc = sIncl[kf] - (kf ? sIncl[kf - 1] : 0);
         }
-        classLane[(size_t)s * kClassLaneInts + 64 + tid] = aux;
-        const int myLen = tid < nA ? sIncl[tid] - (tid ? sIncl[tid - 1] : 0) : 0;
-        classLane[(size_t)s * kClassLaneInts + 128 + tid] = myLen;
+        const int lpad = (lc + kClassEpl - 1) & ~(kClassEpl - 1);
+        const int place = wave_incl_scan_dpp(lpad) - lpad;                     // of the chain's row in a slab
+        const int slab = __builtin_amdgcn_readlane(place + lpad, 63);
+        int maxLen = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxLen = max(maxLen, __shfl_xor(maxLen, o, 64));
+        const int myPlace = __shfl(place, tid < nA ? chain : 0, 64);
+        classLane[(size_t)s * kClassLaneInts + 64 + tid] = tid < nA ? (myPlace | ((tid - opened) << 16) | (myLen << 24)) : 0;
+        classLane[(size_t)s * kClassLaneInts + 128 + tid] = tid < nCh ? (kf | (len << 6) | (lc << 13) | (place << 20)) : 0;
+        if (tid == 0) {
+            classLane[(size_t)s * kClassLaneInts + 192] = nCh | (maxLen << 8) | (slab << 16);
+            // the ring of the workgroup kernel: (entries of the longest chain + 2) slabs; 4 x 64 lanes x 16 bytes per slab at most
+            atomicMax(&stats[CS_MAXRING], slab <= 4 * 64 * kClassEpl ? (maxLen + 2) * slab : 0x7fffffff);
+        }
         int mx = myLen;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
         if (tid == 0) atomicMax(&stats[CS_MAXLB], mx);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lastLen += __shfl_xor(lastLen, o, 64);
-        if (tid == 0) classLane[(size_t)s * kClassLaneInts + 192] = lastLen;
     }
     if (tid == 0) {
         classInfo[s] = make_int4(nA, P, nnz, rep);

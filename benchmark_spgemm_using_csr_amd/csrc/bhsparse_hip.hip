@@ -219,7 +219,7 @@ struct bhs_handle {
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
         bool useClass = false;            // numeric half: k_class_numeric
-        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0;
+        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0;
         int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
@@ -465,48 +465,50 @@ int launch_class_numeric_atomic(bhs_handle* h, int r0, int r1)
 }
 
 
-// Numeric pass by row classes on the rows [r0, r1): the workgroup kernel (bhs_class_wg.hip.h)
-template <int MAXU, int MAXV, int LP>
-int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
+// Numeric pass by row classes on the rows [r0, r1): the ring kernel (bhs_class_wg.hip.h)
+template <int MAXU, int MAXV>
+int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
 {
-    auto kern = k_class_numeric<MAXU, MAXV, LP>;
-    const size_t smem = (size_t)ClassLds<LP, 64 * MAXV>::kBytes;
+    auto kern = k_class_numeric<MAXU, MAXV>;
+    const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
+    const int stageCap = (kClassRun * h->ps.classMaxNA + 63) & ~63; // a run's A entries
+    const int ringCap = (h->ps.classMaxRing + 63) & ~63;            // (longest chain + 2) slabs of the neediest class
+    const size_t smem = (size_t)(accStride + 2 * stageCap) * sizeof(acc_t) + (size_t)ringCap * sizeof(value_t) +
+                        (size_t)(2 * stageCap) * sizeof(int);
     int perCU = 1;
     BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
     perCU = std::max(1, std::min(perCU, 32));
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     const int mR = r1 - r0;
-    const long long nRuns = ((long long)mR + kClassRun - 1) / kClassRun;
-    long long grid = std::min<long long>(nRuns, (long long)h->numCU * useCU);
+    const long long nSuper = ((long long)mR + kClassSuper - 1) / kClassSuper;
+    long long grid = std::min<long long>(nSuper, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
                        (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
-                       out_cx(h), r0);
+                       out_cx(h), accStride, stageCap, ringCap, r0);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
 
-template <int MAXU, int MAXV>
-int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
+// (false: some class's slab or ring is beyond what the ring kernel keeps in LDS -- the caller takes the atomic kernel)
+bool class_ring_fits(bhs_handle* h)
 {
-    const int longest = std::max(h->ps.classMaxNA, h->ps.classMaxLB);   // slots per staged row of A / of B
-    if (longest <= 8) return launch_class_numeric_impl<MAXU, MAXV, 8>(h, r0, r1);
-    if (longest <= 16) return launch_class_numeric_impl<MAXU, MAXV, 16>(h, r0, r1);
-    if (longest <= 32) return launch_class_numeric_impl<MAXU, MAXV, 32>(h, r0, r1);
-    return launch_class_numeric_impl<MAXU, MAXV, 64>(h, r0, r1);
+    if (h->ps.classMaxRing < 0 || h->ps.classMaxRing == 0x7fffffff) return false;
+    const size_t accStride = (size_t)((h->ps.classMaxNnz + 1 + 63) & ~63), stageCap = (size_t)((kClassRun * h->ps.classMaxNA + 63) & ~63);
+    const size_t smem = (accStride + 2 * stageCap) * sizeof(acc_t) + (size_t)((h->ps.classMaxRing + 63) & ~63) * sizeof(value_t) + 2 * stageCap * sizeof(int);
+    return smem <= 40 * 1024;
 }
 
 int launch_class_numeric(bhs_handle* h, int r0, int r1)
 {
-    // steps per lane, and 64-slot groups per row of C (one slot more than its entries: the strays' slot)
-    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 1 + 63) / 64;
+    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
     if (U <= 1 && V <= 1) return launch_class_numeric_uv<1, 1>(h, r0, r1);
     if (U <= 2 && V <= 1) return launch_class_numeric_uv<2, 1>(h, r0, r1);
     if (U <= 4 && V <= 2) return launch_class_numeric_uv<4, 2>(h, r0, r1);
     if (U <= 8 && V <= 4) return launch_class_numeric_uv<8, 4>(h, r0, r1);
     if (U <= 12 && V <= 2) return launch_class_numeric_uv<12, 2>(h, r0, r1);
-    return launch_class_numeric_uv<16, 9>(h, r0, r1);
+    return launch_class_numeric_uv<16, 8>(h, r0, r1);
 }
 
 // Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
@@ -1303,6 +1305,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxNnz = cs[CS_MAXNNZ];
         h->ps.classMaxNA = cs[CS_MAXNA];
         h->ps.classMaxLB = cs[CS_MAXLB];
+        h->ps.classMaxRing = cs[CS_MAXRING];
         if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; %d table probes]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[7]);
     } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
@@ -1379,7 +1382,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (h->ps.useClass) {
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
-        BHS_TRY(h->classNumeric ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
+        BHS_TRY(h->classNumeric && class_ring_fits(h) ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += r1 - r0;
