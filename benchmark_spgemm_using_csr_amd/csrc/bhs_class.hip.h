@@ -41,7 +41,7 @@ constexpr unsigned long long kClassEmpty = ~0ull;
 // `stats` block written by k_class_rows / k_class_patterns (ints)
 constexpr int kClassSumSlots = 32;
 enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_wg.hip.h), 0x7fffffff: some class cannot */,
-       CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
+       CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_MAXSLAB = 7 /* most values per slab */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
        CS_INTS = 8 + 2 * kClassSumSlots + 2 };
@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
             classLane[(size_t)s * kClassLaneInts + 192] = nCh | (maxLen << 8) | (slab << 16);
             // the ring of the workgroup kernel: (entries of the longest chain + 2) slabs; 4 x 64 lanes x 16 bytes per slab at most
             atomicMax(&stats[CS_MAXRING], slab <= 4 * 64 * kClassEpl ? (maxLen + 2) * slab : 0x7fffffff);
+            atomicMax(&stats[CS_MAXSLAB], slab);
         }
         int mx = myLen;
 #pragma unroll

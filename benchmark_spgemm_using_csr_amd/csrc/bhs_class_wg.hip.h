@@ -41,7 +41,7 @@ namespace bhs {
 #endif
 constexpr int kClassRun = BHS_CLS_RUN;                           // rows per run (metadata granularity; <= 63)
 constexpr int kClassSuper = BHS_CLS_SUPER;                       // consecutive rows a wave takes before it moves on
-constexpr int kClassMaxJ = 4;                                    // LDS-direct load instructions per slab (64 lanes x 16 bytes each)
+constexpr int kClassMaxJ = 4;                                    // most LDS-direct load instructions per slab (64 lanes x 16 bytes each)
 static_assert(kClassSuper % kClassRun == 0, "whole runs");
 
 #ifndef BHS_CLS_LAB      // measurement builds only (tools/build_variants.sh): 1 no LDS-direct loads, 2 no stores of C (wrong results)
@@ -54,8 +54,9 @@ static_assert(kClassSuper % kClassRun == 0, "whole runs");
 #endif
 typedef __attribute__((address_space(3))) void bhs_lds_void;
 typedef __attribute__((address_space(1))) const void bhs_glb_void;
+__device__ __forceinline__ unsigned ringBaseOf(const value_t* ring) { return (unsigned)(size_t)ring; }
 
-template <int MAXU, int MAXV>
+template <int MAXU, int MAXV, int SE, int MAXJ>   // SE: 64-entry passes over a run's A entries; MAXJ: load instructions per slab
 __global__ __launch_bounds__(64) void k_class_numeric(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
@@ -63,14 +64,13 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     const int* __restrict__ classLane, const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx,
     int accStride, int stageCap, int ringCap, int rowBase)     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
 {
-    constexpr int SE = kClassRun;                                // 64-entry passes over a run's A entries (rows of <= 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     const int lane = threadIdx.x;
-    // acc[accStride] + sAx[2][stageCap] doubles, ring[ringCap] values (16-byte aligned), sBo[2][stageCap] ints
+    // acc[accStride] + sAx[stageCap] doubles, ring[ringCap] values (16-byte aligned), sBo[stageCap] ints
     acc_t* acc = reinterpret_cast<acc_t*>(smemRaw);
-    acc_t* sAx2 = acc + accStride;                               // A values of the run at hand and of the next run
-    value_t* ring = reinterpret_cast<value_t*>(sAx2 + 2 * stageCap);
-    int* sBo2 = reinterpret_cast<int*>(ring + ringCap);          // B row start of every staged A entry, likewise two runs
+    acc_t* sAx = acc + accStride;                                // A values of the run at hand
+    value_t* ring = reinterpret_cast<value_t*>(sAx + stageCap);
+    int* sBo = reinterpret_cast<int*>(ring + ringCap);           // B row start of every staged A entry
     const unsigned dumpSlot = (unsigned)(accStride - 1);         // never read: idle lanes and partial sums that travel by the tail add
 
     // super-runs: XCD x takes [x * perX, (x + 1) * perX); block b runs on XCD b % 8
@@ -89,8 +89,9 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 
     // A run's metadata travels through a three-deep register pipeline so that no load is waited for where it is
     // issued: at the top of the work on run i the row pointers / classes of run i + 3, the A entries of run i + 2 and
-    // the rowPtrB words of run i + 1 are requested; the first vmcnt(0) of the run (every row has one) covers them, and
-    // right behind it run i + 1's A values and B row starts go to the other half of the LDS staging area.
+    // the rowPtrB words of run i + 1 are requested; the vmcnt(0) of the run's last row covers them (every row has one),
+    // and right behind it -- the last row's arithmetic is done -- run i + 1's A values and B row starts replace run
+    // i's in the LDS staging area.
     struct RunPtrs { int ap, cp, cls; };
     auto load_ptrs = [&](int run) {
         RunPtrs r{0, 0, -1};
@@ -106,14 +107,17 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 
     // class at hand (registers) ...
     int cur = -2, nnz = 0, tail = -1, slab = 0, slots = 1, ahead = 0;
-    unsigned mp[MAXU];
-    int prodStart[MAXU], rel[MAXV];
-    // ... its slab as seen by this lane's share of the kClassMaxJ load instructions: the chain's first A entry, the
+    // per product (lane, step), all LDS BYTE addresses / offsets so that the row loop computes none: the A entry's place in
+    // a row's staged values, the slot of the entry of C (negative: the running sum restarts here -- the address is
+    // ~slot), the place in the ring at a stretch's first row, what a row adds to it (0: no product)
+    int kOff[MAXU], slotB[MAXU], prodStart[MAXU], stepB[MAXU], rel[MAXV];
+    // ... its slab as seen by this lane's share of the MAXJ load instructions: the chain's first A entry, the
     // lane's place in that chain's row (-1: a padding lane), the row's length
-    int dmaKf[kClassMaxJ], dmaO[kClassMaxJ], dmaLen[kClassMaxJ];
+    int dmaKf[MAXJ], dmaO[MAXJ], dmaLen[MAXJ];
     // the ring: where this lane's next piece of a slab comes from, the slot it goes to, every product's place, the last row done
-    long long src[kClassMaxJ];
-    int loadSlot = 0, lastRow = -2, at[MAXU];
+    long long src[MAXJ];
+    int loadSlot = 0, lastRow = -2, wrapB = 0;
+    unsigned at[MAXU];
     bool ringOK = false;
 #if BHS_PHASES_CLS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tPh = __builtin_readcyclecounter();
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
         for (int i = 0; i < SE; ++i) {
             const int bp = aj0[i] >= 0 ? Bp[aj0[i]] : 0;
-            if (i * 64 + lane < nE0) { sAx2[i * 64 + lane] = ax0[i]; sBo2[i * 64 + lane] = bp; }
+            if (i * 64 + lane < nE0) { sAx[i * 64 + lane] = ax0[i]; sBo[i * 64 + lane] = bp; }
         }
     }
     wave_sync();
@@ -146,9 +150,6 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         const int run = run_of(it);
         if (run >= nRuns) break;
         const int row0 = run * kClassRun, nr = rows_of(run);
-        const int half = it & 1;
-        const acc_t* sAx = sAx2 + half * stageCap;
-        const int* sBo = sBo2 + half * stageCap;
         const int base = __builtin_amdgcn_readlane(p0.ap, 0);
         // requests for the runs behind this one (consumed behind this run's first vmcnt(0))
         const RunPtrs p3 = load_ptrs(run_of(it + 3));
@@ -167,23 +168,19 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
             for (int i = 0; i < SE; ++i) bp1[i] = aj1[i] >= 0 ? Bp[aj1[i]] : 0;
         }
-        bool nextStaged = false;
-        auto stage_next = [&]() {                                   // (behind a vmcnt(0): the requests above have arrived)
-            acc_t* dAx = sAx2 + (half ^ 1) * stageCap;
-            int* dBo = sBo2 + (half ^ 1) * stageCap;
+        auto stage_next = [&]() {               // (behind the last row's vmcnt(0): the requests above have arrived, the row is done)
 #pragma unroll
             for (int i = 0; i < SE; ++i) {
-                if (i * 64 + lane < nE1) { dAx[i * 64 + lane] = ax1[i]; dBo[i * 64 + lane] = bp1[i]; }
+                if (i * 64 + lane < nE1) { sAx[i * 64 + lane] = ax1[i]; sBo[i * 64 + lane] = bp1[i]; }
                 aj1[i] = aj2[i];
                 ax1[i] = ax2[i];
             }
-            nextStaged = true;
         };
         // one slab: this lane's 16 bytes of each of its load instructions, if they are a piece of a B row
         auto request_slab = [&]() {
             if (!(BHS_CLS_LAB & 1)) {
 #pragma unroll
-                for (int j = 0; j < kClassMaxJ; ++j) {
+                for (int j = 0; j < MAXJ; ++j) {
                     if (j * 64 * kClassEpl < slab) {
                         if (dmaO[j] >= 0 && src[j] + kClassEpl <= nnzB)
                             __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, 0);
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
                 }
             }
 #pragma unroll
-            for (int j = 0; j < kClassMaxJ; ++j) src[j] += dmaLen[j];
+            for (int j = 0; j < MAXJ; ++j) src[j] += dmaLen[j];
             loadSlot = loadSlot + 1 == slots ? 0 : loadSlot + 1;
         };
         BHS_TICK_CLS(0);
@@ -210,12 +207,10 @@ __global__ __launch_bounds__(64) void k_class_numeric(
                 const int P = __builtin_amdgcn_readfirstlane(ci.y);   // (uniform anyway: tells the compiler so)
                 const int U = (P + 63) >> 6;
                 nnz = __builtin_amdgcn_readfirstlane(ci.z);
+                unsigned mp[MAXU];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) {                     // (the class's U steps are the LAST U of the MAXU)
-                    unsigned d = u >= MAXU - U ? classMap[(size_t)cls * kClassMaxP + (u - (MAXU - U)) * 64 + lane] : kClassIdle;
-                    if ((d >> 16) == kClassDump) d = (d & 0xFFFFu) | (dumpSlot << 16);
-                    mp[u] = d;
-                }
+                for (int u = 0; u < MAXU; ++u)                       // (the class's U steps are the LAST U of the MAXU)
+                    mp[u] = u >= MAXU - U ? classMap[(size_t)cls * kClassMaxP + (u - (MAXU - U)) * 64 + lane] : kClassIdle;
                 tail = classLane[(size_t)cls * kClassLaneInts + lane];
                 const int ent = classLane[(size_t)cls * kClassLaneInts + 64 + lane];     // as A entry
                 const int chn = classLane[(size_t)cls * kClassLaneInts + 128 + lane];    // as chain
@@ -223,20 +218,28 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
                 for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
-                if (!nextStaged) stage_next();
                 const int nCh = geo & 255;
                 ahead = ((geo >> 8) & 255) + 1;                      // slabs a stretch starts with: rows 0 and 1 find theirs
                 slots = ahead + 1;                                   // ... and the ring: one more, for the slab on its way
                 slab = geo >> 16;
                 // every product's place in the ring at the stretch's first row: slot = its A entry's place in the chain
+                const unsigned ringBase = (unsigned)(size_t)ring, accBase = (unsigned)(size_t)acc;   // (low halves of flat LDS addresses)
+                wrapB = slots * slab * (int)sizeof(value_t);
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const int ek = __shfl(ent, (int)(mp[u] & 63u), 64);
-                    prodStart[u] = (mp[u] & kClassIdleBit) ? 0 : ((ek >> 16) & 63) * slab + (ek & 0xFFFF) + (int)((mp[u] >> 6) & 63u);
+                    const unsigned d = mp[u];
+                    const bool idle = (d & kClassIdleBit) != 0;
+                    const int ek = __shfl(ent, (int)(d & 63u), 64);
+                    kOff[u] = (int)(d & 63u) * (int)sizeof(acc_t);
+                    const unsigned slot = (d >> 16) == kClassDump ? dumpSlot : (d >> 16);
+                    const int sb = (int)(accBase + slot * (unsigned)sizeof(acc_t));
+                    slotB[u] = (d & kClassStart) ? ~sb : sb;
+                    stepB[u] = idle ? 0 : slab * (int)sizeof(value_t);
+                    prodStart[u] = (int)ringBase + (idle ? 0 : (((ek >> 16) & 63) * slab + (ek & 0xFFFF) + (int)((d >> 6) & 63u)) * (int)sizeof(value_t));
                 }
                 // this lane's pieces of a slab
 #pragma unroll
-                for (int j = 0; j < kClassMaxJ; ++j) {
+                for (int j = 0; j < MAXJ; ++j) {
                     const int x = (j * 64 + lane) * kClassEpl;
                     int c = 0;
                     for (int cc = 1; cc < nCh; ++cc) c += x >= (__builtin_amdgcn_readlane(chn, cc) >> 20) ? 1 : 0;
@@ -251,47 +254,49 @@ __global__ __launch_bounds__(64) void k_class_numeric(
             }
             if (!ringOK || row != lastRow + 1) {                     // a stretch begins: its first slabs, all at once
 #pragma unroll
-                for (int j = 0; j < kClassMaxJ; ++j) src[j] = (long long)sBo[offT + dmaKf[j]] + max(dmaO[j], 0);
+                for (int j = 0; j < MAXJ; ++j) src[j] = (long long)sBo[offT + dmaKf[j]] + max(dmaO[j], 0);
                 loadSlot = 0;
                 for (int s2 = 0; s2 < ahead; ++s2) request_slab();
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) at[u] = prodStart[u];
+                for (int u = 0; u < MAXU; ++u) at[u] = (unsigned)prodStart[u];
                 ringOK = true;
                 BHS_TICK_CLS(2);
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);
-                if (!nextStaged) stage_next();
                 wave_sync();
                 BHS_TICK_CLS(3);
             }
             // the row's arithmetic: LDS only
             {
+                typedef __attribute__((address_space(3))) const value_t* lds_val;
+                typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
+                typedef __attribute__((address_space(3))) acc_t* lds_acc;
+                const unsigned aBase = (unsigned)(size_t)sAx + (unsigned)offT * (unsigned)sizeof(acc_t);
                 acc_t bv[MAXU], axv[MAXU];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) bv[u] = (acc_t)ring[at[u]];
+                for (int u = 0; u < MAXU; ++u) bv[u] = (acc_t)*(lds_val)(size_t)at[u];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) axv[u] = sAx[offT + (int)(mp[u] & 63u)];
+                for (int u = 0; u < MAXU; ++u) axv[u] = *(lds_acc_c)(size_t)(aBase + (unsigned)kOff[u]);
                 acc_t sum = 0.0;
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const unsigned e = mp[u];
-                    sum = (e & kClassStart) ? 0.0 : sum;
+                    const bool restart = slotB[u] < 0;
+                    sum = restart ? 0.0 : sum;
                     sum = __builtin_fma(axv[u], bv[u], sum);
-                    acc[e >> 16] = sum;
+                    *(lds_acc)(size_t)(unsigned)(restart ? ~slotB[u] : slotB[u]) = sum;
                 }
                 if (tail >= 0) unsafeAtomicAdd(&acc[tail], sum);     // (after every plain store of the row: in order)
                 // every product moves on by one slab, around the ring
-                const int wrap = slots * slab;
+                const unsigned ringEnd = ringBaseOf(ring) + (unsigned)wrapB;
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const unsigned nx = (unsigned)(at[u] + ((mp[u] & kClassIdleBit) ? 0 : slab));
-                    at[u] = (int)min(nx, nx - (unsigned)wrap);
+                    const unsigned nx = at[u] + (unsigned)stepB[u];
+                    at[u] = nx >= ringEnd ? nx - (unsigned)wrapB : nx;
                 }
             }
             wave_sync();
             BHS_TICK_CLS(4);
             // whatever is in flight was requested a row ago: the slab the next row needs first, the row before's stores
             __builtin_amdgcn_s_waitcnt(kWaitVm0);
-            if (!nextStaged) stage_next();
             request_slab();
             const int out = __builtin_amdgcn_readlane(p0.cp, t);
             if (!(BHS_CLS_LAB & 2)) {
@@ -311,7 +316,9 @@ __global__ __launch_bounds__(64) void k_class_numeric(
             ph[7] += 1;
 #endif
         }
-        if (!nextStaged) { __builtin_amdgcn_s_waitcnt(kWaitVm0); stage_next(); }
+        // (the last row's vmcnt(0) came after this run's requests were issued, or there was no row: wait here)
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);
+        stage_next();
         wave_sync();
         p0 = p1; p1 = p2; p2 = p3;
     }

@@ -219,7 +219,7 @@ struct bhs_handle {
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
         bool useClass = false;            // numeric half: k_class_numeric
-        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0;
+        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0, classMaxSlab = 0;
         int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
@@ -466,15 +466,14 @@ int launch_class_numeric_atomic(bhs_handle* h, int r0, int r1)
 
 
 // Numeric pass by row classes on the rows [r0, r1): the ring kernel (bhs_class_wg.hip.h)
-template <int MAXU, int MAXV>
-int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
+template <int MAXU, int MAXV, int SE, int MAXJ>
+int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
 {
-    auto kern = k_class_numeric<MAXU, MAXV>;
+    auto kern = k_class_numeric<MAXU, MAXV, SE, MAXJ>;
     const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
     const int stageCap = (kClassRun * h->ps.classMaxNA + 63) & ~63; // a run's A entries
     const int ringCap = (h->ps.classMaxRing + 63) & ~63;            // (longest chain + 2) slabs of the neediest class
-    const size_t smem = (size_t)(accStride + 2 * stageCap) * sizeof(acc_t) + (size_t)ringCap * sizeof(value_t) +
-                        (size_t)(2 * stageCap) * sizeof(int);
+    const size_t smem = (size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)ringCap * sizeof(value_t) + (size_t)stageCap * sizeof(int);
     int perCU = 1;
     BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
     perCU = std::max(1, std::min(perCU, 32));
@@ -491,12 +490,21 @@ int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
     return BHS_SUCCESS;
 }
 
+template <int MAXU, int MAXV>
+int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
+{
+    const int passes = (kClassRun * h->ps.classMaxNA + 63) / 64;   // 64-entry passes that stage the A entries of a run
+    const bool smallSlab = h->ps.classMaxSlab <= 2 * 64 * kClassEpl;
+    if (passes <= 4) return smallSlab ? launch_class_numeric_impl<MAXU, MAXV, 4, 2>(h, r0, r1) : launch_class_numeric_impl<MAXU, MAXV, 4, kClassMaxJ>(h, r0, r1);
+    return smallSlab ? launch_class_numeric_impl<MAXU, MAXV, kClassRun, 2>(h, r0, r1) : launch_class_numeric_impl<MAXU, MAXV, kClassRun, kClassMaxJ>(h, r0, r1);
+}
+
 // (false: some class's slab or ring is beyond what the ring kernel keeps in LDS -- the caller takes the atomic kernel)
 bool class_ring_fits(bhs_handle* h)
 {
     if (h->ps.classMaxRing < 0 || h->ps.classMaxRing == 0x7fffffff) return false;
     const size_t accStride = (size_t)((h->ps.classMaxNnz + 1 + 63) & ~63), stageCap = (size_t)((kClassRun * h->ps.classMaxNA + 63) & ~63);
-    const size_t smem = (accStride + 2 * stageCap) * sizeof(acc_t) + (size_t)((h->ps.classMaxRing + 63) & ~63) * sizeof(value_t) + 2 * stageCap * sizeof(int);
+    const size_t smem = (accStride + stageCap) * sizeof(acc_t) + (size_t)((h->ps.classMaxRing + 63) & ~63) * sizeof(value_t) + stageCap * sizeof(int);
     return smem <= 40 * 1024;
 }
 
@@ -1306,7 +1314,8 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxNA = cs[CS_MAXNA];
         h->ps.classMaxLB = cs[CS_MAXLB];
         h->ps.classMaxRing = cs[CS_MAXRING];
-        if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; %d table probes]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[7]);
+        h->ps.classMaxSlab = cs[CS_MAXSLAB];
+        if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; slabs of <= %d values]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[CS_MAXSLAB]);
     } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
         for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
