@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         classLane[(size_t)s * kClassLaneInts + 128 + tid] = tid < nCh ? (kf | (len << 6) | (lc << 13) | (place << 20)) : 0;
         if (tid == 0) {
             classLane[(size_t)s * kClassLaneInts + 192] = nCh | (maxLen << 8) | (slab << 16);
-            // the ring of the workgroup kernel: (entries of the longest chain + 2) slabs; 4 x 64 lanes x 16 bytes per slab at most
-            atomicMax(&stats[CS_MAXRING], slab <= 4 * 64 * kClassEpl ? (maxLen + 2) * slab : 0x7fffffff);
+            // the ring of the ring kernel: (entries of the longest chain + 1) slabs; 4 x 64 lanes x 16 bytes per slab at most
+            atomicMax(&stats[CS_MAXRING], slab <= 4 * 64 * kClassEpl ? (maxLen + 1) * slab : 0x7fffffff);
             atomicMax(&stats[CS_MAXSLAB], slab);
         }
         int mx = myLen;

@@ -13,11 +13,11 @@ namespace bhs {
 //   the ring     rows i, i + 1, .. of ONE class: entry k of row i + 1 selects the B row after the one entry k of row i
 //                selects.  So for a CHAIN of A entries with consecutive columns (and B rows of one length) the B rows
 //                that row i + 1 needs are those of row i shifted by one: one NEW B row per chain and row.  A "slab" is
-//                that new row of every chain, side by side; the wave keeps the last (longest chain + 2) slabs in a ring
+//                that new row of every chain, side by side; the wave keeps the last (longest chain + 1) slabs in a ring
 //                in LDS and brings in one slab per row with global_load_lds_dwordx4 (two instructions for poisson27pt's
 //                9 x 27 values), two rows ahead of the row that needs it first.  Every value of B enters the CU once
 //                per wave and stretch (1.9 KB per row of C; round 2's kernel gathers 5.8 KB per row through an L1 that
-//                20 waves overrun, and its CU is bound by the L2 requests in flight), at 10 KB of LDS per wave;
+//                20 waves overrun, and its CU is bound by the L2 requests in flight), at 8 KB of LDS per wave;
 //   per row      every lane holds MAXU product descriptors of the class in registers (k_class_patterns: consecutive
 //                products of the position-sorted list): per product one LDS read of B's value in the ring (its place
 //                moves on by one slab per row), one of A's value and one fused multiply-add into ONE register -- the
@@ -110,12 +110,13 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     // per product (lane, step), all LDS BYTE addresses / offsets so that the row loop computes none: the A entry's place in
     // a row's staged values, the slot of the entry of C (negative: the running sum restarts here -- the address is
     // ~slot), the place in the ring at a stretch's first row, what a row adds to it (0: no product)
-    int kOff[MAXU], slotB[MAXU], prodStart[MAXU], stepB[MAXU], rel[MAXV];
+    int kOff[MAXU], slotB[MAXU], stepB[MAXU], rel[MAXV];
+    int ent = 0, chn = 0;                                        // the class's chain tables: this lane as A entry / as chain (k_class_patterns)
     // ... its slab as seen by this lane's share of the MAXJ load instructions: the chain's first A entry, the
     // lane's place in that chain's row (-1: a padding lane), the row's length
-    int dmaKf[MAXJ], dmaO[MAXJ], dmaLen[MAXJ];
+    int dma[MAXJ];                                               // place in the chain's row (bits 0-7), row length (8-15, 0: padding lane), chain (16-21)
     // the ring: where this lane's next piece of a slab comes from, the slot it goes to, every product's place, the last row done
-    long long src[MAXJ];
+    unsigned src[MAXJ];                                          // (values of B are counted in int32: nnzB < 2^31)
     int loadSlot = 0, lastRow = -2, wrapB = 0;
     unsigned at[MAXU];
     bool ringOK = false;
@@ -182,16 +183,17 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) {
                     if (j * 64 * kClassEpl < slab) {
-                        if (dmaO[j] >= 0 && src[j] + kClassEpl <= nnzB)
+                        const bool piece = (dma[j] & 0xFF00) != 0;
+                        if (piece && (long long)src[j] + kClassEpl <= nnzB)
                             __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, 0);
-                        else if (dmaO[j] >= 0)                       // (the last few values of valB: no 16-byte load past its end)
+                        else if (piece)                              // (the last few values of valB: no 16-byte load past its end)
                             for (int e2 = 0; e2 < kClassEpl; ++e2)
-                                if (src[j] + e2 < nnzB) ring[loadSlot * slab + (j * 64 + lane) * kClassEpl + e2] = Bx[src[j] + e2];
+                                if ((long long)src[j] + e2 < nnzB) ring[loadSlot * slab + (j * 64 + lane) * kClassEpl + e2] = Bx[src[j] + e2];
                     }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) src[j] += dmaLen[j];
+            for (int j = 0; j < MAXJ; ++j) src[j] += (unsigned)((dma[j] >> 8) & 255);
             loadSlot = loadSlot + 1 == slots ? 0 : loadSlot + 1;
         };
         BHS_TICK_CLS(0);
@@ -212,30 +214,29 @@ __global__ __launch_bounds__(64) void k_class_numeric(
                 for (int u = 0; u < MAXU; ++u)                       // (the class's U steps are the LAST U of the MAXU)
                     mp[u] = u >= MAXU - U ? classMap[(size_t)cls * kClassMaxP + (u - (MAXU - U)) * 64 + lane] : kClassIdle;
                 tail = classLane[(size_t)cls * kClassLaneInts + lane];
-                const int ent = classLane[(size_t)cls * kClassLaneInts + 64 + lane];     // as A entry
-                const int chn = classLane[(size_t)cls * kClassLaneInts + 128 + lane];    // as chain
+                ent = classLane[(size_t)cls * kClassLaneInts + 64 + lane];     // as A entry
+                chn = classLane[(size_t)cls * kClassLaneInts + 128 + lane];    // as chain
                 const int geo = __builtin_amdgcn_readfirstlane(classLane[(size_t)cls * kClassLaneInts + 192]);
 #pragma unroll
                 for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
                 const int nCh = geo & 255;
                 ahead = ((geo >> 8) & 255) + 1;                      // slabs a stretch starts with: rows 0 and 1 find theirs
-                slots = ahead + 1;                                   // ... and the ring: one more, for the slab on its way
+                slots = ahead;                                       // ... and the ring: a row's request replaces the slab only that row still needed
                 slab = geo >> 16;
                 // every product's place in the ring at the stretch's first row: slot = its A entry's place in the chain
-                const unsigned ringBase = (unsigned)(size_t)ring, accBase = (unsigned)(size_t)acc;   // (low halves of flat LDS addresses)
+                const unsigned accBase = (unsigned)(size_t)acc;      // (low half of a flat LDS address = the LDS byte address)
                 wrapB = slots * slab * (int)sizeof(value_t);
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
                     const unsigned d = mp[u];
                     const bool idle = (d & kClassIdleBit) != 0;
-                    const int ek = __shfl(ent, (int)(d & 63u), 64);
-                    kOff[u] = (int)(d & 63u) * (int)sizeof(acc_t);
+                    // (bits 0-8: the A entry's place in a row's staged values, in bytes; bits 16-21: the B entry)
+                    kOff[u] = (int)(d & 63u) * (int)sizeof(acc_t) | (int)(((d >> 6) & 63u) << 16);
                     const unsigned slot = (d >> 16) == kClassDump ? dumpSlot : (d >> 16);
                     const int sb = (int)(accBase + slot * (unsigned)sizeof(acc_t));
                     slotB[u] = (d & kClassStart) ? ~sb : sb;
                     stepB[u] = idle ? 0 : slab * (int)sizeof(value_t);
-                    prodStart[u] = (int)ringBase + (idle ? 0 : (((ek >> 16) & 63) * slab + (ek & 0xFFFF) + (int)((d >> 6) & 63u)) * (int)sizeof(value_t));
                 }
                 // this lane's pieces of a slab
 #pragma unroll
@@ -246,19 +247,21 @@ __global__ __launch_bounds__(64) void k_class_numeric(
                     const int mine = __shfl(chn, c, 64);
                     const int o = x - (mine >> 20), len = (mine >> 13) & 127;
                     const bool piece = x < slab && o < len;
-                    dmaKf[j] = mine & 63;
-                    dmaO[j] = piece ? o : -1;
-                    dmaLen[j] = piece ? len : 0;
+                    dma[j] = piece ? (o | (len << 8) | (c << 16)) : (c << 16);
                 }
                 BHS_TICK_CLS(1);
             }
             if (!ringOK || row != lastRow + 1) {                     // a stretch begins: its first slabs, all at once
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j) src[j] = (long long)sBo[offT + dmaKf[j]] + max(dmaO[j], 0);
+                for (int j = 0; j < MAXJ; ++j) src[j] = (unsigned)(sBo[offT + (__shfl(chn, dma[j] >> 16, 64) & 63)] + (dma[j] & 255));
                 loadSlot = 0;
                 for (int s2 = 0; s2 < ahead; ++s2) request_slab();
+                // every product's place in the ring at the stretch's first row: the slot = its A entry's place in its chain
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) at[u] = (unsigned)prodStart[u];
+                for (int u = 0; u < MAXU; ++u) {
+                    const int ek = __shfl(ent, (kOff[u] & 0x1FF) / (int)sizeof(acc_t), 64);
+                    at[u] = ringBaseOf(ring) + (stepB[u] ? (unsigned)((((ek >> 16) & 63) * slab + (ek & 0xFFFF) + (kOff[u] >> 16)) * (int)sizeof(value_t)) : 0u);
+                }
                 ringOK = true;
                 BHS_TICK_CLS(2);
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) bv[u] = (acc_t)*(lds_val)(size_t)at[u];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) axv[u] = *(lds_acc_c)(size_t)(aBase + (unsigned)kOff[u]);
+                for (int u = 0; u < MAXU; ++u) axv[u] = *(lds_acc_c)(size_t)(aBase + (unsigned)(kOff[u] & 0x1FF));
                 acc_t sum = 0.0;
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {

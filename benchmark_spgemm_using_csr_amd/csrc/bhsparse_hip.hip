@@ -472,7 +472,7 @@ int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
     auto kern = k_class_numeric<MAXU, MAXV, SE, MAXJ>;
     const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
     const int stageCap = (kClassRun * h->ps.classMaxNA + 63) & ~63; // a run's A entries
-    const int ringCap = (h->ps.classMaxRing + 63) & ~63;            // (longest chain + 2) slabs of the neediest class
+    const int ringCap = (h->ps.classMaxRing + 63) & ~63;            // (longest chain + 1) slabs of the neediest class
     const size_t smem = (size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)ringCap * sizeof(value_t) + (size_t)stageCap * sizeof(int);
     int perCU = 1;
     BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
@@ -482,6 +482,7 @@ int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
     const long long nSuper = ((long long)mR + kClassSuper - 1) / kClassSuper;
     long long grid = std::min<long long>(nSuper, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    if (h->verbose > 1) printf("  [class numeric (ring): %d waves per CU by the occupancy API, %d used, %zu bytes of LDS each, grid %lld]\n", perCU, useCU, smem, grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
                        (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
