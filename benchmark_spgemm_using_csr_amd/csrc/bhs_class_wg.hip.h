@@ -66,11 +66,10 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     const int lane = threadIdx.x;
-    // acc[accStride] + sAx[stageCap] doubles, ring[ringCap] values (16-byte aligned), sBo[stageCap] ints
+    // acc[accStride] + sAx[stageCap] doubles, ring[ringCap] values (all 16-byte aligned: the three counts are even)
     acc_t* acc = reinterpret_cast<acc_t*>(smemRaw);
     acc_t* sAx = acc + accStride;                                // A values of the run at hand
     value_t* ring = reinterpret_cast<value_t*>(sAx + stageCap);
-    int* sBo = reinterpret_cast<int*>(ring + ringCap);           // B row start of every staged A entry
     const unsigned dumpSlot = (unsigned)(accStride - 1);         // never read: idle lanes and partial sums that travel by the tail add
 
     // super-runs: XCD x takes [x * perX, (x + 1) * perX); block b runs on XCD b % 8
@@ -106,11 +105,12 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     auto entries_of = [&](const RunPtrs& r, int nr) { return min(__builtin_amdgcn_readlane(r.ap, nr) - __builtin_amdgcn_readlane(r.ap, 0), stageCap); };
 
     // class at hand (registers) ...
-    int cur = -2, nnz = 0, tail = -1, slab = 0, slots = 1, ahead = 0;
-    // per product (lane, step), all LDS BYTE addresses / offsets so that the row loop computes none: the A entry's place in
-    // a row's staged values, the slot of the entry of C (negative: the running sum restarts here -- the address is
-    // ~slot), the place in the ring at a stretch's first row, what a row adds to it (0: no product)
-    int kOff[MAXU], slotB[MAXU], stepB[MAXU], rel[MAXV];
+    int cur = -2, nnz = 0, tail = -1, slab = 0, slots = 1;
+    // per product (lane, step) ONE word, LDS byte addresses / offsets so that the row loop computes none: the slot of the entry
+    // of C (bits 0-15), the A entry's place in a row's staged values (16-24), the B entry (25-30; read where a stretch
+    // begins), and the sign bit: the running sum restarts here.  A step without a product reads A's and the ring's first
+    // value and stores to the dump slot; the product behind it restarts the sum.
+    int desc[MAXU], rel[MAXV];
     int ent = 0, chn = 0;                                        // the class's chain tables: this lane as A entry / as chain (k_class_patterns)
     // ... its slab as seen by this lane's share of the MAXJ load instructions: the chain's first A entry, the
     // lane's place in that chain's row (-1: a padding lane), the row's length
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #endif
     // prologue: run 0 staged in half 0, run 1's A entries and run 2's pointers in registers
     RunPtrs p0 = load_ptrs(run_of(0)), p1 = load_ptrs(run_of(1)), p2 = load_ptrs(run_of(2));
-    int aj1[SE];
+    int aj1[SE], bp0[SE];                                        // (bp0: B row start of every A entry of the run at hand)
     acc_t ax1[SE];
     {
         const int nr0 = rows_of(run_of(0)), nr1 = rows_of(run_of(1));
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         }
 #pragma unroll
         for (int i = 0; i < SE; ++i) {
-            const int bp = aj0[i] >= 0 ? Bp[aj0[i]] : 0;
-            if (i * 64 + lane < nE0) { sAx[i * 64 + lane] = ax0[i]; sBo[i * 64 + lane] = bp; }
+            bp0[i] = aj0[i] >= 0 ? Bp[aj0[i]] : 0;
+            if (i * 64 + lane < nE0) sAx[i * 64 + lane] = ax0[i];
         }
     }
     wave_sync();
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         auto stage_next = [&]() {               // (behind the last row's vmcnt(0): the requests above have arrived, the row is done)
 #pragma unroll
             for (int i = 0; i < SE; ++i) {
-                if (i * 64 + lane < nE1) { sAx[i * 64 + lane] = ax1[i]; sBo[i * 64 + lane] = bp1[i]; }
+                if (i * 64 + lane < nE1) sAx[i * 64 + lane] = ax1[i];
+                bp0[i] = bp1[i];
                 aj1[i] = aj2[i];
                 ax1[i] = ax2[i];
             }
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(64) void k_class_numeric(
                 for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
                 const int nCh = geo & 255;
-                ahead = ((geo >> 8) & 255) + 1;                      // slabs a stretch starts with: rows 0 and 1 find theirs
-                slots = ahead;                                       // ... and the ring: a row's request replaces the slab only that row still needed
+                slots = ((geo >> 8) & 255) + 1;                      // slabs a stretch starts with (rows 0 and 1 find theirs) = slots of
+                                                                     // the ring: a row's request replaces the slab only that row still needed
                 slab = geo >> 16;
                 // every product's place in the ring at the stretch's first row: slot = its A entry's place in the chain
                 const unsigned accBase = (unsigned)(size_t)acc;      // (low half of a flat LDS address = the LDS byte address)
@@ -230,13 +231,9 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
                     const unsigned d = mp[u];
-                    const bool idle = (d & kClassIdleBit) != 0;
-                    // (bits 0-8: the A entry's place in a row's staged values, in bytes; bits 16-21: the B entry)
-                    kOff[u] = (int)(d & 63u) * (int)sizeof(acc_t) | (int)(((d >> 6) & 63u) << 16);
                     const unsigned slot = (d >> 16) == kClassDump ? dumpSlot : (d >> 16);
-                    const int sb = (int)(accBase + slot * (unsigned)sizeof(acc_t));
-                    slotB[u] = (d & kClassStart) ? ~sb : sb;
-                    stepB[u] = idle ? 0 : slab * (int)sizeof(value_t);
+                    desc[u] = (int)((accBase + slot * (unsigned)sizeof(acc_t)) | ((d & 63u) * (unsigned)sizeof(acc_t)) << 16 |
+                                    ((d >> 6) & 63u) << 25 | ((d & kClassStart) ? 0x80000000u : 0u));
                 }
                 // this lane's pieces of a slab
 #pragma unroll
@@ -253,14 +250,23 @@ __global__ __launch_bounds__(64) void k_class_numeric(
             }
             if (!ringOK || row != lastRow + 1) {                     // a stretch begins: its first slabs, all at once
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j) src[j] = (unsigned)(sBo[offT + (__shfl(chn, dma[j] >> 16, 64) & 63)] + (dma[j] & 255));
+                for (int j = 0; j < MAXJ; ++j) {                     // the B row of the chain's first A entry, from its holder's register
+                    const int idx = offT + (__shfl(chn, dma[j] >> 16, 64) & 63);
+                    int bo = 0;
+#pragma unroll
+                    for (int i = 0; i < SE; ++i) {
+                        const int got = __shfl(bp0[i], idx & 63, 64);
+                        bo = (idx >> 6) == i ? got : bo;
+                    }
+                    src[j] = (unsigned)(bo + (dma[j] & 255));
+                }
                 loadSlot = 0;
-                for (int s2 = 0; s2 < ahead; ++s2) request_slab();
+                for (int s2 = 0; s2 < slots; ++s2) request_slab();
                 // every product's place in the ring at the stretch's first row: the slot = its A entry's place in its chain
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const int ek = __shfl(ent, (kOff[u] & 0x1FF) / (int)sizeof(acc_t), 64);
-                    at[u] = ringBaseOf(ring) + (stepB[u] ? (unsigned)((((ek >> 16) & 63) * slab + (ek & 0xFFFF) + (kOff[u] >> 16)) * (int)sizeof(value_t)) : 0u);
+                    const int ek = __shfl(ent, ((desc[u] >> 16) & 0x1FF) / (int)sizeof(acc_t), 64);
+                    at[u] = ringBaseOf(ring) + (unsigned)((((ek >> 16) & 63) * slab + (ek & 0xFFFF) + ((desc[u] >> 25) & 63)) * (int)sizeof(value_t));
                 }
                 ringOK = true;
                 BHS_TICK_CLS(2);
@@ -278,21 +284,20 @@ __global__ __launch_bounds__(64) void k_class_numeric(
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) bv[u] = (acc_t)*(lds_val)(size_t)at[u];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) axv[u] = *(lds_acc_c)(size_t)(aBase + (unsigned)(kOff[u] & 0x1FF));
+                for (int u = 0; u < MAXU; ++u) axv[u] = *(lds_acc_c)(size_t)(aBase + (((unsigned)desc[u] >> 16) & 0x1FFu));
                 acc_t sum = 0.0;
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const bool restart = slotB[u] < 0;
-                    sum = restart ? 0.0 : sum;
+                    sum = desc[u] < 0 ? 0.0 : sum;
                     sum = __builtin_fma(axv[u], bv[u], sum);
-                    *(lds_acc)(size_t)(unsigned)(restart ? ~slotB[u] : slotB[u]) = sum;
+                    *(lds_acc)(size_t)((unsigned)desc[u] & 0xFFFFu) = sum;
                 }
                 if (tail >= 0) unsafeAtomicAdd(&acc[tail], sum);     // (after every plain store of the row: in order)
                 // every product moves on by one slab, around the ring
-                const unsigned ringEnd = ringBaseOf(ring) + (unsigned)wrapB;
+                const unsigned ringEnd = ringBaseOf(ring) + (unsigned)wrapB, stepB = (unsigned)slab * (unsigned)sizeof(value_t);
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
-                    const unsigned nx = at[u] + (unsigned)stepB[u];
+                    const unsigned nx = at[u] + stepB;
                     at[u] = nx >= ringEnd ? nx - (unsigned)wrapB : nx;
                 }
             }

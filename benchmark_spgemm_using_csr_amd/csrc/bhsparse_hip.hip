@@ -465,15 +465,27 @@ int launch_class_numeric_atomic(bhs_handle* h, int r0, int r1)
 }
 
 
+// LDS of a wave of the ring kernel: slots of a row of C (one spare for idle lanes), a run's A values, (longest chain + 1)
+// slabs of the neediest class; all in multiples of 16 bytes
+struct RingLds { int accStride, stageCap, ringCap; size_t bytes; };
+RingLds class_ring_lds(bhs_handle* h)
+{
+    RingLds l;
+    l.accStride = (h->ps.classMaxNnz + 1 + 3) & ~3;
+    l.stageCap = (kClassRun * h->ps.classMaxNA + 3) & ~3;
+    l.ringCap = (int)(((long long)h->ps.classMaxRing + 3) & ~3ll);
+    l.bytes = (size_t)(l.accStride + l.stageCap) * sizeof(acc_t) + (size_t)l.ringCap * sizeof(value_t);
+    return l;
+}
+
 // Numeric pass by row classes on the rows [r0, r1): the ring kernel (bhs_class_wg.hip.h)
 template <int MAXU, int MAXV, int SE, int MAXJ>
 int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
 {
     auto kern = k_class_numeric<MAXU, MAXV, SE, MAXJ>;
-    const int accStride = (h->ps.classMaxNnz + 1 + 63) & ~63;      // (one spare slot for idle lanes)
-    const int stageCap = (kClassRun * h->ps.classMaxNA + 63) & ~63; // a run's A entries
-    const int ringCap = (h->ps.classMaxRing + 63) & ~63;            // (longest chain + 1) slabs of the neediest class
-    const size_t smem = (size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)ringCap * sizeof(value_t) + (size_t)stageCap * sizeof(int);
+    const RingLds lds = class_ring_lds(h);
+    const int accStride = lds.accStride, stageCap = lds.stageCap, ringCap = lds.ringCap;
+    const size_t smem = lds.bytes;
     int perCU = 1;
     BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
     perCU = std::max(1, std::min(perCU, 32));
@@ -504,9 +516,7 @@ int launch_class_numeric_uv(bhs_handle* h, int r0, int r1)
 bool class_ring_fits(bhs_handle* h)
 {
     if (h->ps.classMaxRing < 0 || h->ps.classMaxRing == 0x7fffffff) return false;
-    const size_t accStride = (size_t)((h->ps.classMaxNnz + 1 + 63) & ~63), stageCap = (size_t)((kClassRun * h->ps.classMaxNA + 63) & ~63);
-    const size_t smem = (accStride + stageCap) * sizeof(acc_t) + (size_t)((h->ps.classMaxRing + 63) & ~63) * sizeof(value_t) + stageCap * sizeof(int);
-    return smem <= 40 * 1024;
+    return class_ring_lds(h).bytes <= 40 * 1024;
 }
 
 int launch_class_numeric(bhs_handle* h, int r0, int r1)
