@@ -143,7 +143,7 @@ struct bhs_handle {
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 256;   // tuning hooks of k_class_rows
     int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
-    int classNumeric = 0;                // numeric kernel of the class path: 0 k_class_numeric_atomic (round 2), 1 k_class_numeric (bhs_class_wg.hip.h)
+    int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
     DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt;
