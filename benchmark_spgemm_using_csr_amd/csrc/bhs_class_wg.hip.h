@@ -305,6 +305,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
             BHS_TICK_CLS(4);
             // whatever is in flight was requested a row ago: the slab the next row needs first, the row before's stores
             __builtin_amdgcn_s_waitcnt(kWaitVm0);
+            BHS_TICK_CLS(6);
             request_slab();
             const int out = __builtin_amdgcn_readlane(p0.cp, t);
             if (!(BHS_CLS_LAB & 2)) {

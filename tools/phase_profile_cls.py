@@ -22,8 +22,8 @@ raw.bhs_debug_phases(buf)
 assert bh.spgemm() == 0
 raw.bhs_debug_phases(buf)
 rows = buf[7]
-names = ["run: row ptrs, A entries, rowPtrB -> LDS", "class data (on a change)", "chains, rebasing, LDS-direct loads issued",
-         "wait for the staged B values", "row: LDS reads back", "row: fma + stores to slots", "row: write-out"]
+names = ["run: requests for the runs behind", "class data (on a change)", "stretch start: first slabs requested",
+         "stretch start: wait for them", "row: arithmetic (LDS only)", "row: slab request + write-out", "row: vmcnt wait"]
 tot = sum(buf[i] for i in range(7))
 print("rows", rows, "wave cycles per row: %.0f" % (tot / rows))
 for i, n in enumerate(names): print("  %-44s %8.0f cycles/row  %5.1f %%" % (n, buf[i] / rows, 100.0 * buf[i] / tot))
