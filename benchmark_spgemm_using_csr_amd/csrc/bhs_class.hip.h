@@ -33,8 +33,11 @@ namespace bhs {
 constexpr int kClassEpl = 16 / (int)sizeof(value_t);   // values of B per lane of a 16-byte LDS-direct load
 constexpr int kClassSlots = 4096;          // slots of each hash table; a class id is a slot number
 constexpr int kClassProbe = 32;            // linear probes before a row counts as unclassified
-constexpr int kClassMaxRow = 64;           // entries per row of A / of B
-constexpr int kClassMaxP = 1024;           // products per row of C
+constexpr int kClassMaxRow = 64;           // entries per row of A / of B  } classes within these limits get the tables of
+constexpr int kClassMaxP = 1024;           // products per row of C        } the register kernels (k_class_patterns)
+constexpr int kClassMaxRowBig = 256;       // the same limits of the "big" classes (bhs_class_big.hip.h: block-structured
+constexpr int kClassBigMaxP = 8192;        //   grids -- several unknowns per node): their product lists stay in memory
+constexpr int kClassBigCap = 1024;         // big classes per multiply
 constexpr int kClassMaxNnz = 512;          // entries per row of C
 constexpr unsigned long long kClassEmpty = ~0ull;
 
@@ -44,7 +47,8 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_MAXSLAB = 7 /* most values per slab */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
-       CS_INTS = 8 + 2 * kClassSumSlots + 2 };
+       CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3,
+       CS_INTS = 8 + 2 * kClassSumSlots + 4 };
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 {
@@ -98,19 +102,20 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
                                                     const int* __restrict__ rowCount,  //   blockIdx.y of kClassHeadSegs lists (k_class_heads),
                                                     int segCap)                        //   segCap slots apart, its length at rowCount[16 * segment]
 {
-    static_assert(G * E <= kClassMaxRow, "the block's class cache holds kClassMaxRow entries per pattern");
+    static_assert(G * E <= kClassMaxRowBig, "rows of up to kClassMaxRowBig entries");
+    constexpr int PW = G * E > kClassMaxRow ? G * E : kClassMaxRow;   // entries per pattern of the block's class cache
     constexpr int RPB = kClassRowsBlock / G;                       // rows per block and pass
     // Block-local cache of the table, indexed by the hash: {slot, 20 bits of the hash} and the class's pattern (the
     // relative columns, for A rows also the B classes) -- a row whose class is here is recognised without touching
     // the representative row in memory.  The blocks are persistent and a stretch of rows has few classes; the
     // device-wide table (coherent loads, compare-and-swap) is for the misses.  An entry is claimed once (LDS
     // compare-and-swap to "busy"), filled, then published; it never changes afterwards.
-    constexpr int NC = 32;
+    constexpr int NC = PW > 2 * kClassMaxRow ? 16 : 32;
     constexpr unsigned kBusy = 0xFFFFFFFEu;
     __shared__ unsigned ctag[NC];
-    __shared__ int cpat[NC][kClassMaxRow];
+    __shared__ int cpat[NC][PW];
     __shared__ int clen[NC];
-    __shared__ int cpatB[IS_A ? NC : 1][kClassMaxRow];
+    __shared__ int cpatB[IS_A ? NC : 1][PW];
     const int tid = threadIdx.x, lane = tid & 63, g = tid % G;
     if (tid < NC) ctag[tid] = 0xFFFFFFFFu;
     __syncthreads();
@@ -286,6 +291,9 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 // ---------------------------------------------------------------------------
 // Rows that look like the row before them.  On a matrix assembled on a grid a row is, almost always, its predecessor
 // shifted by one column -- the same relative pattern (and, for rows of A, the same classes of B rows behind it).
+// (With several unknowns per node it is the row `period` rows back that a row repeats -- period = unknowns per node, a
+// hint sampled by k_row_period when the data set is handed over: the rows are then walked in `period` interleaved
+// sequences, and everything below reads "the row before" as "the row before in its sequence".)
 // Such a row needs no hash and no table: it has its predecessor's class.  k_class_heads streams the rows once (every
 // lane group takes R CONSECUTIVE rows, so a row's predecessor is in the same lanes' registers, or one group to the
 // left; a wave takes one contiguous piece of kClassHeadPiece rows), compares, lists the rows that differ ("heads":
@@ -294,6 +302,29 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 // entry by entry, like the table's.  The heads go to kClassHeadSegs lists, a block's with one atomic (a single
 // counter bumped once per wave queues for most of a millisecond).
 // ---------------------------------------------------------------------------
+// The period hint: eight rows spread over the matrix, each compared with the rows 1 .. 8 before it; the smallest
+// distance at which a sample repeats, by majority (1 when there is none).  One wave, at hand-over time.
+__global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out)
+{
+    const int lane = threadIdx.x, smp = lane >> 3, d = (lane & 7) + 1;
+    const long long row = (long long)(smp + 1) * nrows / 9;
+    bool same = row - d >= 0 && row < nrows;
+    if (same) {
+        const int a0 = Rp[row], len = Rp[row + 1] - a0, b0 = Rp[row - d];
+        same = Rp[row - d + 1] - b0 == len && len > 0;
+        for (int e = 0; same && e < len; ++e) same = Rj[a0 + e] - (int)row == Rj[b0 + e] - (int)(row - d);
+    }
+    const unsigned long long votes = __ballot(same);
+    int count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < 8; ++q) {
+        const unsigned byte = (unsigned)(votes >> (8 * q)) & 255u;
+        if (byte) count[__ffs((int)byte)]++;                       // (the sample's smallest distance)
+    }
+    int best = 1;
+    for (int q = 2; q <= 8; ++q) if (count[q] > count[best]) best = q;
+    if (lane == 0) *out = count[best] >= 4 ? best : 1;
+}
+
 constexpr int kClassHeadSegs = 8;
 constexpr int kClassHeadsBlock = 1024;
 constexpr int kClassHeadPiece = 256;                               // rows per wave: its first is a head by decree
@@ -301,7 +332,8 @@ template <bool IS_A, int G, int E>
 __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                      const int* __restrict__ classB, int* __restrict__ classOut,
                                                      int* __restrict__ headList, int* __restrict__ headCount, int segCap,
-                                                     const int* __restrict__ range)     // rows [range[0], range[1]] only (nullptr: all)
+                                                     const int* __restrict__ range,     // rows [range[0], range[1]] only (nullptr: all)
+                                                     int period)                        // a row is compared with the row `period` before it
 {
     constexpr int GPW = 64 / G;                                    // lane groups per wave
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);               // consecutive rows per lane group
@@ -325,15 +357,22 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
     int lenP = 0, elP[E], cbP[E], followP = -1;
 #pragma unroll
     for (int e = 0; e < E; ++e) { elP[e] = 0; cbP[e] = 0; }
-    for (long long base = pieceBegin; base < pieceEnd; base += RPW) {
-        const bool firstPass = base == pieceBegin;
+    // the wave walks its piece as `period` sequences, one after the other: position q of sequence `seq` = row pieceBegin + q * period + seq
+    const int perSeq = (kClassHeadPiece + period - 1) / period;
+    for (int seq = 0; seq < period; ++seq) {
+    auto row_at = [&](int q) { return pieceBegin + (long long)q * period + seq; };
+    followP = -1;
+    for (int qbase = 0; qbase < perSeq && row_at(qbase) < pieceEnd; qbase += RPW) {
+        const bool firstPass = qbase == 0;                         // (of this sequence: its first row is a head by decree)
         long long rowv[R];
+        int vi[R];
         bool live[R], ok[R];
         int a0[R], len[R], el[R][E], cb[R][E], cc[R][E];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            rowv[r] = base + (long long)grp * R + r;
-            live[r] = rowv[r] < pieceEnd;
+            vi[r] = qbase + grp * R + r;
+            rowv[r] = row_at(vi[r]);
+            live[r] = vi[r] < perSeq && rowv[r] < pieceEnd;
             const long long rr = live[r] ? rowv[r] : 0;
             a0[r] = Rp[rr];
             len[r] = Rp[rr + 1];
@@ -390,10 +429,10 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
             }
             head[r] = live[r] && (__ballot(differs) & gmask) != 0;
         }
-        // the head every row follows: the last head at or before it in the wave's piece
+        // the head every row follows: the last head at or before it in the wave's walk (as positions of the walk)
         int lastIn = -1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) lastIn = head[r] ? (int)rowv[r] : lastIn;
+        for (int r = 0; r < R; ++r) lastIn = head[r] ? vi[r] : lastIn;
         int incl = lastIn;                                         // inclusive running maximum over the groups
 #pragma unroll
         for (int o = G; o < 64; o <<= 1) {
@@ -419,8 +458,8 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
             for (int r = 0; r < R; ++r) {
                 if (head[r]) {
                     sList[at++] = (int)rowv[r];                   // (the list need not be sorted, only complete)
-                    follow = (int)rowv[r];
-                } else if (live[r]) classOut[rowv[r]] = -2 - follow;
+                    follow = vi[r];
+                } else if (live[r]) classOut[rowv[r]] = -2 - (int)row_at(follow);
             }
         }
         // hand the pass's last row to the next pass's group 0 (lane g takes lane (GPW - 1) * G + g's)
@@ -430,6 +469,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
 #pragma unroll
         for (int e = 0; e < E; ++e) { elP[e] = __shfl(el[R - 1][e], from, 64); if (IS_A) cbP[e] = __shfl(cb[R - 1][e], from, 64); }
         followP = max(followP, __builtin_amdgcn_readlane(incl, 63));
+    }
     }
     // the block's heads go to list blockIdx.x % kClassHeadSegs: one global atomic per block
     __syncthreads();
@@ -496,7 +536,11 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         return;
     }
     const int rep = (int)(unsigned)v;
-    const int a0 = Ap[rep], nA = Ap[rep + 1] - a0;               // <= kClassMaxRow (k_class_rows)
+    const int a0 = Ap[rep], nA = Ap[rep + 1] - a0;               // <= kClassMaxRowBig (k_class_rows)
+    if (nA > kClassMaxRow) {                                       // a big class: k_class_patterns_big's (z = -2: not done yet)
+        if (tid == 0) classInfo[s] = make_int4(nA, 0, -2, rep);
+        return;
+    }
     if (tid < 64) {
         int b0 = 0, len = 0;
         if (tid < nA) {
@@ -507,11 +551,15 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         const int incl = wave_incl_scan_dpp(len);
         sIncl[tid] = incl;
         sB0[tid] = b0 - (incl - len);
+        int longest = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o, 64));
+        if (tid == 0) scan[0] = longest;
     }
     __syncthreads();
     const int P = nA > 0 ? sIncl[nA - 1] : 0;
-    if (P > kClassMaxP) {
-        if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
+    if (P > kClassMaxP || scan[0] > kClassMaxRow) {                // (a B entry's number has 6 bits in these tables)
+        if (tid == 0) classInfo[s] = make_int4(nA, P, -2, rep);
         return;
     }
     int N2 = 1;
@@ -662,6 +710,7 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
             const int4 ci = classInfo[c];
             v = ci.z;
             products += (unsigned long long)ci.y;
+            if (v == -2) atomicOr(&stats[CS_FLAGS], 2);           // (a big class nobody worked out: stale hints)
         }
         cnt[i] = v > 0 ? v : 0;
     }

@@ -18,6 +18,7 @@
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
 #include "bhs_class_wg.hip.h"
+#include "bhs_class_big.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -146,7 +147,7 @@ struct bhs_handle {
     int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
-    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt;
+    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt, classBigIdx, classBigMap;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -181,6 +182,7 @@ struct bhs_handle {
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
     int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 8 (where it wins)
     int maxRowA = 0;
+    int periodA = 1, periodB = 1;        // rows repeat the row this many rows back (k_row_period: a hint for k_class_heads)
     // compressed pattern of B for the symbolic pass (k_compress_b): 0 never, 1 (default) when it moves rows out of
     // the workgroup-per-row symbolic kernels -- the average row has more than 1536 products (beyond the 2048-slot
     // wave table) and the data has <= 60 % as many (block, mask) pairs as entries --, 2 always (needs sorted B rows
@@ -220,6 +222,7 @@ struct bhs_handle {
         bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
         bool useClass = false;            // numeric half: k_class_numeric
         int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0, classMaxSlab = 0;
+        int classBig = 0, classBigMaxP = 0;   // classes beyond the register kernels' tables (bhs_class_big.hip.h), their longest product list
         int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
@@ -464,6 +467,30 @@ int launch_class_numeric_atomic(bhs_handle* h, int r0, int r1)
     return launch_class_numeric_atomic_uv<16, 8>(h, r0, r1);
 }
 
+
+// Numeric pass of a multiply with big classes on the rows [r0, r1) (bhs_class_big.hip.h)
+int launch_class_numeric_big(bhs_handle* h, int r0, int r1)
+{
+    auto kern = k_class_numeric_big;
+    const int accStride = (h->ps.classMaxNnz + 3) & ~3, stageCap = (h->ps.classMaxNA + 3) & ~3;
+    const int descCap = (std::max(h->ps.classMaxP, h->ps.classBigMaxP) + 3) & ~3;
+    const size_t smem = (size_t)kClassBigWaves * ((size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int)) +
+                        sizeof(int) * ((size_t)descCap + accStride + 2 * kClassBigRange + 16);
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * kClassBigWaves, smem, &perCU));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    const int mR = r1 - r0;
+    const long long nRanges = ((long long)mR + kClassBigRange - 1) / kClassBigRange;
+    long long grid = std::min<long long>(nRanges, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    if (h->verbose > 1) printf("  [class numeric (big): %d workgroups per CU, %zu bytes of LDS each, grid %lld]\n", perCU, smem, grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kClassBigWaves), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+                       h->dBp, h->dBx, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p, (const unsigned*)h->classMapA.p,
+                       (const int*)h->classBigIdx.p, (const unsigned*)h->classBigMap.p, (const int*)h->classRel.p,
+                       (const int*)h->Cp.p + r0, out_cj(h), out_cx(h), accStride, stageCap, descCap, r0);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
 
 // LDS of a wave of the ring kernel: slots of a row of C (one spare for idle lanes), a run's A values, (longest chain + 1)
 // slabs of the neediest class; all in multiples of 16 bytes
@@ -1152,6 +1179,13 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
     BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
     BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
+    // classes beyond the register kernels' tables are possible: their lists and the big numeric kernel (bhs_class_big.hip.h)
+    const bool bigPossible = h->maxRowA > kClassMaxRow || h->maxRowB > kClassMaxRow || (long long)h->maxRowA * h->maxRowB > kClassMaxP;
+    BHS_TRY(ensure(h, h->classBigIdx, sizeof(int) * kClassSlots));
+    if (bigPossible) {
+        BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
+        BHS_HIP(hipMemsetAsync(h->classBigIdx.p, 0xFF, sizeof(int) * kClassSlots, h->stream));
+    }
     BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
     BHS_HIP(hipMemsetAsync(h->classHeadCnt.p, 0, sizeof(int) * 2 * 16 * kClassHeadSegs, h->stream));
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
@@ -1170,7 +1204,7 @@ int symbolic_class(bhs_handle* h)
 #define BHS_CLASS_ROWS(ISA, G, E, grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads)                                  \
     do {                                                                                                              \
         if (h->classHeadsOn) {                                                                                        \
-            hipLaunchKernelGGL((k_class_heads<ISA, G, E>), dim3(heads_grid(n)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out, heads, nheads, heads_cap(n), rng); \
+            hipLaunchKernelGGL((k_class_heads<ISA, G, E>), dim3(heads_grid(n)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out, heads, nheads, heads_cap(n), rng, std::max(1, std::min(8, ISA ? h->periodA : h->periodB))); \
             hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3((unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs)), kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, (const int*)nullptr, (const int*)heads, (const int*)nheads, heads_cap(n)); \
             hipLaunchKernelGGL(k_class_propagate, dim3((unsigned)std::max<long long>(1, std::min<long long>(((long long)(n) + 255) / 256, (long long)h->numCU * 8))), dim3(256), 0, h->stream, n, out, rng); \
         } else                                                                                                        \
@@ -1202,20 +1236,30 @@ int symbolic_class(bhs_handle* h)
     int* headsL = (int*)h->classHeads.p;
     int* nHeadsB = (int*)h->classHeadCnt.p;
     int* nHeadsA = nHeadsB + 16 * kClassHeadSegs;
-    const int GB = pow2_at_least(h->avgRowB / h->classPerLane, 4, 64), GA = pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);   // ~4 entries per lane in flight
+    // (~2 entries per lane in flight; a data set with rows of more than kClassMaxRow entries: 64 lanes, 2 or 4 entries each)
+    const int GB = h->maxRowB > kClassMaxRow ? 64 : pow2_at_least(h->avgRowB / h->classPerLane, 4, 64);
+    const int GA = h->maxRowA > kClassMaxRow ? 64 : pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);
     switch (GB) {
         case 4: BHS_CLASS_ROWS_G(false, 4, h->maxRowB, rows_grid(k, 4), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
         case 8: BHS_CLASS_ROWS_G(false, 8, h->maxRowB, rows_grid(k, 8), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
         case 16: BHS_CLASS_ROWS_G(false, 16, h->maxRowB, rows_grid(k, 16), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
         case 32: BHS_CLASS_ROWS_G(false, 32, h->maxRowB, rows_grid(k, 32), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
-        default: BHS_CLASS_ROWS_G(false, 64, h->maxRowB, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB); break;
+        default:
+            if (h->maxRowB <= kClassMaxRow) BHS_CLASS_ROWS(false, 64, 1, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB);
+            else if (h->maxRowB <= 2 * kClassMaxRow) BHS_CLASS_ROWS(false, 64, 2, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB);
+            else BHS_CLASS_ROWS(false, 64, 4, rows_grid(k, 64), k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, headsL, nHeadsB);
+            break;
     }
     switch (GA) {
         case 4: BHS_CLASS_ROWS_G(true, 4, h->maxRowA, rows_grid(m, 4), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
         case 8: BHS_CLASS_ROWS_G(true, 8, h->maxRowA, rows_grid(m, 8), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
         case 16: BHS_CLASS_ROWS_G(true, 16, h->maxRowA, rows_grid(m, 16), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
         case 32: BHS_CLASS_ROWS_G(true, 32, h->maxRowA, rows_grid(m, 32), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
-        default: BHS_CLASS_ROWS_G(true, 64, h->maxRowA, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA); break;
+        default:
+            if (h->maxRowA <= kClassMaxRow) BHS_CLASS_ROWS(true, 64, 1, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA);
+            else if (h->maxRowA <= 2 * kClassMaxRow) BHS_CLASS_ROWS(true, 64, 2, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA);
+            else BHS_CLASS_ROWS(true, 64, 4, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA);
+            break;
     }
 #undef BHS_CLASS_ROWS
 #undef BHS_CLASS_ROWS_G
@@ -1229,11 +1273,19 @@ int symbolic_class(bhs_handle* h)
     hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
                        h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
                        (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p, cstats);
+    if (bigPossible) {
+        const size_t smemBig = sizeof(int) * 2 * kClassBigMaxP;
+        int unused = 0;
+        BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(k_class_patterns_big), kClassBigPatThreads, smemBig, &unused));   // (raises its LDS limit)
+        hipLaunchKernelGGL(k_class_patterns_big, dim3(kClassSlots), dim3(kClassBigPatThreads), smemBig, h->stream, (const unsigned long long*)tabA,
+                           h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p, (int*)h->classBigIdx.p,
+                           (unsigned*)h->classBigMap.p, (int*)h->classRel.p, cstats);
+    }
     hipLaunchKernelGGL(k_class_counts, dim3(gA), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
                        (const int4*)h->classInfo.p, (int*)h->Cp.p, cstats);
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
-    h->stats[ep->stat].launches += 2;
+    h->stats[ep->stat].launches += bigPossible ? 3 : 2;
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
     return BHS_SUCCESS;
 }
@@ -1279,7 +1331,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     // ... and long enough for the classification passes to pay: poisson27pt (729 products per row) runs 4.85 -> 3.1 ms
     // on the class kernels, poisson9pt (81) 0.58 -> 0.88 ms -- its whole general pipeline costs less than classifying
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
-                          h->maxRowA <= kClassMaxRow && h->maxRowB <= kClassMaxRow &&
+                          h->maxRowA <= kClassMaxRowBig && h->maxRowB <= kClassMaxRowBig &&
                           (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
                                                  // ... and enough of them: every block of the classifier meets every class once
                                                  // (poisson27pt 51^3, 90 M products: 0.46 ms general, 0.50 ms by classes)
@@ -1326,6 +1378,8 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxLB = cs[CS_MAXLB];
         h->ps.classMaxRing = cs[CS_MAXRING];
         h->ps.classMaxSlab = cs[CS_MAXSLAB];
+        h->ps.classBig = cs[CS_BIGCOUNT];
+        h->ps.classBigMaxP = cs[CS_BIGMAXP];
         if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; slabs of <= %d values]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[CS_MAXSLAB]);
     } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
@@ -1402,7 +1456,8 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (h->ps.useClass) {
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
-        BHS_TRY(h->classNumeric && class_ring_fits(h) ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
+        if (h->ps.classBig) BHS_TRY(launch_class_numeric_big(h, r0, r1));
+        else BHS_TRY(h->classNumeric && class_ring_fits(h) ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += r1 - r0;
@@ -1662,6 +1717,10 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(&maxRowA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_MAXROW);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(&h->periodA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
     }
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
@@ -1676,6 +1735,10 @@ int finish_set_data(bhs_handle* h)
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_MAXROW);
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(&h->maxRowB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_MAXROW);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(&h->periodB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
     }
     h->ubG = pow2_at_least(std::max(avgA, std::min(maxRowA, kUbLongA) / 32.0), 1, 64);   // (longer rows: k_upper_bound_long)

@@ -948,8 +948,18 @@ def _toeplitz(m, n, offsets, rng, holes=()):
     return rp, col, rng.integers(1, 10, len(col)).astype(np.float64)
 
 
+def _kron_ones(rp, col, dof):
+    """(stencil matrix) (x) ones(dof, dof): the pattern of a grid with dof unknowns per node, every coupling a full block."""
+    import scipy.sparse as sp
+    P = sp.csr_matrix((np.ones(len(col)), col, rp), shape=(len(rp) - 1,) * 2)
+    A = sp.kron(P, np.ones((dof, dof)), format="csr")
+    A.sort_indices()
+    return A.shape[0], A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
 @pytest.mark.parametrize("case", ["p27", "p5", "p7", "p9", "rect_toeplitz", "holes", "float_values", "f32_build",
-                                  "unsorted_b", "row_block"])
+                                  "unsorted_b", "row_block", "fem_3dof", "fem_4dof", "fem_3dof_f32", "long_b_rows",
+                                  "fem_3dof_row_block"])
 def test_row_class_path(oracle, case):
     """Row classes (bhs_class.hip.h): inputs whose rows repeat one another's relative pattern take the class kernels --
     classify_rows / class_patterns / numeric_class instead of upper bound, symbolic and numeric bins -- and give the
@@ -972,6 +982,28 @@ def test_row_class_path(oracle, case):
         m = r1 - r0
         A = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], val[rp[r0]:rp[r1]])
         B = (rp, col, val)
+    elif case in ("fem_3dof", "fem_3dof_f32", "fem_4dof", "fem_3dof_row_block"):
+        # several unknowns per node: the classes are beyond the register kernels' tables (81 entries per row, 6561
+        # products and 375 entries per row of C; 4 unknowns on poisson9pt: 36, 1296, 100) -- bhs_class_big.hip.h
+        if case == "fem_4dof":
+            _, rp0, col0, _ = poisson_case("poisson9pt", 23, 19, 1)
+            m, rp, col = _kron_ones(rp0, col0, 4)
+        else:
+            _, rp0, col0, _ = poisson_case("poisson27pt", 7, 6, 5)
+            m, rp, col = _kron_ones(rp0, col0, 3)
+        k = n = m
+        val = rng.integers(1, 10, len(col)).astype(np.float64)
+        A = B = (rp, col, val)
+        if case == "fem_3dof_row_block":
+            r0, r1 = 100, 431
+            m = r1 - r0
+            A = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], val[rp[r0]:rp[r1]])
+        if case == "fem_3dof_f32":
+            value_dtype = np.float32
+    elif case == "long_b_rows":
+        m, k, n = 2000, 2500, 4000          # 3 entries per row of A, 100 per row of B: few products, but a B entry's number needs 7 bits
+        A = _toeplitz(m, k, (-7, 0, 300), rng)
+        B = _toeplitz(k, n, tuple(range(-50, 50)), rng)
     elif case == "rect_toeplitz":
         m, k, n = 3000, 3500, 5000          # relative columns far from 0, rows cut off at every border
         A = _toeplitz(m, k, (-40, -3, 0, 1, 2, 500, 501, 3400), rng)
@@ -1074,7 +1106,7 @@ def test_row_class_path_randomized(oracle, seed):
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
 def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     """Inputs the class tables cannot take: more classes than table slots (unstructured rows), a class with more than
-    1024 products or 512 entries per row, a row with more than 64 entries.  The multiply starts over on the general
+    8192 products or 512 entries per row, a row with more than 256 entries.  The multiply starts over on the general
     pipeline (same call, right answer) and the data set stays there: the next multiply does not classify again."""
     rng = np.random.default_rng(32)
     if case == "random_short_rows":
@@ -1083,10 +1115,10 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
         B = random_csr(k, n, 8.0 / n, rng)
         tried = True
     elif case == "too_many_products":
-        m = k = n = 3000                       # 40 x 40 = 1600 products per row
-        offs = tuple(range(-20, 20))
+        m = k = n = 1500                       # 96 x 96 = 9216 products per row (191 distinct columns)
+        offs = tuple(range(-48, 48))
         A = _toeplitz(m, k, offs, rng)
-        B = _toeplitz(k, n, tuple(7 * o for o in offs), rng)
+        B = _toeplitz(k, n, offs, rng)
         tried = True
     elif case == "too_many_entries":
         m = k = n = 3000                       # 24 x 30 = 720 products, 24 * 30 distinct columns > 512
@@ -1097,7 +1129,7 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
         m = k = n = 2000
         rp, col, val = _toeplitz(m, k, (-1, 0, 1), rng)
         rows = [col[rp[i]:rp[i + 1]] for i in range(m)]
-        rows[700] = np.arange(600, 700)        # 100 entries: the hint from bhs_set_data keeps the class path away
+        rows[700] = np.arange(600, 900)        # 300 entries: the hint from bhs_set_data keeps the class path away
         rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
         col = np.concatenate(rows).astype(np.int32)
         A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
