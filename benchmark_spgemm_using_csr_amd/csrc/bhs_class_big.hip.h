@@ -24,7 +24,8 @@ constexpr int kClassBigPatThreads = 1024;
 
 // ---------------------------------------------------------------------------
 // classInfo[s].z == -2 (k_class_patterns found the class beyond its tables): {A entry (8 bits), B entry (8), position (16)}
-// of every product to bigMap[classBigIdx[s] * kClassBigMaxP + p], the relative columns to classRel like a small class's.
+// of every product -- of every group of T entries' product, see below -- to bigMap[i * kClassBigMaxP + ..], with
+// classBigIdx[s] = i | T << 16; the relative columns to classRel like a small class's.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(const unsigned long long* __restrict__ tableA,
                                                             const int* __restrict__ Ap, const int* __restrict__ Aj,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
     extern __shared__ int smemBig[];                               // keys[kClassBigMaxP], srt[kClassBigMaxP]
     int* keys = smemBig;
     int* srt = smemBig + kClassBigMaxP;
-    __shared__ int sIncl[kClassMaxRowBig], sB0[kClassMaxRowBig], scan[kClassBigPatThreads], ulist[kClassMaxNnz], sIdx;
+    __shared__ int sIncl[kClassMaxRowBig], sB0[kClassMaxRowBig], scan[kClassBigPatThreads], ulist[kClassMaxNnz], sIdx, sGroup[5];
     constexpr int NT = kClassBigPatThreads;
     const int tid = threadIdx.x, s = blockIdx.x;
     if (tableA[s] == kClassEmpty) return;
@@ -90,6 +91,23 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
         srt[p] = key;
     }
     __syncthreads();
+    // Groups of T consecutive A entries whose B rows have the same columns (the unknowns of one node: the B rows of a
+    // node's unknowns are that node's neighbours, all of them): entry k's product e and entry k + 1's product e fall on
+    // the same entry of C, so the list carries one word per GROUP and B entry -- the numeric kernel sums the group's T
+    // products in a register and adds once.  T = 4, 3 or 2 if every group of the row qualifies, else 1.
+    if (tid < 5) sGroup[tid] = nA % max(tid, 1) == 0 ? 1 : 0;
+    __syncthreads();
+    for (int p = tid; p < P; p += NT) {
+        const int k = entry_of(p);
+        if (k == 0) continue;
+        const int lenK = sIncl[k] - sIncl[k - 1], lenPrev = sIncl[k - 1] - (k > 1 ? sIncl[k - 2] : 0);
+        const bool twin = lenK == lenPrev && keys[p] == keys[p - lenPrev];     // (p - lenPrev: product e of entry k - 1)
+        if (!twin)
+            for (int T = 2; T <= 4; ++T)
+                if (k % T) sGroup[T] = 0;                          // (a benign race: every writer writes 0)
+    }
+    __syncthreads();
+    const int T = sGroup[4] ? 4 : (sGroup[3] ? 3 : (sGroup[2] ? 2 : 1));
     for (int kk = 2; kk <= N2; kk <<= 1)                           // ascending bitonic sort of srt[0, N2)
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < N2; i += NT) {
@@ -126,13 +144,15 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
     for (int e = tid; e < nnz; e += NT) classRel[(size_t)s * kClassMaxNnz + e] = ulist[e];
     for (int p = tid; p < P; p += NT) {
         const int key = keys[p], k = entry_of(p);
+        if (k % T) continue;                                       // (its group's first entry speaks for it)
         int l = 0, r = nnz - 1;
         while (l < r) { const int mid = (l + r) >> 1; if (ulist[mid] < key) l = mid + 1; else r = mid; }
-        bigMap[(size_t)idx * kClassBigMaxP + p] = (unsigned)k | (unsigned)(p - (k ? sIncl[k - 1] : 0)) << 8 | (unsigned)l << 16;
+        const int start = k ? sIncl[k - 1] : 0;                    // (the groups before this one: T equal rows each)
+        bigMap[(size_t)idx * kClassBigMaxP + start / T + (p - start)] = (unsigned)k | (unsigned)(p - start) << 8 | (unsigned)l << 16;
     }
     if (tid == 0) {
         classInfo[s] = make_int4(nA, P, nnz, rep);
-        classBigIdx[s] = idx;
+        classBigIdx[s] = idx | (T << 16);
         atomicMax(&stats[CS_BIGMAXP], P);
         atomicMax(&stats[CS_MAXNNZ], nnz);
         atomicMax(&stats[CS_MAXNA], nA);
@@ -146,6 +166,36 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
 // LDS: per wave acc[accStride] + sAx[stageCap] (acc_t) and sBp[stageCap] (int); per workgroup the class's list
 // sDesc[descCap], its relative columns sRel[accStride], the classes of the range's rows and the rows of the class at hand.
 // ---------------------------------------------------------------------------
+// the products of one row: list word = first A entry of the group | B entry << eShift | position << 16
+template <int T>
+__device__ __forceinline__ void class_big_row(const unsigned* sDesc, int words, int eShift, unsigned kMask, const acc_t* sAx,
+                                              const int* sBp, const value_t* __restrict__ Bx, acc_t* acc, int lane)
+{
+    constexpr int UN = T >= 3 ? 2 : 4;                             // (8 to 4 loads in flight per lane)
+    for (int base = 0; base < words; base += 64 * UN) {
+        unsigned d[UN];
+        acc_t a[UN][T], b[UN][T];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) d[u] = sDesc[min(base + u * 64 + lane, words - 1)];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (int)(d[u] & kMask), e = (int)((d[u] >> eShift) & kMask);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                b[u][t] = (acc_t)Bx[sBp[k + t] + e];
+                a[u][t] = sAx[k + t];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc_t v = a[u][0] * b[u][0];
+#pragma unroll
+            for (int t = 1; t < T; ++t) v = __builtin_fma(a[u][t], b[u][t], v);
+            if (base + u * 64 + lane < words) unsafeAtomicAdd(&acc[d[u] >> 16], v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * kClassBigWaves) void k_class_numeric_big(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, const int* __restrict__ classC,
@@ -187,11 +237,13 @@ __global__ __launch_bounds__(64 * kClassBigWaves) void k_class_numeric_big(
             const int cls = sCls[first];
             const int4 ci = classInfo[cls];
             const int nA = ci.x, P = ci.y, nnz = ci.z;
-            const bool big = nA > kClassMaxRow || P > kClassMaxP || classBigIdx[cls] >= 0;
-            const unsigned* list = big ? bigMap + (size_t)classBigIdx[cls] * kClassBigMaxP : classMapA + (size_t)cls * kClassMaxP;
+            const int bi = classBigIdx[cls];
+            const bool big = bi >= 0;
+            const int T = big ? bi >> 16 : 1, words = P / T;      // (entries per group: one list word per group and B entry)
+            const unsigned* list = big ? bigMap + (size_t)(bi & 0xFFFF) * kClassBigMaxP : classMapA + (size_t)cls * kClassMaxP;
             const int eShift = big ? 8 : 6;
             const unsigned kMask = big ? 255u : 63u;
-            for (int p = tid; p < P; p += NT) sDesc[p] = list[p];
+            for (int p = tid; p < words; p += NT) sDesc[p] = list[p];
             for (int e = tid; e < nnz; e += NT) sRel[e] = classRel[(size_t)cls * kClassMaxNnz + e];
             // the rows of this class, in order (kClassBigRange <= 64 * kClassBigWaves: one row per thread)
             const bool match = tid < kClassBigRange && sCls[tid] == cls;
@@ -220,22 +272,10 @@ __global__ __launch_bounds__(64 * kClassBigWaves) void k_class_numeric_big(
                     sBp[e] = Bp[aj];
                 }
                 wave_sync();
-                constexpr int UN = 4;
-                for (int base = 0; base < P; base += 64 * UN) {
-                    unsigned d[UN];
-                    acc_t a[UN], b[UN];
-#pragma unroll
-                    for (int u = 0; u < UN; ++u) d[u] = sDesc[min(base + u * 64 + lane, P - 1)];
-#pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        const int k = (int)(d[u] & kMask);
-                        b[u] = (acc_t)Bx[sBp[k] + (int)((d[u] >> eShift) & kMask)];
-                        a[u] = sAx[k];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UN; ++u)
-                        if (base + u * 64 + lane < P) unsafeAtomicAdd(&acc[d[u] >> 16], a[u] * b[u]);
-                }
+                if (T == 1) class_big_row<1>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
+                else if (T == 2) class_big_row<2>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
+                else if (T == 3) class_big_row<3>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
+                else class_big_row<4>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
                 wave_sync();
                 for (int e = lane; e < nnz; e += 64) {
                     const acc_t v = acc[e];
