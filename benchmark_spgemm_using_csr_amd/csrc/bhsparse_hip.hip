@@ -14,7 +14,6 @@
 // rowPtrC (bhsparse_cuda.h:280, 289, 2787-2808).
 #include "../../include/bhsparse_hip.h"
 #include "bhs_kernels.hip.h"
-#include "bhs_rank.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
 #include "bhs_class_wg.hip.h"
@@ -172,10 +171,6 @@ struct bhs_handle {
     int maxRowB = 0;
     int kernelStats = 0;                 // per-kernel-family hipEvent pairs (bhs_get_kernel_stats): off unless asked for -- they cost
                                          // 34 us of a 0.24 ms poisson5pt 1024^2 multiply; the four stage timers are always read
-    int rankPath = 0;                    // pattern + rank kernels (bhs_rank.hip.h) for the matrices that qualify for wave-first: 0 off (default:
-                                         // measured slower than the hash kernels on poisson27pt), 1 on
-    int rankState = 0;                   // per data set: -1 after a multiply that sent too many rows to the overflow queue
-    DevBuf pat;                          // row patterns: kPatPairs x 8 bytes per row
     bool specFailed = false;             // a lane-first / wave-first launch met a row beyond the bounds seen at set_data time
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
@@ -219,11 +214,11 @@ struct bhs_handle {
     struct PipeState {
         bool open = false;                // symbolic done, finish pending
         bool empty = false;               // empty product: nothing to launch
-        bool noUpperBound = false, symDirect = false, useRank = false, overflowDone = false;
+        bool noUpperBound = false, symDirect = false;
         bool useClass = false;            // numeric half: k_class_numeric
         int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0, classMaxSlab = 0;
         int classBig = 0, classBigMaxP = 0;   // classes beyond the register kernels' tables (bhs_class_big.hip.h), their longest product list
-        int laneK = 0, rankOvf = 0, maxCnt = 0, hubRows = 0;
+        int laneK = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
         int symStat[kMaxBins], numStat[kMaxBins];
         int fullCount[kMaxBins];          // numeric-bin histogram of all rows (from the scan)
@@ -248,7 +243,7 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_NUM_SUMS = 104 + 96,
        S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
        S_ZERO_END = 104 + 194,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* rows k_sym_blocks sent to the overflow queue */,
+       S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* (free) */,
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
@@ -676,65 +671,6 @@ int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
     return BHS_SUCCESS;
 }
 
-// ---- pattern + rank kernels (bhs_rank.hip.h): every row straight from rowPtrA, XCD-aware persistent grid
-int rank_grid(bhs_handle* h, const void* kern, size_t smem, int qn, long long* grid, int* chunkLog2)
-{
-    constexpr int WPB = kWavesPerBlock;
-    int perCU = 1;
-    BHS_TRY(kernel_occupancy(h, kern, 64 * WPB, smem, &perCU));
-    perCU = std::max(1, std::min(perCU, 32 / WPB));
-    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
-    long long g = std::min<long long>(((long long)qn + WPB - 1) / WPB, (long long)h->numCU * useCU);
-    *grid = std::max<long long>(8, (g + 7) / 8 * 8);
-    int cl = 0;
-    while ((2 << cl) <= BHS_XCD_CHUNK && (128LL << cl) <= (long long)qn) ++cl;
-    *chunkLog2 = cl;
-    return BHS_SUCCESS;
-}
-
-int launch_sym_sorted(bhs_handle* h)
-{
-    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
-    const size_t smem = sizeof(SymSortSmem) * kWavesPerBlock;
-    int* small = (int*)h->small.p;
-    long long grid;
-    int cl;
-#define BHS_SYMS(SB)                                                                                              \
-    {                                                                                                             \
-        auto kern = k_sym_sorted<SB>;                                                                             \
-        BHS_TRY(rank_grid(h, reinterpret_cast<const void*>(kern), smem, h->m, &grid, &cl));                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), smem, h->ls, h->m, cl, h->dAp,  \
-                           h->dAj, h->dBp, h->dBj, (int*)h->Cp.p, (int*)h->ub.p,                                  \
-                           (unsigned long long*)(small + S_CT_SLOTS), (int*)h->pat.p, (int4*)h->queue.p,          \
-                           small + S_OVF);                                                                        \
-    }
-    if (smallB) BHS_SYMS(true) else BHS_SYMS(false)
-#undef BHS_SYMS
-    BHS_HIP(hipGetLastError());
-    return BHS_SUCCESS;
-}
-
-template <int RMAX>
-int launch_num_rank(bhs_handle* h)
-{
-    const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
-    const size_t smem = sizeof(NumRankSmem<RMAX>) * kWavesPerBlock;
-    long long grid;
-    int cl;
-#define BHS_NUMR(SB)                                                                                              \
-    {                                                                                                             \
-        auto kern = k_num_rank<RMAX, SB>;                                                                         \
-        BHS_TRY(rank_grid(h, reinterpret_cast<const void*>(kern), smem, h->m, &grid, &cl));                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), smem, h->ls, h->m, cl, h->dAp,  \
-                           h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, (const int*)h->Cp.p, out_cj(h),                \
-                           out_cx(h), (const int*)h->pat.p, (int*)h->small.p + S_ERR);                    \
-    }
-    if (smallB) BHS_NUMR(true) else BHS_NUMR(false)
-#undef BHS_NUMR
-    BHS_HIP(hipGetLastError());
-    return BHS_SUCCESS;
-}
-
 int launch_compress_b(bhs_handle* h)
 {
     int G = 1 << h->logL;                       // lanes per row of B: its average length, 2..16
@@ -978,7 +914,7 @@ int join_bins(bhs_handle* h)
 // Stages 1 and 2 of the general pipeline: upper bound, symbolic bins and queues, the symbolic kernels.  Leaves the
 // per-row counts in Cp and tells stage 3 which choices it made.
 struct SymChoices {
-    bool noUpperBound = false, symDirect = false, useRank = false;
+    bool noUpperBound = false, symDirect = false;
     int laneK = 0, hubRows = 0;
     BinSpec numSpec;
 };
@@ -1034,17 +970,11 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
         if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
             for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
     }
-    // The wave-first class (stencils, FEM meshes) takes the pattern + rank kernels: the symbolic pass hands every
-    // row's sorted column list to the numeric pass, which then needs no hash inserts, no compaction and no sort.
-    // (maxRowA is a hint: rows with more than 64 A entries go to the overflow queue on the device.)
-    const bool useRank = wfBin > 0 && h->rankPath && h->rankState >= 0 && h->maxRowA <= 64;
-    if (useRank) BHS_TRY(ensure(h, h->pat, sizeof(int) * (size_t)kPatStride * (size_t)m));
     const bool noUpperBound = laneFirst || wfBin > 0;
     if (noUpperBound) numSpec.hubMin = 0;     // (every row is bounded by maxRow(A) x maxRow(B), far below the hub bin)
     int symCount[kMaxBins], symStart[kMaxBins + 1];
     if (noUpperBound) {
         BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
-        if (useRank) BHS_HIP(hipMemsetAsync(small + S_OVF, 0, sizeof(int), h->stream));
         for (int b = 0; b < kMaxBins; ++b) { symCount[b] = 0; symStart[b] = 0; }
         symStart[kMaxBins] = 0;
         symCount[laneFirst ? kLaneBin : wfBin] = m;
@@ -1121,23 +1051,6 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
         h->stats[ep->stat].rows += symCount[kHubBin];
         symStat[kHubBin] = ep->stat;
     }
-    if (useRank) {
-        BHS_TRY(timed_begin(h, "symbolic_sorted", &ep));
-        BHS_TRY(launch_sym_sorted(h));
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-        h->stats[ep->stat].rows += m;
-        symStat[wfBin] = ep->stat;
-        // rows the block table could not hold: workgroup-per-row hash kernel over the device-built queue (its
-        // length is read on the device; the launch is a persistent grid that leaves at once when the queue is empty)
-        h->ticketSlot = S_TICKETS + kMaxBins - 2;
-        BHS_TRY(timed_begin(h, "symbolic_overflow", &ep));
-        BHS_TRY((launch_row_block<15, 1024, false>(h, (const int4*)h->queue.p, h->numCU, (int*)h->Cp.p, small + S_OVF)));
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-        h->ticketSlot = S_TICKET;
-        symCount[wfBin] = 0;                                         // (done: the bin loop below has nothing left)
-    }
     for (int i = 1; i < kNumSymBins; ++i) {
         const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
         if (!symCount[b]) continue;
@@ -1155,7 +1068,6 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
 
     out.noUpperBound = noUpperBound;
     out.symDirect = symDirect;
-    out.useRank = useRank;
     out.laneK = laneK;
     out.hubRows = noUpperBound ? 0 : symCount[kHubBin];
     out.numSpec = numSpec;
@@ -1343,7 +1255,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     } else {
         BHS_TRY(symbolic_general(h, sc));
     }
-    const bool noUpperBound = sc.noUpperBound, symDirect = sc.symDirect, useRank = sc.useRank;
+    const bool noUpperBound = sc.noUpperBound, symDirect = sc.symDirect;
     const int laneK = sc.laneK;
     const BinSpec& numSpec = sc.numSpec;
 
@@ -1402,16 +1314,12 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     h->nnzC = nnzC;
     h->ps.noUpperBound = noUpperBound;
     h->ps.symDirect = symDirect;
-    h->ps.useRank = useRank;
     h->ps.laneK = laneK;
     h->ps.numSpec = numSpec;
     h->ps.maxCnt = hs[S_MAXCNT];
     h->ps.hubRows = sc.hubRows;
-    h->ps.rankOvf = useRank ? hs[S_OVF] : 0;
     for (int b = 0; b < kMaxBins; ++b) h->ps.fullCount[b] = hs[S_NUM_COUNT + b];
     memcpy(h->ps.symSums, hs + S_SYM_SUMS, sizeof(h->ps.symSums));
-    // a data set that sends more than 2 % of its rows to the overflow queue is better served by the hash bins
-    if (useRank && (long long)h->ps.rankOvf * 50 > (long long)m) h->rankState = -1;
     if (h->extCj) {
         if (nnzC > h->extCap) return BHS_ERR_ALLOC;
     } else if (!h->lazyOut) {
@@ -1450,7 +1358,6 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     EventPair* ep;
     const BinSpec& numSpec = h->ps.numSpec;
     const int laneK = h->ps.laneK;
-    const bool useRank = h->ps.useRank;
     int (&numStat)[kMaxBins] = h->ps.numStat;
     h->ls = h->stream;
     if (h->ps.useClass) {
@@ -1464,29 +1371,17 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         if (full) { h->stats[ep->stat].products += h->nnzCt; h->stats[ep->stat].nnz_out += h->nnzC; h->stats[ep->stat].nnzA_rows += h->nnzA; }
         return BHS_SUCCESS;
     }
-    // overflow rows of the rank path carry absolute row numbers: all of them with the first range
-    if (useRank && h->ps.rankOvf > 0 && !h->ps.overflowDone) {
-        h->ps.overflowDone = true;
-        h->ticketSlot = S_TICKETS + kMaxBins - 2;
-        BHS_TRY(timed_begin(h, "numeric_overflow", &ep));
-        BHS_TRY((launch_row_block<13, 512, true>(h, (const int4*)h->queue.p, h->ps.rankOvf, (int*)h->Cp.p)));
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-        h->stats[ep->stat].rows += h->ps.rankOvf;
-        h->ticketSlot = S_TICKET;
-    }
     // ---- the range as a view
     struct View {
-        bhs_handle* h; int m; const int* dAp; void *cp, *ub, *pat;
-        View(bhs_handle* h_, int r0_, int mR) : h(h_), m(h_->m), dAp(h_->dAp), cp(h_->Cp.p), ub(h_->ub.p), pat(h_->pat.p)
+        bhs_handle* h; int m; const int* dAp; void *cp, *ub;
+        View(bhs_handle* h_, int r0_, int mR) : h(h_), m(h_->m), dAp(h_->dAp), cp(h_->Cp.p), ub(h_->ub.p)
         {
             h->m = mR;
             h->dAp = dAp + r0_;
             h->Cp.p = (int*)cp + r0_;
             h->ub.p = (int*)ub + r0_;
-            if (pat) h->pat.p = (int*)pat + (size_t)r0_ * kPatStride;
         }
-        ~View() { h->m = m; h->dAp = dAp; h->Cp.p = cp; h->ub.p = ub; h->pat.p = pat; }
+        ~View() { h->m = m; h->dAp = dAp; h->Cp.p = cp; h->ub.p = ub; }
     } view(h, r0, r1 - r0);
     const int m = r1 - r0;
     int numCount[kMaxBins], numStart[kMaxBins + 1];
@@ -1512,15 +1407,10 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     numStart[0] = 0;
     for (int b = 0; b < kMaxBins; ++b) numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
     bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
-    if (useRank) {
-        for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
-        numStart[kMaxBins] = 0;
-        numDirect = true;
-    }
     // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
     // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
     // queue, and the few short boundary rows no longer pay for kernels of their own.
-    if (!useRank && !numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+    if (!numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
         h->ps.hubRows == 0) {
         int nb = 0;
         for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
@@ -1547,15 +1437,6 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (full) h->ps.numDirectFull = numDirect;
     h->ps.rangesRun++;
     const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
-    if (useRank) {
-        BHS_TRY(timed_begin(h, "numeric_rank", &ep));
-        if (h->ps.maxCnt <= 128) BHS_TRY(launch_num_rank<128>(h));
-        else BHS_TRY(launch_num_rank<256>(h));
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-        h->stats[ep->stat].rows += m;
-        numStat[2] = ep->stat;
-    }
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
     if (numCount[kHubBin]) {
         bin_stream(h, kHubBin);
@@ -1750,7 +1631,6 @@ int finish_set_data(bhs_handle* h)
     h->bSorted = 1;
     h->cmpState = 0;
     h->specFailed = false;
-    h->rankState = 0;
     h->classState = 0;
     if (h->nnzB > 1 && h->k > 0) {
         int* small = (int*)h->small.p;
@@ -1913,7 +1793,6 @@ int bhs_destroy(bhs_handle* h)
     release(h->sortV);
     release(h->cLen);
     release(h->symKey);
-    release(h->pat);
     release(h->blockSum);
     release(h->small);
     release(h->spaRank);
@@ -2193,7 +2072,6 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "rank_path")) { h->rankPath = (int)value; h->rankState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }

@@ -216,19 +216,24 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     timers are recorded -- the pairs cost 34 us of a 0.24 ms poisson5pt 1024^2 multiply, 0.16 ms of
  *                     the 3.3 ms power-law stand-in (many bins).  The reference's own `_profiling` prints are off by
  *                     default too (bhsparse_cuda.h:728-733).
- *   "rank_path"       1: matrices of the wave-first class take the pattern + rank kernels (bhs_rank.hip.h: the symbolic
- *                     pass hands every row's sorted column list to a numeric pass without hash inserts or sort);
- *                     0 (default): measured slower than the hash kernels on poisson27pt
  *   "concurrent_bins" the kernels of a stage's bins run concurrently on side streams: 0 never, 1 always,
  *                     2 (default) when the stage has >= 8 non-empty bins (power-law matrices)
  *   "spa_slots"       HBM bitmap slots (default: one per CU)
  *   "class_path"      row classes (bhs_class.hip.h): rows that repeat one another's relative pattern -- stencils, anything
  *                     assembled on a regular grid -- get their structure (sorted columns, entry count, product ->
  *                     position map) worked out once per class instead of once per row.  1 (default): tried on data
- *                     sets whose rows of A and B have at most 64 entries and, on average, at least
+ *                     sets whose rows of A and B have at most 256 entries and, on average, at least
  *                     "class_min_products" (default 256) products per row of C and 2.5e8 products in all; every row is classified and verified
- *                     on the device, and a data set with rows that find no class goes back to the general pipeline
- *                     for good.  2: tried whatever the average; 0: never.
+ *                     on the device, and a data set with rows that find no class (or a class of more than 8192
+ *                     products / 512 entries per row of C) goes back to the general pipeline for good.
+ *                     2: tried whatever the average; 0: never.
+ *   "class_numeric"   numeric kernel of the classes whose product list fits a wave's registers (<= 64 entries per row
+ *                     of A and B, <= 1024 products): 1 (default) the ring kernel (bhs_class_wg.hip.h: sums in
+ *                     registers, B's values through a ring of slabs in LDS) wherever its LDS fits, 0 always the LDS-atomic
+ *                     kernel of round 2.  Multiplies with bigger classes (several unknowns per grid node) run
+ *                     bhs_class_big.hip.h whatever this says.
+ *   "class_heads"     1 (default): only rows that differ from the row `period` rows before them are looked up in
+ *                     the class table (period: sampled at bhs_set_data time, the unknowns per node); 0: every row
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),

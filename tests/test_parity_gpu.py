@@ -1155,7 +1155,7 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
 
 
 def _banded(m, offsets, rng, drop=0.0):
-    """Rows i -> columns {i + o} (clipped), optionally thinned: the clustered-column class the rank path is for."""
+    """Rows i -> columns {i + o} (clipped), optionally thinned."""
     rows = []
     for i in range(m):
         c = np.array(sorted({i + o for o in offsets if 0 <= i + o < m}), np.int32)
@@ -1168,20 +1168,15 @@ def _banded(m, offsets, rng, drop=0.0):
     return rp, col
 
 
-def _kernel_names(info):
-    return {s["name"] for s in info["kernels"]}
-
-
-@pytest.mark.parametrize("case", ["p27", "p27_slab", "band_runs", "band_thin", "two_level"])
-def test_rank_path_pattern_then_rank(oracle, case):
-    """k_sym_sorted + k_num_rank (bhs_rank.hip.h): the symbolic pass hands the row patterns to the numeric pass.
-    Matrices of the wave-first class; the kernels that ran are checked by name, the result against the oracle."""
+@pytest.mark.parametrize("case", ["p27_slab", "band_runs", "band_thin", "two_level"])
+def test_banded_matrices(oracle, case):
+    """Clustered columns: thin grids, runs of entries around far-apart diagonals, thinned bands, rows of A with more
+    than 64 entries -- through the default path and through the general pipeline alone: the oracle's C, and identical
+    bits from both."""
     rng = np.random.default_rng(17)
-    if case == "p27":
-        m, rp, col, val = poisson_case("poisson27pt", 14, 13, 12)
-    elif case == "p27_slab":
+    if case == "p27_slab":
         m, rp, col, val = poisson_case("poisson27pt", 40, 40, 3)
-    elif case == "band_runs":                                   # runs of 4 around far-apart diagonals: blocks straddle
+    elif case == "band_runs":                                   # runs of 4 around far-apart diagonals
         m = 6000
         offs = [d + t for d in (-1900, -611, -30, 0, 33, 700, 2500) for t in range(4)]
         rp, col = _banded(m, offs, rng)
@@ -1190,65 +1185,18 @@ def test_rank_path_pattern_then_rank(oracle, case):
         m = 5000
         rp, col = _banded(m, list(range(-40, 41, 3)) + [400, 401, 402], rng, drop=0.3)
         val = rng.integers(1, 10, len(col)).astype(np.float64)
-    else:                                                       # > 64-entry rows of A (chunk loop), clustered columns
+    else:                                                       # > 64-entry rows of A, clustered columns
         m = 3000
         rp, col = _banded(m, list(range(-35, 36)), rng, drop=0.1)
         val = rng.integers(1, 10, len(col)).astype(np.float64)
     A = (rp, col, val)
-    Cp, Cj, Cx, info = _check(oracle, m, m, m, A, A, options={"rank_path": 1})
-    names = _kernel_names(info)
-    if case != "two_level":
-        assert "symbolic_sorted" in names and "numeric_rank" in names, names
-    # and the same product through the hash kernels (the default): identical bits
-    Cp2, Cj2, Cx2, info2 = _check(oracle, m, m, m, A, A, options={"rank_path": 0})
-    assert "numeric_rank" not in _kernel_names(info2)
+    Cp, Cj, Cx, info = _check(oracle, m, m, m, A, A)
+    Cp2, Cj2, Cx2, info2 = _check(oracle, m, m, m, A, A, options={"class_path": 0, "wave_first": 0, "lane_first": 0, "direct_bins": 0})
     assert np.array_equal(Cp, Cp2) and np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
 
 
-def test_rank_path_overflow_rows_take_the_hash_kernels(oracle):
-    """Rows the fixed-size pattern cannot hold (> 64 occupied column blocks, > 256 entries) go to the overflow
-    queue and through k_row_block in both passes; a data set made mostly of such rows leaves the rank path."""
-    rng = np.random.default_rng(23)
-    m = 4000
-    # banded rows, every 97th row of B scattered over the whole column range (its products land in > 64 blocks)
-    rp, col = _banded(m, list(range(-8, 9)), rng)
-    rows = [col[rp[i]:rp[i + 1]] for i in range(m)]
-    for i in range(5, m, 97):
-        rows[i] = np.sort(rng.choice(m, 17, replace=False)).astype(np.int32)
-    rp2 = np.zeros(m + 1, np.int32)
-    rp2[1:] = np.cumsum([len(r) for r in rows])
-    col2 = np.concatenate(rows).astype(np.int32)
-    val = rng.integers(1, 10, len(col2)).astype(np.float64)
-    A = (rp2, col2, val)
-    Cp, Cj, Cx, info = _check(oracle, m, m, m, A, A, options={"rank_path": 1})
-    names = _kernel_names(info)
-    assert "numeric_rank" in names and "numeric_overflow" in names, names
-    # every row scattered: all rows overflow on the first multiply, the second one uses the hash bins
-    m2, n2 = 1500, 60000
-    rpA = np.arange(0, 24 * m2 + 1, 24, dtype=np.int32)
-    colA = np.concatenate([np.sort(rng.choice(m2, 24, replace=False)) for _ in range(m2)]).astype(np.int32)
-    rpB = np.arange(0, 24 * m2 + 1, 24, dtype=np.int32)
-    colB = np.concatenate([np.sort(rng.choice(n2, 24, replace=False)) for _ in range(m2)]).astype(np.int32)
-    valA = rng.integers(1, 10, len(colA)).astype(np.float64)
-    valB = rng.integers(1, 10, len(colB)).astype(np.float64)
-    plats = [False] * bhmod.NUM_PLATFORMS
-    plats[bhmod.BHSPARSE_HIP] = True
-    bh = bhmod.bhsparse()
-    assert bh.initPlatform(plats) == 0
-    assert bh.set_option("rank_path", 1) == 0
-    Cp = np.zeros(m2 + 1, np.int32)
-    assert bh.initData(m2, m2, n2, len(colA), valA, rpA, colA, len(colB), valB, rpB, colB, Cp) == 0
-    ref = oracle.spgemm(m2, m2, n2, rpA, colA, valA, rpB, colB, valB)
-    seen = []
-    for _ in range(2):
-        assert bh.spgemm() == 0
-        seen.append({s["name"] for s in bh.kernel_stats()})
-        nnzC = bh.get_nnzC()
-        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
-        assert bh.get_C(Cj, Cx) == 0
-        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
-    assert "numeric_overflow" in seen[0] and "numeric_rank" not in seen[1], seen
-    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+def _kernel_names(info):
+    return {s["name"] for s in info["kernels"]}
 
 
 def _phase_cases():
@@ -1263,9 +1211,9 @@ def _phase_cases():
     yield "rect", A, B
 
 
-@pytest.mark.parametrize("rank_path", [0, 1, "classes"])
+@pytest.mark.parametrize("path", ["general", "classes"])
 @pytest.mark.parametrize("nranges", [1, 3, 7])
-def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
+def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, path):
     """bhs_spgemm_symbolic / bhs_spgemm_numeric(row range) / bhs_spgemm_finish == bhs_spgemm, for every kernel family
     (direct lane / wave launches and binned queues), with the ranges issued in any order, into the library's own C
     arrays and into caller-owned ones (bhs_set_output_device)."""
@@ -1285,11 +1233,7 @@ def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
         plats[bhmod.BHSPARSE_HIP] = True
         bh = bhmod.bhsparse()
         assert bh.initPlatform(plats) == 0
-        if rank_path == "classes":                                 # row classes whenever the rows classify (p27, p5)
-            assert bh.set_option("class_path", 2) == 0
-        else:
-            assert bh.set_option("class_path", 0) == 0
-            assert bh.set_option("rank_path", rank_path) == 0      # (only the wave-first class takes it)
+        assert bh.set_option("class_path", 2 if path == "classes" else 0) == 0     # (2: row classes whenever the rows classify: p27, p5)
         assert bh.initData_device(m, k, n, len(Aj), dA[2], dA[0], dA[1], len(Bj), dB[2], dB[0], dB[1]) == 0
         L, h = bh._lib, bh._h
         for external in (False, True):
@@ -1319,7 +1263,7 @@ def test_symbolic_numeric_halves_in_row_ranges(oracle, nranges, rank_path):
             assert res["ok"], (tag, external, res)
         # and an ordinary multiply on the same handle afterwards
         assert bh.spgemm() == 0 and bh.get_nnzC() == ref[0][-1]
-        if rank_path == "classes" and tag in ("p27", "p5"):
+        if path == "classes" and tag in ("p27", "p5"):
             assert "numeric_class" in {s["name"] for s in bh.kernel_stats() if s["launches"]}, tag
         assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
