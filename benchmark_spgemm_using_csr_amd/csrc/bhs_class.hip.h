@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     __shared__ int clen[NC];
     __shared__ int cpatB[IS_A ? NC : 1][PW];
     const int tid = threadIdx.x, lane = tid & 63, g = tid % G;
-    if (tid < NC) ctag[tid] = 0xFFFFFFFFu;
+    if (tid < NC) { ctag[tid] = 0xFFFFFFFFu; clen[tid] = -1; }   // (LDS is not cleared between workgroups)
     __syncthreads();
     const int leaderLane = lane - g;                               // first lane of this lane's group
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << leaderLane;
@@ -229,8 +229,9 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
             const int ci = (int)(hr & (NC - 1));
             {
                 unsigned tg = 0xFFFFFFFFu;
-                if (searching && g == 0) tg = ctag[ci];
+                if (searching && g == 0) tg = __hip_atomic_load(&ctag[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 tg = (unsigned)__shfl((int)tg, leaderLane, 64);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the pattern is read after its tag, never before
                 const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (hr >> 12);
                 bool same = clen[ci] == lenr;
                 int pc[E], pb[E];
