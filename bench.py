@@ -151,13 +151,53 @@ def main():
     native = None
     use_native = os.environ.get("BENCH_GATHER", "native") != "torch"
     sub_blocks = int(os.environ.get("BENCH_SUB_BLOCKS", "4"))
+    native_fallback = [None]              # why the run left the native all-gatherv for the torch.distributed one (None: it did not)
     if (world > 1 or force_gather) and not args.no_gather and use_native:
-        native = bdist.NativeDist(bh, world=world, rank=rank)
+        # every rank must end up on the same path: a rank whose communicator cannot be made takes all of them to the
+        # torch.distributed all-gatherv (the N > 1 native path has never met hardware in development)
+        why = None
+        try:
+            if os.environ.get("BENCH_NATIVE_FAIL") == "init":       # (test hook)
+                raise RuntimeError("injected")
+            native = bdist.NativeDist(bh, world=world, rank=rank)
+        except Exception as e:
+            why = "init: %s" % e
+        if world > 1:
+            okf = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0 and why is None:
+                why = "init failed on another rank"
+        if why is not None:
+            if native is not None:
+                native.close()
+            native = None
+            native_fallback[0] = why
     gather_ms = [0.0, 0.0, 0.0]
     native_totals = [0, 0]
 
+    def leave_native(e):
+        # the library's failures are collective (every rank of the call gets an error, include/bhsparse_dist.h), so
+        # every rank comes here in the same step and goes on with the torch.distributed all-gatherv
+        nonlocal native
+        native_fallback[0] = "step: %s" % e
+        try:
+            native.close()
+        except Exception:
+            pass
+        native = None
+        gather_out[0] = None
+        assert bh.set_output_device(None, None, 0) == 0
+
     def step():
         if native is not None:
+            try:
+                return native_step()
+            except Exception as e:
+                leave_native(e)
+        return torch_step()
+
+    def native_step():
+        if True:
             if gather_out[0] is None:
                 # capacity: this rank's share times the world (weak scaling: equal shares) plus slack, grown on demand
                 e = bh.spgemm()
@@ -173,6 +213,8 @@ def main():
                                  torch.empty(capn, dtype=torch.float64, device=dev))
             rp, cc, vv = gather_out[0]
             tq = time.perf_counter()
+            if os.environ.get("BENCH_NATIVE_FAIL") == "step":       # (test hook)
+                raise RuntimeError("injected")
             ct, cn = native.spgemm_allgatherv(r1 - r0, m, rp, cc, vv, sub_blocks=sub_blocks)
             bh.time_ms = (time.perf_counter() - tq) * 1e3 - native.ms[2]      # multiply + overlapped part
             for i in range(3):
@@ -181,6 +223,8 @@ def main():
             if world == 1:
                 bh.nnzCt, bh.nnzC = ct, cn
             return rp, cc[:cn], vv[:cn]
+
+    def torch_step():
         e = bh.spgemm()
         if e != 0:
             raise RuntimeError("spgemm: " + facade._lib.strerror(e))
@@ -423,6 +467,7 @@ def main():
         "gather_ms_per_step": round(ms_per_step - t_compute / args.steps, 4) if (world > 1 or force_gather) else 0.0,
         "gather_link_floor_ms": round(native.link_floor_ms(), 4) if native is not None else None,
         "nranks_seen": native.nranks() if native is not None else None,
+        "native_fallback": native_fallback[0],
         "native_ms_per_step": [round(x / args.steps, 4) for x in gather_ms] if native is not None else None,
         "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),
         "pipeline_compulsory_bytes": int(bytes_alg_total),
