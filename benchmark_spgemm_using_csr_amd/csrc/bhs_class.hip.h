@@ -500,14 +500,17 @@ __global__ __launch_bounds__(256) void k_class_propagate(int nrows, int* __restr
 // classRel[s * kClassMaxNnz + e] = column of entry e minus the row number, ascending
 // classMapA[s * kClassMaxP + p] = A entry | B entry << 6 | position << 16 for product p in A-entry-major order
 //   (k_class_numeric_atomic)
-// classMap[s * kClassMaxP + u * 64 + L] = product descriptor of lane L, step u of the workgroup numeric kernel.  The class's P
-//   products are sorted by (position in the row of C, product number) and dealt out in that order, U = ceil(P / 64)
-//   consecutive products per lane: the products that sum into one entry of C sit in ONE lane, one after the other
-//   (a few entries straddle a lane boundary).  Descriptor = A entry | B entry << 6 | kClassStart (first product of
-//   an entry within this lane: the running sum restarts) | kClassIdleBit (no product) | slot << 16, where slot is
-//   the entry's position, or kClassDump when the entry goes on in the NEXT lane (then the lane's sum at the end of
-//   its list is a partial sum that it adds to that entry's position, classLane[.. + L] below).  A lane with fewer
-//   than U products has its idle steps FIRST (the sum it carries at the end of the list is that of real products).
+// classMap[s * kClassMaxP + (kClassMaxSteps - U + u) * 64 + L] = product descriptor of lane L, step u of the ring kernel.
+//   The class's P products are sorted by (position in the row of C, product number) and dealt out in that order,
+//   U = ceil(P / 64) consecutive products per lane: the products that sum into one entry of C sit in ONE lane, one
+//   after the other (a few entries straddle a lane boundary).  The descriptor is the word the kernel keeps in a
+//   register: byte offset of the entry's accumulator slot (bits 0-15), byte offset of the A entry's value in the row's
+//   staged values (16-24), B entry (25-30), sign bit: first product of an entry within this lane (the running sum
+//   restarts).  An entry that goes on in the NEXT lane has the class's spare slot (number nnz) instead of its own:
+//   the lane's sum at the end of its list is a partial sum that it adds to that entry's position, classLane[.. + L]
+//   below.  A lane with fewer than U products has its idle steps FIRST (spare slot, restart: the sum it carries at
+//   the end of the list is that of real products), and the U steps are the LAST of the kClassMaxSteps stored ones, so
+//   that the kernel's loads of its MAXU steps do not wait for the class's U.
 // classLane[s * kClassLaneInts + ..]: [L] = tail position of lane L (-1: none).  The rest describes the CHAINS of the A
 //   row: maximal stretches of A entries with consecutive columns whose B rows have one length -- consecutive rows of
 //   B, also across consecutive rows of the class (row i + 1's entry k selects the B row after row i's).  A "slab" is
@@ -515,10 +518,12 @@ __global__ __launch_bounds__(256) void k_class_propagate(int nrows, int* __restr
 //   [64 + L]  as A entry L: its chain's place in a slab (bits 0-15), its place in the chain (16-21), its B row's length (24-30)
 //   [128 + L] as chain L:   first A entry (0-5), entries (6-12), B row length (13-19), place in a slab (20-30)
 //   [192] chains (0-7), entries of the longest chain (8-15), values per slab (16-31)
+//   [256 + j * 64 + L] lane L's 16 bytes of the j-th LDS-direct load of a slab: place in its chain's B row (bits 0-7),
+//             that row's length (8-15; 0: a padding lane, no load), the chain's first A entry (16-21)
 // ---------------------------------------------------------------------------
-constexpr int kClassLaneInts = 256;
-constexpr unsigned kClassStart = 1u << 12, kClassIdleBit = 1u << 13, kClassDump = 1023u;
-constexpr unsigned kClassIdle = kClassStart | kClassIdleBit | (kClassDump << 16);   // descriptor of a lane without a product
+constexpr int kClassLaneInts = 512;
+constexpr int kClassMaxSteps = kClassMaxP / 64;                  // steps of the stored map
+constexpr int kClassMaxLoads = 4;                                // LDS-direct loads per slab (64 lanes x 16 bytes each)
 
 __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long* __restrict__ tableA,
                                                         const int* __restrict__ Ap, const int* __restrict__ Aj,
@@ -631,16 +636,19 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
     __syncthreads();
     bitonic();
     const int U = (P + 63) >> 6;
-    for (int idx = tid; idx < U * 64; idx += 256) {
-        const int L = idx & 63, u = idx >> 6;
+    const unsigned spare = (unsigned)nnz * (unsigned)sizeof(acc_t);           // the slot behind the row's entries
+    for (int idx = tid; idx < kClassMaxSteps * 64; idx += 256) {
+        const int L = idx & 63, u = (idx >> 6) - (kClassMaxSteps - U);         // (negative: not a step of this class)
         const int first = L * U, last = min(P, first + U) - 1;      // ranks this lane holds
         const int r = last - (U - 1 - u);                           // (right-aligned: idle steps first)
-        unsigned d = kClassIdle;
-        if (r >= first) {
+        unsigned d = spare | 0x80000000u;
+        if (u >= 0 && r >= first) {
             const int sv = srt[r], l = sv >> 10;
             const bool start = r == first || (srt[r - 1] >> 10) != l;
             const bool goesOn = l == (srt[last] >> 10) && last + 1 < P && (srt[last + 1] >> 10) == l;
-            d = (unsigned)pk[sv & 1023] | (start ? kClassStart : 0u) | ((goesOn ? kClassDump : (unsigned)l) << 16);
+            const unsigned code = (unsigned)pk[sv & 1023];          // A entry | B entry << 6
+            d = (goesOn ? spare : (unsigned)l * (unsigned)sizeof(acc_t)) | ((code & 63u) * (unsigned)sizeof(acc_t)) << 16 |
+                (code >> 6) << 25 | (start ? 0x80000000u : 0u);
         }
         classMap[(size_t)s * kClassMaxP + idx] = d;
     }
@@ -678,10 +686,18 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         const int myPlace = __shfl(place, tid < nA ? chain : 0, 64);
         classLane[(size_t)s * kClassLaneInts + 64 + tid] = tid < nA ? (myPlace | ((tid - opened) << 16) | (myLen << 24)) : 0;
         classLane[(size_t)s * kClassLaneInts + 128 + tid] = tid < nCh ? (kf | (len << 6) | (lc << 13) | (place << 20)) : 0;
+        for (int j = 0; j < kClassMaxLoads; ++j) {                             // this lane's pieces of a slab
+            const int x = (j * 64 + tid) * kClassEpl;
+            int c = 0;
+            for (int cc = 1; cc < nCh; ++cc) c += x >= __shfl(place, cc, 64) ? 1 : 0;
+            const int o = x - __shfl(place, c, 64), rowLen = __shfl(lc, c, 64), kFirst = __shfl(kf, c, 64);
+            const bool piece = x < slab && o < rowLen;
+            classLane[(size_t)s * kClassLaneInts + 256 + j * 64 + tid] = piece ? (o | (rowLen << 8) | (kFirst << 16)) : (kFirst << 16);
+        }
         if (tid == 0) {
             classLane[(size_t)s * kClassLaneInts + 192] = nCh | (maxLen << 8) | (slab << 16);
             // the ring of the ring kernel: (entries of the longest chain + 1) slabs; 4 x 64 lanes x 16 bytes per slab at most
-            atomicMax(&stats[CS_MAXRING], slab <= 4 * 64 * kClassEpl ? (maxLen + 1) * slab : 0x7fffffff);
+            atomicMax(&stats[CS_MAXRING], slab <= kClassMaxLoads * 64 * kClassEpl ? (maxLen + 1) * slab : 0x7fffffff);
             atomicMax(&stats[CS_MAXSLAB], slab);
         }
         int mx = myLen;

@@ -41,7 +41,7 @@ namespace bhs {
 #endif
 constexpr int kClassRun = BHS_CLS_RUN;                           // rows per run (metadata granularity; <= 63)
 constexpr int kClassSuper = BHS_CLS_SUPER;                       // consecutive rows a wave takes before it moves on
-constexpr int kClassMaxJ = 4;                                    // most LDS-direct load instructions per slab (64 lanes x 16 bytes each)
+constexpr int kClassMaxJ = kClassMaxLoads;                       // most LDS-direct load instructions per slab (64 lanes x 16 bytes each)
 static_assert(kClassSuper % kClassRun == 0, "whole runs");
 
 #ifndef BHS_CLS_LAB      // measurement builds only (tools/build_variants.sh): 1 no LDS-direct loads, 2 no stores of C (wrong results)
@@ -70,7 +70,6 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     acc_t* acc = reinterpret_cast<acc_t*>(smemRaw);
     acc_t* sAx = acc + accStride;                                // A values of the run at hand
     value_t* ring = reinterpret_cast<value_t*>(sAx + stageCap);
-    const unsigned dumpSlot = (unsigned)(accStride - 1);         // never read: idle lanes and partial sums that travel by the tail add
 
     // super-runs: XCD x takes [x * perX, (x + 1) * perX); block b runs on XCD b % 8
     constexpr int RPS = kClassSuper / kClassRun;                 // runs per super-run
@@ -111,10 +110,10 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     // begins), and the sign bit: the running sum restarts here.  A step without a product reads A's and the ring's first
     // value and stores to the dump slot; the product behind it restarts the sum.
     int desc[MAXU], rel[MAXV];
-    int ent = 0, chn = 0;                                        // the class's chain tables: this lane as A entry / as chain (k_class_patterns)
+    int ent = 0;                                                 // the class's chain table: this lane as A entry (k_class_patterns)
     // ... its slab as seen by this lane's share of the MAXJ load instructions: the chain's first A entry, the
     // lane's place in that chain's row (-1: a padding lane), the row's length
-    int dma[MAXJ];                                               // place in the chain's row (bits 0-7), row length (8-15, 0: padding lane), chain (16-21)
+    int dma[MAXJ];                                               // place in the chain's row (bits 0-7), row length (8-15, 0: padding lane), the chain's first A entry (16-21)
     // the ring: where this lane's next piece of a slab comes from, the slot it goes to, every product's place, the last row done
     unsigned src[MAXJ];                                          // (values of B are counted in int32: nnzB < 2^31)
     int loadSlot = 0, lastRow = -2, wrapB = 0;
@@ -206,52 +205,34 @@ __global__ __launch_bounds__(64) void k_class_numeric(
             if (cls != cur) {                                        // (wave-uniform)
                 cur = cls;
                 ringOK = false;
+                // every word of the class's tables is where the kernel can ask for it without knowing the class (right-aligned
+                // map, fixed places): one round trip
                 const int4 ci = classInfo[cls];
-                const int P = __builtin_amdgcn_readfirstlane(ci.y);   // (uniform anyway: tells the compiler so)
-                const int U = (P + 63) >> 6;
-                nnz = __builtin_amdgcn_readfirstlane(ci.z);
-                unsigned mp[MAXU];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u)                       // (the class's U steps are the LAST U of the MAXU)
-                    mp[u] = u >= MAXU - U ? classMap[(size_t)cls * kClassMaxP + (u - (MAXU - U)) * 64 + lane] : kClassIdle;
+                for (int u = 0; u < MAXU; ++u) desc[u] = (int)classMap[(size_t)cls * kClassMaxP + (kClassMaxSteps - MAXU + u) * 64 + lane];
                 tail = classLane[(size_t)cls * kClassLaneInts + lane];
                 ent = classLane[(size_t)cls * kClassLaneInts + 64 + lane];     // as A entry
-                chn = classLane[(size_t)cls * kClassLaneInts + 128 + lane];    // as chain
-                const int geo = __builtin_amdgcn_readfirstlane(classLane[(size_t)cls * kClassLaneInts + 192]);
+                const int geoV = classLane[(size_t)cls * kClassLaneInts + 192];
 #pragma unroll
-                for (int v = 0; v < MAXV; ++v) rel[v] = v * 64 + lane < nnz ? classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane] : 0;
+                for (int j = 0; j < MAXJ; ++j) dma[j] = classLane[(size_t)cls * kClassLaneInts + 256 + j * 64 + lane];
+#pragma unroll
+                for (int v = 0; v < MAXV; ++v) rel[v] = classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane];   // (beyond the row: never stored)
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
-                const int nCh = geo & 255;
+                nnz = __builtin_amdgcn_readfirstlane(ci.z);
+                const int geo = __builtin_amdgcn_readfirstlane(geoV);
                 slots = ((geo >> 8) & 255) + 1;                      // slabs a stretch starts with (rows 0 and 1 find theirs) = slots of
                                                                      // the ring: a row's request replaces the slab only that row still needed
                 slab = geo >> 16;
-                // every product's place in the ring at the stretch's first row: slot = its A entry's place in the chain
-                const unsigned accBase = (unsigned)(size_t)acc;      // (low half of a flat LDS address = the LDS byte address)
                 wrapB = slots * slab * (int)sizeof(value_t);
+                const unsigned accBase = (unsigned)(size_t)acc;      // (low half of a flat LDS address = the LDS byte address)
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) {
-                    const unsigned d = mp[u];
-                    const unsigned slot = (d >> 16) == kClassDump ? dumpSlot : (d >> 16);
-                    desc[u] = (int)((accBase + slot * (unsigned)sizeof(acc_t)) | ((d & 63u) * (unsigned)sizeof(acc_t)) << 16 |
-                                    ((d >> 6) & 63u) << 25 | ((d & kClassStart) ? 0x80000000u : 0u));
-                }
-                // this lane's pieces of a slab
-#pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {
-                    const int x = (j * 64 + lane) * kClassEpl;
-                    int c = 0;
-                    for (int cc = 1; cc < nCh; ++cc) c += x >= (__builtin_amdgcn_readlane(chn, cc) >> 20) ? 1 : 0;
-                    const int mine = __shfl(chn, c, 64);
-                    const int o = x - (mine >> 20), len = (mine >> 13) & 127;
-                    const bool piece = x < slab && o < len;
-                    dma[j] = piece ? (o | (len << 8) | (c << 16)) : (c << 16);
-                }
+                for (int u = 0; u < MAXU; ++u) desc[u] += (int)accBase;
                 BHS_TICK_CLS(1);
             }
             if (!ringOK || row != lastRow + 1) {                     // a stretch begins: its first slabs, all at once
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) {                     // the B row of the chain's first A entry, from its holder's register
-                    const int idx = offT + (__shfl(chn, dma[j] >> 16, 64) & 63);
+                    const int idx = offT + ((dma[j] >> 16) & 63);
                     int bo = 0;
 #pragma unroll
                     for (int i = 0; i < SE; ++i) {
