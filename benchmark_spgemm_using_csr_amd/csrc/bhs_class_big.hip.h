@@ -97,14 +97,19 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
     // products in a register and adds once.  T = 4, 3 or 2 if every group of the row qualifies, else 1.
     if (tid < 5) sGroup[tid] = nA % max(tid, 1) == 0 ? 1 : 0;
     __syncthreads();
-    for (int p = tid; p < P; p += NT) {
+    for (int k = 1 + tid; k < nA; k += NT) {                       // lengths, entry by entry (an empty B row has no product to speak for it)
+        const int lenK = sIncl[k] - sIncl[k - 1], lenPrev = sIncl[k - 1] - (k > 1 ? sIncl[k - 2] : 0);
+        if (lenK != lenPrev)
+            for (int T = 2; T <= 4; ++T)
+                if (k % T) sGroup[T] = 0;                          // (a benign race: every writer writes 0)
+    }
+    for (int p = tid; p < P; p += NT) {                            // columns, product by product
         const int k = entry_of(p);
         if (k == 0) continue;
         const int lenK = sIncl[k] - sIncl[k - 1], lenPrev = sIncl[k - 1] - (k > 1 ? sIncl[k - 2] : 0);
-        const bool twin = lenK == lenPrev && keys[p] == keys[p - lenPrev];     // (p - lenPrev: product e of entry k - 1)
-        if (!twin)
+        if (lenK == lenPrev && keys[p] != keys[p - lenPrev])       // (p - lenPrev: product e of entry k - 1)
             for (int T = 2; T <= 4; ++T)
-                if (k % T) sGroup[T] = 0;                          // (a benign race: every writer writes 0)
+                if (k % T) sGroup[T] = 0;
     }
     __syncthreads();
     const int T = sGroup[4] ? 4 : (sGroup[3] ? 3 : (sGroup[2] ? 2 : 1));

@@ -1103,6 +1103,53 @@ def test_row_class_path_randomized(oracle, seed):
     check_csr_invariants(m, n, Cp, Cj)
 
 
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_row_class_path_big_classes_randomized(oracle, seed):
+    """Classes beyond the register kernels' tables (bhs_class_big.hip.h) on randomised block-structured inputs: a random
+    stencil (x) ones(d, d) for d = 2 .. 4 -- rows of up to ~200 entries, thousands of products -- with some rows thinned
+    (groups of entries that do not qualify, rows that repeat nobody), some rows emptied, rectangular shapes, either sign."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(4000 + seed)
+    d = int(rng.choice([2, 3, 4]))
+    nodes_m, nodes_k, nodes_n = (int(rng.integers(150, 500)) for _ in range(3))
+    na = int(rng.choice([5, 9, 13, 21])); nb = int(rng.choice([5, 9, 13, 21]))
+    while (na * d) * (nb * d) > 8000:                      # (a class may have 8192 products)
+        na -= 1
+    spread = int(rng.choice([8, 12, 30]))                  # (offsets within +- spread nodes: the products overlap)
+
+    def blocks(rows, cols, cnt, noise):
+        offs = np.unique(rng.integers(-spread, spread + 1, cnt))
+        data, ri, ci = [], [], []
+        for i in range(rows):
+            c = i * cols // rows + offs
+            c = c[(c >= 0) & (c < cols)]
+            ri += [i] * len(c); ci += list(c)
+        P = sp.csr_matrix((np.ones(len(ri)), (ri, ci)), shape=(rows, cols))
+        M = sp.kron(P, np.ones((d, d)), format="lil")
+        for i in rng.integers(0, rows * d, max(1, int(noise * rows * d))):     # thinned / emptied scalar rows
+            cols_i = M.rows[i]
+            if len(cols_i) > 1:
+                keep = rng.random(len(cols_i)) < (0.0 if rng.random() < 0.2 else 0.7)
+                M.rows[i] = [c for c, kp in zip(cols_i, keep) if kp]
+                M.data[i] = [1.0] * len(M.rows[i])
+        M = M.tocsr(); M.sort_indices()
+        return M.indptr.astype(np.int32), M.indices.astype(np.int32)
+
+    Ap, Aj = blocks(nodes_m, nodes_k, na, 0.02)
+    Bp, Bj = blocks(nodes_k, nodes_n, nb, 0.02)
+    m, k, n = nodes_m * d, nodes_k * d, nodes_n * d
+    Ax = rng.integers(-9, 10, len(Aj)).astype(np.float64)
+    Bx = rng.integers(-9, 10, len(Bj)).astype(np.float64)
+    ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, options={"class_path": 2})
+    assert info["nnzCt"] == oracle.nnzCt(Ap, Aj, Bp) and info["nnzC"] == ref[0][-1]
+    res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+    assert res["ok"], (seed, d, na, nb, res, sorted(_kernel_names(info)))
+    check_csr_invariants(m, n, Cp, Cj)
+    print("big classes, seed %d: %d unknowns per node, %d x %d entries per row -> %s" % (
+        seed, d, na * d, nb * d, "numeric_class" if "numeric_class" in _kernel_names(info) else "general pipeline"))
+
+
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
 def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     """Inputs the class tables cannot take: more classes than table slots (unstructured rows), a class with more than
