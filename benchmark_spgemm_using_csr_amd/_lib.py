@@ -65,7 +65,7 @@ _lib = None
 _libs = {}
 
 
-SOURCES = ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_hub.hip.h", "bhs_class.hip.h", "bhs_class_wg.hip.h", "bhs_class_big.hip.h", "bhs_wave.hip.h")
+SOURCES = ("bhsparse_hip.hip", "bhs_kernels.hip.h", "bhs_hub.hip.h", "bhs_class.hip.h", "bhs_class_wg.hip.h", "bhs_class_big.hip.h", "bhs_wave.hip.h", "bhs_lab.hip.h")
 
 
 def source_digest():

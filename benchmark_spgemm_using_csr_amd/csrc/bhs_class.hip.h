@@ -758,13 +758,7 @@ __global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restri
 // with plain read-fma-write accumulation (3.5 ms: 56 partial-lane LDS instructions per row), the same with four
 // accumulator copies (3.9 ms), the same with atomics (4.0 ms).
 // ---------------------------------------------------------------------------
-#ifndef BHS_CLS_PARTS
-#define BHS_CLS_PARTS 1
-#endif
 constexpr unsigned kClassIdleA = 1u << 12;     // product triple of a lane without a product
-#ifndef BHS_CLS_STORE_SC1
-#define BHS_CLS_STORE_SC1 1
-#endif
 // Stores of C that do not stay in the XCD's L2 (sc1: write-through, the line is dropped).  The kernel writes 3.3 GB that
 // nobody reads again through a 4 MB L2 per XCD: with plain stores those lines push out the rows of B that the next
 // rows of A need again (measured: 5.2 GB read per launch where 1.2 GB is compulsory).

@@ -33,25 +33,11 @@ namespace bhs {
 // (profiles/r03_class_numeric_forms.md, which also has the forms of this kernel that staged whole stretches of rows
 // and were left with 4 to 6 waves per CU).
 // ---------------------------------------------------------------------------
-#ifndef BHS_CLS_RUN
-#define BHS_CLS_RUN 8
-#endif
-#ifndef BHS_CLS_SUPER
-#define BHS_CLS_SUPER 64
-#endif
 constexpr int kClassRun = BHS_CLS_RUN;                           // rows per run (metadata granularity; <= 63)
 constexpr int kClassSuper = BHS_CLS_SUPER;                       // consecutive rows a wave takes before it moves on
 constexpr int kClassMaxJ = kClassMaxLoads;                       // most LDS-direct load instructions per slab (64 lanes x 16 bytes each)
 static_assert(kClassSuper % kClassRun == 0, "whole runs");
 
-#ifndef BHS_CLS_LAB      // measurement builds only (tools/build_variants.sh): 1 no LDS-direct loads, 2 no stores of C (wrong results)
-#define BHS_CLS_LAB 0
-#endif
-#if BHS_PHASES_CLS      // measurement builds only (tools/phase_profile_cls.py): wave cycles per phase, summed by lane 0
-#define BHS_TICK_CLS(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPh; tPh = t__; } while (0)
-#else
-#define BHS_TICK_CLS(i) do { } while (0)
-#endif
 typedef __attribute__((address_space(3))) void bhs_lds_void;
 typedef __attribute__((address_space(1))) const void bhs_glb_void;
 __device__ __forceinline__ unsigned ringBaseOf(const value_t* ring) { return (unsigned)(size_t)ring; }

@@ -22,9 +22,6 @@
 
 namespace bhs {
 
-#ifndef BHS_HUB_PRECHECK
-#define BHS_HUB_PRECHECK 3
-#endif
 constexpr int kHubChunk = 512;            // A entries per chunk: their B-row lengths are prefix-summed in LDS
 constexpr int kHubBlock = 1024;           // lanes of the item kernels and of the bitmap sweeps
 constexpr int kHubMaxSeg = 64;            // bitmap segments per row (one workgroup each in count / emit)

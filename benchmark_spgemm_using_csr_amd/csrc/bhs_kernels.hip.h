@@ -17,35 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bhs_wave.hip.h"
-#ifndef BHS_ABL
-#define BHS_ABL 0
-#endif
-#ifndef BHS_ABL_SYM
-#define BHS_ABL_SYM 0
-#endif
-// measurement only: per-phase shader-clock accounting of the numeric wave kernel (tools/phase_profile.py)
-#ifndef BHS_PHASES
-#define BHS_PHASES 0
-#endif
-#ifndef BHS_PHASES_SPA
-#define BHS_PHASES_SPA 0
-#endif
-#ifndef BHS_PHASES_CLS
-#define BHS_PHASES_CLS 0
-#endif
-#if BHS_PHASES || BHS_PHASES_SPA || BHS_PHASES_CLS
-__device__ unsigned long long g_phase_cycles[16];
-#endif
-#if BHS_PHASES_SPA
-#define BHS_TICK_SPA(i) do { if (NUM && tid == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], t__ - tSpa); tSpa = t__; } } while (0)
-#else
-#define BHS_TICK_SPA(i) do { } while (0)
-#endif
-#if BHS_PHASES
-#define BHS_TICK(i) do { if (NUM) { const unsigned long long t__ = __builtin_readcyclecounter(); ph[i] += t__ - tPrev; tPrev = t__; } } while (0)
-#else
-#define BHS_TICK(i) do { } while (0)
-#endif
+#include "bhs_lab.hip.h"
 #include <stdint.h>
 #include <type_traits>
 
@@ -331,12 +303,6 @@ __global__ __launch_bounds__(256) void k_upper_bound_long_finish(const int2* __r
 // a block stay together so queue order stays close to row order (L2 locality
 // of the B rows they touch).
 // ---------------------------------------------------------------------------
-#ifndef BHS_FILL_ROUNDS
-#define BHS_FILL_ROUNDS 16
-#endif
-#ifndef BHS_FILL_NOSTATS
-#define BHS_FILL_NOSTATS 0
-#endif
 constexpr int kFillRounds = BHS_FILL_ROUNDS;     // rows per thread per reservation
 constexpr int kFillTile = 256 * kFillRounds;     // rows per block per global reservation
 
@@ -855,9 +821,6 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
     __shared__ int sBase[BLOCK];
     __shared__ int wtot[BLOCK / 64];
     __shared__ int bcast;
-#ifndef BHS_SPA_U
-#define BHS_SPA_U 4
-#endif
     constexpr int U = BHS_SPA_U, NW = BLOCK / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nWords = (int)((((long long)ncolsB + 31) >> 5) + 3) & ~3;   // slot stride: whole 16-byte groups
@@ -922,8 +885,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
 #endif
         // ---- pass 1: occupancy bits
         expand(a0, a1, [&](int c, long long, int) {
-            if (BHS_ABL & 4096) { if (c < 0) bits[0] = 1u; }   // measurement only (with 2048): no bit atomics
-            else atomicOr(&bits[c >> 5], 1u << (c & 31));
+            atomicOr(&bits[c >> 5], 1u << (c & 31));
         });
         // The slot is private to this workgroup and every access to it is served by this XCD's L2
         // (device-scope atomics, sc1 loads, write-through stores), so a workgroup barrier (which drains
@@ -999,14 +961,12 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
             __syncthreads();
             BHS_TICK_SPA(10);
             // ---- pass 2: every product lands in its final place
-            if (!(BHS_ABL & 2048))      // measurement only: 1024 = no adds, 2048 = no pass 2
             expand(a0, a1, [&](int c, long long idx, int l) {
                 const int w = c >> 5;
                 const unsigned word = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int pos = __hip_atomic_load(&rank[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
                                 __popc(word & ((1u << (c & 31)) - 1u));
-                if (BHS_ABL & 1024) { if (pos < 0) Cx[base] = sAv[l] * Bx[idx]; }
-                else unsafeAtomicAdd(&Cx[base + pos], (value_t)((acc_t)sAv[l] * (acc_t)Bx[idx]));
+                unsafeAtomicAdd(&Cx[base + pos], (value_t)((acc_t)sAv[l] * (acc_t)Bx[idx]));
             });
             __syncthreads();
             BHS_TICK_SPA(11);
@@ -1226,34 +1186,13 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
 //    dispatch order), so each XCD walks one contiguous eighth of the queue and
 //    neighbouring rows share B rows through that XCD's private L2.
 // ===========================================================================
-#ifndef BHS_WPB
-#define BHS_WPB 1
-#endif
-#ifndef BHS_XCD_CHUNK
-#define BHS_XCD_CHUNK 2048
-#endif
-#ifndef BHS_NT_STORES
-#define BHS_NT_STORES 0
-#endif
 // numeric loads: valB and the A value of a batch stay in registers and are multiplied when the batch is
 // inserted (1; 2 keeps the A entry index instead of its value; 0 = multiply behind the load, which makes every
 // valB load wait for its data before the next batch's loads are issued: measured 3.92 -> 3.80 ms on p27 128^3)
-#ifndef BHS_DEFER_MUL
-#define BHS_DEFER_MUL 1
-#endif
-#ifndef BHS_UNIFORM
-#define BHS_UNIFORM 1
-#endif
 // ask the register allocator for >= 5 waves per SIMD (<= 96 VGPRs).  With the deferred multiply the window
 // holds 6 x (col, valB, av) in registers; 6 waves (80 VGPRs) spill, measured 3.80 vs 3.49 ms.
-#ifndef BHS_WAVE_ATTR
-#define BHS_WAVE_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
-#endif
 // first probe = one ds_cmpst_rtn (claims an empty slot or returns the resident key) instead of
 // ds_read + conditional ds_cmpst: measured -19 % symbolic / -8 % numeric on poisson27pt
-#ifndef BHS_CAS_ONLY
-#define BHS_CAS_ONLY 1
-#endif
 constexpr int kWavesPerBlock = BHS_WPB;   // independent row-waves per workgroup (co-located on one CU)
 
 // Orders LDS traffic between the lanes of ONE wave: the LDS pipe executes a wave's DS
@@ -1267,18 +1206,6 @@ __device__ __forceinline__ void wave_sync()
 
 // product batches per window (MAXB x 64 products with their loads in flight): deeper for the symbolic pass
 // (one register per product), shallower for the numeric pass (three) so that it keeps 8 waves per SIMD
-#ifndef BHS_MAXB_SYM
-#define BHS_MAXB_SYM 12
-#endif
-#ifndef BHS_MAXB_NUM
-#define BHS_MAXB_NUM 6
-#endif
-#ifndef BHS_MAXB_LONG
-#define BHS_MAXB_LONG 12
-#endif
-#ifndef BHS_LONG_WAVES
-#define BHS_LONG_WAVES 4
-#endif
 constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = BHS_MAXB_LONG;
 constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // sizes the LDS mark words
 // Every window of a row costs one exposed memory round trip (~3 us on a loaded chip).  Rows of the 256-slot numeric
@@ -1286,9 +1213,6 @@ constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // si
 // thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
 // and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
 constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
-#ifndef BHS_NUM_WAVES
-#define BHS_NUM_WAVES 5
-#endif
 constexpr int wave_min_waves(int TS, bool NUM) { return !NUM ? 5 : (TS < 512 ? BHS_NUM_WAVES : (TS >= 1024 ? 3 : BHS_LONG_WAVES)); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
@@ -1505,9 +1429,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
     // upper-bound pass ran and no queue exists): queue entry q is row q, its descriptor comes from rowPtrA, and the
     // row's product count goes to ubOut[row] and into one of 64 spread counters (ctSlots), which is all the
     // upper-bound pass would have delivered.
-    // measurement-only ablation mask, compile time (tools/build_variants.sh builds variants with -DBHS_ABL=..):
-    // 1 no value atomics, 2 no sort, 4 no inserts, 8 no stores, 16 no colIndB load, 32 no valB load, 64 no sAv read
-    constexpr int abl = NUM ? BHS_ABL : BHS_ABL_SYM;
     using Smem = WaveSmem<TS, NUM, PACK32>;
     using packed_t = typename Smem::packed_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1715,7 +1636,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                             cum += __popcll(mk);
                         }
                         if (p < total) {
-                            if constexpr (SMALLB && BHS_DEFER_MUL == 1 && !(NUM ? BHS_ABL : BHS_ABL_SYM)) {
+                            if constexpr (SMALLB && BHS_DEFER_MUL == 1) {
                                 // nnz(B) < 2^29: byte offsets fit 32 bits, so the loads use SGPR base + 32-bit VGPR
                                 // offset addressing and the 64-bit address arithmetic per product disappears
                                 const unsigned idx32 = (unsigned)(sm.sBase[j] + p);
@@ -1730,8 +1651,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                                 continue;
                             }
                             const long long idx = (long long)sm.sBase[j] + p;
-                            if (abl & 16) col[u] = (p * 7) & 31;   // <= 32 distinct keys: never overflows
-                            else col[u] = Bj[idx];
+                            col[u] = Bj[idx];
                             if (NUM) {
 #if BHS_DEFER_MUL == 1
                                 avv[u] = sm.sAv[j];
@@ -1740,8 +1660,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                                 jjv[u] = j;
                                 bxv[u] = Bx[idx];
 #else
-                                const acc_t avj = (abl & 64) ? 1.0 : (acc_t)sm.sAv[j];
-                                pv[u] = (abl & 32) ? avj : avj * (acc_t)Bx[idx];
+                                pv[u] = (acc_t)sm.sAv[j] * (acc_t)Bx[idx];
 #endif
                             }
                         }
@@ -1753,14 +1672,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                 if (NUM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 BHS_TICK(2);
 #endif
-                if (abl & 4) {
-#pragma unroll
-                    for (int u = 0; u < MAXB; ++u) { asm volatile("" ::"v"(col[u])); if (NUM) asm volatile("" ::"v"(pv[u])); }
-                }
                 // ---- inserts, GRP batches at a time: first probes of a group are read back to back
 #pragma unroll
                 for (int g = 0; g < MAXB; g += GRP) {
-                    if (g < nb && !(abl & 4)) {
+                    if (g < nb) {
                         unsigned hh[GRP];
                         int cur[GRP];
 #pragma unroll
@@ -1806,7 +1721,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
 #elif BHS_DEFER_MUL == 2
                                 if (NUM) pv[g + v] = (acc_t)sm.sAv[jjv[g + v]] * (acc_t)bxv[g + v];
 #endif
-                                if (NUM && !(abl & 1)) unsafeAtomicAdd(&sm.vals[hh[v]], pv[g + v]);
+                                if (NUM) unsafeAtomicAdd(&sm.vals[hh[v]], pv[g + v]);
                             }
                         }
                     }
@@ -1867,21 +1782,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
             const int uniq = run;
             wave_sync();
             BHS_TICK(4);
-            if (abl & 2) {
-                if (!(abl & 8))
-                    for (int r = lane; r < uniq; r += 64) {
-                        const packed_t e = sm.packed[r];
-                        Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
-                        Cx[outBase + r] = (value_t)sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
-                    }
-            } else if (uniq <= 64)
+            if (uniq <= 64)
                 wave_sort_and_store<LOG2TS, PACK32, 1>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
             else if (TS >= 128 && uniq <= 128)
                 wave_sort_and_store<LOG2TS, PACK32, 2>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
-#ifndef BHS_NO_E4
             else if (TS >= 256 && uniq <= 256)
                 wave_sort_and_store<LOG2TS, PACK32, 4>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
-#endif
             else if (TS >= 512 && uniq <= 512)
                 wave_sort_and_store<LOG2TS, PACK32, 8>(sm.packed, sm.vals, uniq, lane, Cj, Cx, outBase);
             else if (TS >= 1024 && uniq <= 1024)
@@ -2456,9 +2362,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) BHS_WAVE_ATTR void k_row_wave_
 // ===========================================================================
 // SMALLB: nnz(B) < 2^29, so byte offsets into colIndB / valB fit 32 bits and the loads take the scalar base +
 // 32-bit lane offset form: no 64-bit address pair per head.
-#ifndef BHS_LANE_S
-#define BHS_LANE_S 16
-#endif
 // waves per SIMD asked of the register allocator (left alone it keeps both arms of every predicated load live:
 // 118 VGPRs for K = 6); the numeric pass is bounded by its LDS staging buffers (S = 16: 52 KB per workgroup)
 constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 ? 6 : 5) : (BHS_LANE_S == 16 ? 3 : BHS_LANE_S == 8 ? (K <= 10 ? 5 : 4) : (K <= 10 ? 7 : 4)); }

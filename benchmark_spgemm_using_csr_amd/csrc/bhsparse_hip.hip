@@ -384,9 +384,6 @@ int ensure_spa(bhs_handle* h)
 template <bool NUM>
 int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 {
-#ifndef BHS_SPA_BLOCK
-#define BHS_SPA_BLOCK 1024
-#endif
     constexpr int BLOCK = BHS_SPA_BLOCK;
     const long long grid = std::max<long long>(1, std::min<long long>(qn, h->spaSlots));
     int* small = (int*)h->small.p;

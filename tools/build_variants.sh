@@ -6,7 +6,7 @@ mkdir -p ../../gpurun_variants
 n=0
 for spec in "$@"; do
   name="${spec%%=*}"; flags="${spec#*=}"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fvisibility=hidden $flags -shared -o ../../gpurun_variants/$name.so bhsparse_hip.hip &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fvisibility=hidden -DBHS_LAB=1 $flags -shared -o ../../gpurun_variants/$name.so bhsparse_hip.hip &
   n=$((n+1)); if [ $((n % 3)) -eq 0 ]; then wait; fi
 done
 wait
