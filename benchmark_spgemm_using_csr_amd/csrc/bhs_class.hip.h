@@ -47,7 +47,7 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_MAXLB = 1 /* longest B row behind any class's A entries */, CS_MAXSLAB = 7 /* most values per slab */, CS_FLAGS = 2 /* 1 unclassified row, 2 class beyond the limits */, CS_MAXP = 3, CS_MAXNNZ = 4, CS_CLASSES = 5,
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
-       CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3,
+       CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3 /* words of their longest list */,
        CS_INTS = 8 + 2 * kClassSumSlots + 4 };
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)

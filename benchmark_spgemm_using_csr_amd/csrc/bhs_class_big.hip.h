@@ -7,7 +7,7 @@
 //   k_class_patterns_big   works the list out like k_class_patterns does (one workgroup per class: the representative
 //                          row's products, sorted and made unique -> the relative column list; then every product's
 //                          {A entry, B entry, position} word, in A-entry-major order) and leaves it in memory;
-//   k_class_numeric_big    a workgroup takes kClassBigRange consecutive rows and goes through them CLASS BY CLASS: the
+//   k_class_numeric_big    a workgroup takes a range of ~200 consecutive rows and goes through them CLASS BY CLASS: the
 //                          class's list is copied to LDS once and every wave multiplies rows of that class with it
 //                          (per 64 products: one LDS read of the list, the A value and B row start of the entry from
 //                          LDS, one gather of B's values -- consecutive lanes read consecutive entries of one B row --
@@ -18,8 +18,7 @@
 
 namespace bhs {
 
-constexpr int kClassBigRange = 192;        // consecutive rows a workgroup takes at a time (a multiple of 3 and 4 unknowns per node)
-constexpr int kClassBigWaves = 8;
+constexpr int kClassBigRangeMax = 224;     // consecutive rows a workgroup takes at a time: the largest multiple of (waves x rows per group) up to this
 constexpr int kClassBigPatThreads = 1024;
 
 // ---------------------------------------------------------------------------
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
     if (tid == 0) {
         classInfo[s] = make_int4(nA, P, nnz, rep);
         classBigIdx[s] = idx | (T << 16);
-        atomicMax(&stats[CS_BIGMAXP], P);
+        atomicMax(&stats[CS_BIGMAXP], P / T);                      // (the longest list, in words)
         atomicMax(&stats[CS_MAXNNZ], nnz);
         atomicMax(&stats[CS_MAXNA], nA);
         atomicAdd(&stats[CS_CLASSES], 1);
@@ -168,73 +167,111 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
 // ---------------------------------------------------------------------------
 // Numeric pass of a multiply that has big classes (all of its rows: a small class's list is read from classMapA in the
 // same way).  Workgroups are dealt to the XCDs so that each XCD's L2 sees one contiguous band of ranges.
-// LDS: per wave acc[accStride] + sAx[stageCap] (acc_t) and sBp[stageCap] (int); per workgroup the class's list
-// sDesc[descCap], its relative columns sRel[accStride], the classes of the range's rows and the rows of the class at hand.
+//
+// Rows in groups: the rmax unknowns of a node are rmax consecutive rows with the SAME columns of A -- the same B rows --
+// and word for word the same list (their classes differ only in the relative columns).  Where the pass finds such a
+// tuple of classes (lists compared word by word once per pass; the rows' A columns entry by entry for every group), a
+// wave takes the group's rows together: one gather of B's values serves all of them (rmax accumulator sets per wave).
+// A group whose rows do not share their columns after all is multiplied row by row.
+//
+// LDS: per wave acc[rmax][accStride] + sAx[rmax][stageCap] (acc_t) and sBp[stageCap] (int); per workgroup the class's
+// list sDesc[descCap], the relative columns sRel[rmax][accStride], the classes of the range's rows and the rows (group
+// leaders) of the pass at hand.
 // ---------------------------------------------------------------------------
-// the products of one row: list word = first A entry of the group | B entry << eShift | position << 16
-template <int T>
-__device__ __forceinline__ void class_big_row(const unsigned* sDesc, int words, int eShift, unsigned kMask, const acc_t* sAx,
-                                              const int* sBp, const value_t* __restrict__ Bx, acc_t* acc, int lane)
+constexpr int kClassBigMaxGroup = 4;
+
+// the products of R rows with the same A columns: list word = first A entry of the group | B entry << eShift | position << 16.
+// Two batches of 64 x UN words alternate: the gathers of one are in flight while the other is multiplied and added.
+template <int T, int R>
+__device__ __forceinline__ void class_big_rows(const unsigned* sDesc, int words, int eShift, unsigned kMask, const acc_t* sAx,
+                                               int stageCap, const int* sBp, const value_t* __restrict__ Bx, acc_t* acc,
+                                               int accStride, int lane)
 {
-    constexpr int UN = T >= 3 ? 2 : 4;                             // (8 to 4 loads in flight per lane)
-    for (int base = 0; base < words; base += 64 * UN) {
-        unsigned d[UN];
-        acc_t a[UN][T], b[UN][T];
+    constexpr int UN = T >= 3 ? 2 : 4;                             // (6 to 8 loads per lane and batch)
+    auto load = [&](int base, unsigned (&d)[UN], acc_t (&b)[UN][T]) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) d[u] = sDesc[min(base + u * 64 + lane, words - 1)];
+        for (int u = 0; u < UN; ++u) d[u] = sDesc[min(base + u * 64 + lane, words - 1)];   // (beyond the list: its last word again)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = (int)(d[u] & kMask), e = (int)((d[u] >> eShift) & kMask);
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                b[u][t] = (acc_t)Bx[sBp[k + t] + e];
-                a[u][t] = sAx[k + t];
-            }
+            for (int t = 0; t < T; ++t) b[u][t] = (acc_t)Bx[sBp[k + t] + e];
         }
+    };
+    auto add = [&](int base, const unsigned (&d)[UN], const acc_t (&b)[UN][T]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            acc_t v = a[u][0] * b[u][0];
+            const int k = (int)(d[u] & kMask);
+            const bool valid = base + u * 64 + lane < words;
 #pragma unroll
-            for (int t = 1; t < T; ++t) v = __builtin_fma(a[u][t], b[u][t], v);
-            if (base + u * 64 + lane < words) unsafeAtomicAdd(&acc[d[u] >> 16], v);
+            for (int r = 0; r < R; ++r) {
+                acc_t v = sAx[r * stageCap + k] * b[u][0];
+#pragma unroll
+                for (int t = 1; t < T; ++t) v = __builtin_fma(sAx[r * stageCap + k + t], b[u][t], v);
+                if (valid) unsafeAtomicAdd(&acc[r * accStride + (d[u] >> 16)], v);
+            }
         }
+    };
+    unsigned d0[UN], d1[UN];
+    acc_t b0[UN][T], b1[UN][T];
+    constexpr int STEP = 64 * UN;
+    load(0, d0, b0);
+    for (int base = 0; base < words; base += 2 * STEP) {
+        load(base + STEP, d1, b1);
+        add(base, d0, b0);
+        if (base + STEP >= words) break;
+        load(base + 2 * STEP, d0, b0);
+        add(base + STEP, d1, b1);
     }
 }
 
-__global__ __launch_bounds__(64 * kClassBigWaves) void k_class_numeric_big(
+template <int R>
+__device__ __forceinline__ void class_big_rows_t(int T, const unsigned* sDesc, int words, int eShift, unsigned kMask, const acc_t* sAx,
+                                                 int stageCap, const int* sBp, const value_t* __restrict__ Bx, acc_t* acc,
+                                                 int accStride, int lane)
+{
+    if (T == 1) class_big_rows<1, R>(sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+    else if (T == 2) class_big_rows<2, R>(sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+    else if (T == 3) class_big_rows<3, R>(sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+    else class_big_rows<4, R>(sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+}
+
+__global__ __launch_bounds__(1024) void k_class_numeric_big(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classMapA, const int* __restrict__ classBigIdx,
     const unsigned* __restrict__ bigMap, const int* __restrict__ classRel, const int* __restrict__ Cp,
     int* __restrict__ Cj, value_t* __restrict__ Cx, int accStride, int stageCap, int descCap,
+    int rmax, int range,                                           // rows per group (1: none), rows per range (<= blockDim.x)
     int rowBase)                                                   // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
-    constexpr int NT = 64 * kClassBigWaves;
+    const int NT = blockDim.x, NW = NT >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    acc_t* acc = reinterpret_cast<acc_t*>(smemRaw) + (size_t)wv * (accStride + stageCap);
-    acc_t* sAx = acc + accStride;
-    int* ints = reinterpret_cast<int*>(reinterpret_cast<acc_t*>(smemRaw) + (size_t)kClassBigWaves * (accStride + stageCap));
+    const int perWave = rmax * (accStride + stageCap);
+    acc_t* acc = reinterpret_cast<acc_t*>(smemRaw) + (size_t)wv * perWave;
+    acc_t* sAx = acc + rmax * accStride;
+    int* ints = reinterpret_cast<int*>(reinterpret_cast<acc_t*>(smemRaw) + (size_t)NW * perWave);
     int* sBp = ints + wv * stageCap;
-    unsigned* sDesc = reinterpret_cast<unsigned*>(ints + kClassBigWaves * stageCap);
+    unsigned* sDesc = reinterpret_cast<unsigned*>(ints + NW * stageCap);
     int* sRel = reinterpret_cast<int*>(sDesc + descCap);
-    int* sCls = sRel + accStride;
-    int* sList = sCls + kClassBigRange;
-    int* sMisc = sList + kClassBigRange;                           // [0] first row without a result, [1..] rows of the class per wave
-    for (int i = lane; i < accStride; i += 64) acc[i] = 0.0;
+    int* sCls = sRel + rmax * accStride;
+    int* sList = sCls + range;
+    int* sMisc = sList + range;                                    // [0] first row without a result, [1..] leaders per wave
+    for (int i = lane; i < rmax * accStride; i += 64) acc[i] = 0.0;
 
-    const int nRanges = (m + kClassBigRange - 1) / kClassBigRange;
+    const int nRanges = (m + range - 1) / range;
     const int xcd = blockIdx.x & 7, perX = (nRanges + 7) / 8, wgPerX = gridDim.x >> 3;
     for (int i = blockIdx.x >> 3; i < perX; i += wgPerX) {
         const int rg = xcd * perX + i;
         if (rg >= nRanges) break;
-        const int row0 = rg * kClassBigRange, nr = min(kClassBigRange, m - row0);
+        const int row0 = rg * range, nr = min(range, m - row0);
         __syncthreads();                                           // (the range before is done with sCls)
-        for (int t = tid; t < kClassBigRange; t += NT) sCls[t] = t < nr ? classC[row0 + t] : -1;
+        for (int t = tid; t < range; t += NT) sCls[t] = t < nr ? classC[row0 + t] : -1;
         for (;;) {
             if (tid == 0) sMisc[0] = 0x7fffffff;
             __syncthreads();
-            for (int t = tid; t < kClassBigRange; t += NT)
+            for (int t = tid; t < range; t += NT)
                 if (sCls[t] >= 0) atomicMin(&sMisc[0], t);
             __syncthreads();
             const int first = sMisc[0];
@@ -248,45 +285,90 @@ __global__ __launch_bounds__(64 * kClassBigWaves) void k_class_numeric_big(
             const unsigned* list = big ? bigMap + (size_t)(bi & 0xFFFF) * kClassBigMaxP : classMapA + (size_t)cls * kClassMaxP;
             const int eShift = big ? 8 : 6;
             const unsigned kMask = big ? 255u : 63u;
+            // a tuple of classes for rows in groups: the rmax rows from `first` on, if their tables are this class's
+            int R = 1, cj[kClassBigMaxGroup] = {cls, -1, -1, -1};
+            if (rmax > 1 && big && first + rmax <= nr) {
+                bool ok = true;
+                const unsigned* lj[kClassBigMaxGroup] = {list, list, list, list};
+                for (int j = 1; j < rmax; ++j) {
+                    cj[j] = sCls[first + j];
+                    ok = ok && cj[j] >= 0;
+                    for (int jj = 0; jj < j; ++jj) ok = ok && cj[j] != cj[jj];      // (distinct: no row leads two groups)
+                    if (ok) {
+                        const int4 c2 = classInfo[cj[j]];
+                        const int b2 = classBigIdx[cj[j]];
+                        ok = b2 >= 0 && (b2 >> 16) == T && c2.x == nA && c2.y == P && c2.z == nnz;
+                        lj[j] = bigMap + (size_t)(b2 & 0xFFFF) * kClassBigMaxP;
+                    }
+                }
+                int same = 1;
+                if (ok)
+                    for (int p = tid; p < words; p += NT) {
+                        const unsigned w0 = list[p];
+                        for (int j = 1; j < rmax; ++j) same &= lj[j][p] == w0 ? 1 : 0;
+                    }
+                if (__syncthreads_and(ok && same)) R = rmax;       // (ok is workgroup-uniform)
+            }
             for (int p = tid; p < words; p += NT) sDesc[p] = list[p];
-            for (int e = tid; e < nnz; e += NT) sRel[e] = classRel[(size_t)cls * kClassMaxNnz + e];
-            // the rows of this class, in order (kClassBigRange <= 64 * kClassBigWaves: one row per thread)
-            const bool match = tid < kClassBigRange && sCls[tid] == cls;
-            const unsigned long long mm = __ballot(match);
+            for (int j = 0; j < R; ++j)
+                for (int e = tid; e < nnz; e += NT) sRel[j * accStride + e] = classRel[(size_t)cj[j] * kClassMaxNnz + e];
+            // the (leading) rows of this pass, in order (range <= blockDim.x: one row per thread)
+            bool lead = tid < range && tid + R <= nr && sCls[tid] == cls;
+            for (int j = 1; j < R; ++j) lead = lead && sCls[min(tid + j, range - 1)] == cj[j];
+            const unsigned long long mm = __ballot(lead);
             if (lane == 0) sMisc[1 + wv] = __popcll(mm);
             __syncthreads();
             int before = 0, cnt = 0;
-#pragma unroll
-            for (int w = 0; w < kClassBigWaves; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const int c = sMisc[1 + w];
                 before += w < wv ? c : 0;
                 cnt += c;
             }
-            if (match) {
+            if (lead) {
                 sList[before + __popcll(mm & ((1ull << lane) - 1ull))] = tid;
-                sCls[tid] = -1;
+                for (int j = 0; j < R; ++j) sCls[tid + j] = -1;
             }
             __syncthreads();
-            for (int q = wv; q < cnt; q += kClassBigWaves) {
+            for (int q = wv; q < cnt; q += NW) {
                 const int row = row0 + sList[q];
-                const int a0 = Ap[row];
-                const long long out = Cp[row];
+                int a0[kClassBigMaxGroup];
+                for (int r = 0; r < R; ++r) a0[r] = Ap[row + r];
+                bool twins = true;
                 for (int e = lane; e < nA; e += 64) {
-                    const int aj = Aj[a0 + e];
-                    sAx[e] = (acc_t)Ax[a0 + e];
+                    const int aj = Aj[a0[0] + e];
+                    sAx[e] = (acc_t)Ax[a0[0] + e];
                     sBp[e] = Bp[aj];
+                    for (int r = 1; r < R; ++r) {
+                        twins = twins && Aj[a0[r] + e] == aj;
+                        sAx[r * stageCap + e] = (acc_t)Ax[a0[r] + e];
+                    }
+                }
+                twins = __all(twins);
+                wave_sync();
+                if (R == 1) class_big_rows_t<1>(T, sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+                else if (twins) {
+                    if (R == 2) class_big_rows_t<2>(T, sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+                    else if (R == 3) class_big_rows_t<3>(T, sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+                    else class_big_rows_t<4>(T, sDesc, words, eShift, kMask, sAx, stageCap, sBp, Bx, acc, accStride, lane);
+                } else {
+                    for (int r = 0; r < R; ++r) {                  // (same list, other B rows: one row at a time)
+                        if (r) {
+                            wave_sync();
+                            for (int e = lane; e < nA; e += 64) sBp[e] = Bp[Aj[a0[r] + e]];
+                            wave_sync();
+                        }
+                        class_big_rows_t<1>(T, sDesc, words, eShift, kMask, sAx + r * stageCap, stageCap, sBp, Bx, acc + r * accStride, accStride, lane);
+                    }
                 }
                 wave_sync();
-                if (T == 1) class_big_row<1>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
-                else if (T == 2) class_big_row<2>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
-                else if (T == 3) class_big_row<3>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
-                else class_big_row<4>(sDesc, words, eShift, kMask, sAx, sBp, Bx, acc, lane);
-                wave_sync();
-                for (int e = lane; e < nnz; e += 64) {
-                    const acc_t v = acc[e];
-                    acc[e] = 0.0;
-                    class_store_c(&Cj[out + e], sRel[e] + row + rowBase);
-                    class_store_c(&Cx[out + e], (value_t)v);
+                for (int r = 0; r < R; ++r) {
+                    const long long out = Cp[row + r];
+                    for (int e = lane; e < nnz; e += 64) {
+                        const acc_t v = acc[r * accStride + e];
+                        acc[r * accStride + e] = 0.0;
+                        class_store_c(&Cj[out + e], sRel[r * accStride + e] + row + r + rowBase);
+                        class_store_c(&Cx[out + e], (value_t)v);
+                    }
                 }
                 wave_sync();
             }

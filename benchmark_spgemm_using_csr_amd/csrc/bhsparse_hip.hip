@@ -466,20 +466,33 @@ int launch_class_numeric_big(bhs_handle* h, int r0, int r1)
     auto kern = k_class_numeric_big;
     const int accStride = (h->ps.classMaxNnz + 3) & ~3, stageCap = (h->ps.classMaxNA + 3) & ~3;
     const int descCap = (std::max(h->ps.classMaxP, h->ps.classBigMaxP) + 3) & ~3;
-    const size_t smem = (size_t)kClassBigWaves * ((size_t)(accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int)) +
-                        sizeof(int) * ((size_t)descCap + accStride + 2 * kClassBigRange + 16);
+    // rows per group: the period sampled at hand-over time (the unknowns of a node share their columns of A); waves per
+    // workgroup: twelve when the groups' accumulator sets still fit the LDS, else eight, else no groups
+    int rmax = h->periodA >= 2 && h->periodA <= kClassBigMaxGroup ? h->periodA : 1, waves = 8;
+    auto lds = [&](int rm, int wv, int range) {
+        return (size_t)wv * ((size_t)rm * (accStride + stageCap) * sizeof(acc_t) + (size_t)stageCap * sizeof(int)) +
+               sizeof(int) * ((size_t)descCap + (size_t)rm * accStride + 2 * (size_t)range + 32);
+    };
+    auto range_of = [&](int rm, int wv) { return kClassBigRangeMax / (wv * rm) * (wv * rm); };
+    const size_t ldsMax = 160 * 1024;
+    if (rmax > 1) {
+        if (lds(rmax, 12, range_of(rmax, 12)) <= ldsMax) waves = 12;
+        else if (lds(rmax, 8, range_of(rmax, 8)) > ldsMax) rmax = 1;
+    }
+    const int range = range_of(rmax, waves);
+    const size_t smem = lds(rmax, waves, range);
     int perCU = 1;
-    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * kClassBigWaves, smem, &perCU));
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64 * waves, smem, &perCU));
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     const int mR = r1 - r0;
-    const long long nRanges = ((long long)mR + kClassBigRange - 1) / kClassBigRange;
+    const long long nRanges = ((long long)mR + range - 1) / range;
     long long grid = std::min<long long>(nRanges, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    if (h->verbose > 1) printf("  [class numeric (big): %d workgroups per CU, %zu bytes of LDS each, grid %lld]\n", perCU, smem, grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kClassBigWaves), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+    if (h->verbose > 1) printf("  [class numeric (big): rows in groups of %d, %d waves per workgroup, ranges of %d rows, %d workgroups per CU, %zu bytes of LDS each, grid %lld]\n", rmax, waves, range, perCU, smem, grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        h->dBp, h->dBx, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p, (const unsigned*)h->classMapA.p,
                        (const int*)h->classBigIdx.p, (const unsigned*)h->classBigMap.p, (const int*)h->classRel.p,
-                       (const int*)h->Cp.p + r0, out_cj(h), out_cx(h), accStride, stageCap, descCap, r0);
+                       (const int*)h->Cp.p + r0, out_cj(h), out_cx(h), accStride, stageCap, descCap, rmax, range, r0);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measurement helper: per-phase workgroup cycles of numeric_long_rows (library built with -DBHS_PHASES=1)."""
+"""Measurement helper: per-phase workgroup cycles of numeric_long_rows (library built with -DBHS_PHASES_SPA=1 by tools/build_variants.sh; BHSPARSE_HIP_LIB=gpurun_variants/phspa.so)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ m = Bp.numel() - 1
 plats = [False] * 9; plats[3] = True
 bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
-raw = C.CDLL(_lib.SO_PATH)
+raw = C.CDLL(os.environ.get("BHSPARSE_HIP_LIB", _lib.SO_PATH))
 buf = (C.c_ulonglong * 16)()
 print("data ready", flush=True)
 for _ in range(2): assert bh.spgemm() == 0
