@@ -328,7 +328,9 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
 
 constexpr int kClassHeadSegs = 8;
 constexpr int kClassHeadsBlock = 1024;
-constexpr int kClassHeadPiece = 256;                               // rows per wave: its first is a head by decree
+constexpr int kClassHeadPiece = 256;                               // most rows per wave (its first is a head by decree)
+// ... fewer where a row takes many lanes: a wave walks its piece pass by pass, three dependent round trips each
+constexpr int class_head_piece(int G) { return G >= 64 ? 64 : (G >= 32 ? 128 : kClassHeadPiece); }
 template <bool IS_A, int G, int E>
 __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                      const int* __restrict__ classB, int* __restrict__ classOut,
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);               // consecutive rows per lane group
     constexpr int RPW = GPW * R;                                   // consecutive rows per wave and pass
     constexpr int WPB = kClassHeadsBlock / 64;
-    __shared__ int sList[WPB * kClassHeadPiece], sCount, sBase;    // the block's heads
+    constexpr int PIECE = class_head_piece(G);
+    __shared__ int sList[WPB * PIECE], sCount, sBase;              // the block's heads
     const int lane = threadIdx.x & 63, g = lane % G, grp = lane / G;
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (lane - g);
     long long first = 0;
@@ -352,14 +355,14 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
     const long long wave = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
-    const long long pieceBegin = first + wave * kClassHeadPiece;
-    const long long pieceEnd = min((long long)nrows, pieceBegin + kClassHeadPiece);
+    const long long pieceBegin = first + wave * PIECE;
+    const long long pieceEnd = min((long long)nrows, pieceBegin + PIECE);
     bool okP = false;                                              // the pass before's last row (lane g of every group)
     int lenP = 0, elP[E], cbP[E], followP = -1;
 #pragma unroll
     for (int e = 0; e < E; ++e) { elP[e] = 0; cbP[e] = 0; }
     // the wave walks its piece as `period` sequences, one after the other: position q of sequence `seq` = row pieceBegin + q * period + seq
-    const int perSeq = (kClassHeadPiece + period - 1) / period;
+    const int perSeq = (PIECE + period - 1) / period;
     for (int seq = 0; seq < period; ++seq) {
     auto row_at = [&](int q) { return pieceBegin + (long long)q * period + seq; };
     followP = -1;

@@ -1126,8 +1126,8 @@ int symbolic_class(bhs_handle* h)
 #define BHS_CLASS_ROWS(ISA, G, E, grid, n, Rp, Rj, cb, tab, out, rng, heads, nheads)                                  \
     do {                                                                                                              \
         if (h->classHeadsOn) {                                                                                        \
-            hipLaunchKernelGGL((k_class_heads<ISA, G, E>), dim3(heads_grid(n)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out, heads, nheads, heads_cap(n), rng, std::max(1, std::min(8, ISA ? h->periodA : h->periodB))); \
-            hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3((unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs)), kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, (const int*)nullptr, (const int*)heads, (const int*)nheads, heads_cap(n)); \
+            hipLaunchKernelGGL((k_class_heads<ISA, G, E>), dim3(heads_grid(n, G)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out, heads, nheads, heads_cap(n, G), rng, std::max(1, std::min(8, ISA ? h->periodA : h->periodB))); \
+            hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3((unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs)), kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, (const int*)nullptr, (const int*)heads, (const int*)nheads, heads_cap(n, G)); \
             hipLaunchKernelGGL(k_class_propagate, dim3((unsigned)std::max<long long>(1, std::min<long long>(((long long)(n) + 255) / 256, (long long)h->numCU * 8))), dim3(256), 0, h->stream, n, out, rng); \
         } else                                                                                                        \
             hipLaunchKernelGGL((k_class_rows<ISA, G, E>), dim3(grid), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out, cstats, rng, (const int*)nullptr, (const int*)nullptr, 0); \
@@ -1143,8 +1143,8 @@ int symbolic_class(bhs_handle* h)
     auto rows_grid = [&](int n, int G) {
         return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
-    auto heads_grid = [&](int n) { const long long perBlock = (long long)(kClassHeadsBlock / 64) * kClassHeadPiece; return (unsigned)std::max<long long>(1, ((long long)n + perBlock - 1) / perBlock); };
-    auto heads_cap = [&](int n) { return (int)(((long long)heads_grid(n) + kClassHeadSegs - 1) / kClassHeadSegs) * (kClassHeadsBlock / 64) * kClassHeadPiece; };    // slots per list
+    auto heads_grid = [&](int n, int G) { const long long perBlock = (long long)(kClassHeadsBlock / 64) * class_head_piece(G); return (unsigned)std::max<long long>(1, ((long long)n + perBlock - 1) / perBlock); };
+    auto heads_cap = [&](int n, int G) { return (int)(((long long)heads_grid(n, G) + kClassHeadSegs - 1) / kClassHeadSegs) * (kClassHeadsBlock / 64) * class_head_piece(G); };    // slots per list
     // A as a row block of a larger product (multi-GPU): only the rows of B that A points at need a class
     const int* bRange = nullptr;
     if ((long long)m * 2 <= (long long)k) {
