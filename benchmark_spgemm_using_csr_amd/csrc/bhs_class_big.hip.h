@@ -20,6 +20,7 @@ namespace bhs {
 
 constexpr int kClassBigRangeMax = 224;     // consecutive rows a workgroup takes at a time: the largest multiple of (waves x rows per group) up to this
 constexpr int kClassBigPatThreads = 1024;
+constexpr int kClassBigSpan = 1 << 18;      // widest span of a class's relative columns that is ranked with a bitmap (32 KB of bits)
 
 // ---------------------------------------------------------------------------
 // classInfo[s].z == -2 (k_class_patterns found the class beyond its tables): {A entry (8 bits), B entry (8), position (16)}
@@ -112,6 +113,42 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
     }
     __syncthreads();
     const int T = sGroup[4] ? 4 : (sGroup[3] ? 3 : (sGroup[2] ? 2 : 1));
+    // The distinct keys in ascending order -> ulist.  A class's relative columns span a few thousand values (a grid's
+    // neighbours of neighbours): a presence bitmap over [smallest, largest] ranks them with a dozen barriers; a wider
+    // span takes the bitonic sort (91 barriers for 8192 keys).
+    int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+    for (int p = tid; p < P; p += NT) { lo = min(lo, keys[p]); hi = max(hi, keys[p]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((tid & 63) == 0) { scan[tid >> 6] = lo; scan[NT / 64 + (tid >> 6)] = hi; }
+    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w) { lo = min(lo, scan[w]); hi = max(hi, scan[NT / 64 + w]); }
+    __syncthreads();
+    const long long span = P > 0 ? (long long)hi - lo + 1 : 0;
+    int nnz = 0;
+    if (span <= kClassBigSpan) {
+        unsigned* bits = reinterpret_cast<unsigned*>(srt);          // (srt is free on this path: kClassBigSpan / 32 words)
+        const int nw = (int)((span + 31) >> 5), wpt = (nw + NT - 1) / NT;
+        for (int w = tid; w < nw; w += NT) bits[w] = 0u;
+        __syncthreads();
+        for (int p = tid; p < P; p += NT) atomicOr(&bits[(keys[p] - lo) >> 5], 1u << ((keys[p] - lo) & 31));
+        __syncthreads();
+        int mine = 0;
+        for (int w = tid * wpt; w < (tid + 1) * wpt && w < nw; ++w) mine += __popc(bits[w]);
+        scan[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < NT; o <<= 1) {
+            const int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        nnz = scan[NT - 1];
+        if (nnz > kClassMaxNnz) { fail(); return; }
+        int at = scan[tid] - mine;
+        for (int w = tid * wpt; w < (tid + 1) * wpt && w < nw; ++w)
+            for (unsigned mm = bits[w]; mm; mm &= mm - 1) ulist[at++] = lo + (w << 5) + (__ffs((int)mm) - 1);
+    } else {
     for (int kk = 2; kk <= N2; kk <<= 1)                           // ascending bitonic sort of srt[0, N2)
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < N2; i += NT) {
@@ -136,12 +173,13 @@ __global__ __launch_bounds__(kClassBigPatThreads) void k_class_patterns_big(cons
         scan[tid] += add;
         __syncthreads();
     }
-    const int nnz = scan[NT - 1];
+    nnz = scan[NT - 1];
     if (nnz > kClassMaxNnz) { fail(); return; }
-    if (tid == 0) sIdx = atomicAdd(&stats[CS_BIGCOUNT], 1);
     int at = scan[tid] - heads;
     for (int i = tid * per; i < (tid + 1) * per && i < P; ++i)
         if (i == 0 || srt[i] != srt[i - 1]) ulist[at++] = srt[i];
+    }
+    if (tid == 0) sIdx = atomicAdd(&stats[CS_BIGCOUNT], 1);
     __syncthreads();
     const int idx = sIdx;
     if (idx >= kClassBigCap) { fail(); return; }
