@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void k_class_propagate(int nrows, int* __restr
 //             that row's length (8-15; 0: a padding lane, no load), the chain's first A entry (16-21)
 // ---------------------------------------------------------------------------
 constexpr int kClassLaneInts = 512;
+constexpr int kClassSpanWords = 4096;                            // k_class_patterns ranks relative columns with a bitmap of this many words where their span fits
 constexpr int kClassMaxSteps = kClassMaxP / 64;                  // steps of the stored map
 constexpr int kClassMaxLoads = 4;                                // LDS-direct loads per slab (64 lanes x 16 bytes each)
 
@@ -600,28 +601,68 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         pk[p] = code;
     }
     __syncthreads();
-    bitonic();
-    // distinct keys: thread t owns srt[t * per .. (t + 1) * per)
-    const int per = (N2 + 255) / 256;
-    int heads = 0;
-    for (int i = tid * per; i < (tid + 1) * per && i < P; ++i) heads += (i == 0 || srt[i] != srt[i - 1]) ? 1 : 0;
-    scan[tid] = heads;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int add = tid >= o ? scan[tid - o] : 0;
-        __syncthreads();
-        scan[tid] += add;
-        __syncthreads();
-    }
-    const int nnz = scan[255];
-    if (nnz > kClassMaxNnz) {
-        if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
-        return;
-    }
+    // The distinct keys in ascending order -> ulist: ranked with a presence bitmap over [smallest, largest] where that
+    // span fits (a grid's neighbours of neighbours: 66 K values on a 128^3 grid), else sorted.
     __shared__ int ulist[kClassMaxNnz];
-    int at = scan[tid] - heads;
-    for (int i = tid * per; i < (tid + 1) * per && i < P; ++i)
-        if (i == 0 || srt[i] != srt[i - 1]) ulist[at++] = srt[i];
+    __shared__ unsigned bits[kClassSpanWords];
+    int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+    for (int p = tid; p < P; p += 256) { lo = min(lo, keys[p]); hi = max(hi, keys[p]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((tid & 63) == 0) { scan[tid >> 6] = lo; scan[4 + (tid >> 6)] = hi; }
+    __syncthreads();
+    lo = min(min(scan[0], scan[1]), min(scan[2], scan[3]));
+    hi = max(max(scan[4], scan[5]), max(scan[6], scan[7]));
+    __syncthreads();
+    const long long span = P > 0 ? (long long)hi - lo + 1 : 0;
+    int nnz = 0;
+    if (span <= (long long)kClassSpanWords * 32) {
+        const int nw = (int)((span + 31) >> 5), wpt = (nw + 255) / 256;
+        for (int w = tid; w < nw; w += 256) bits[w] = 0u;
+        __syncthreads();
+        for (int p = tid; p < P; p += 256) atomicOr(&bits[(keys[p] - lo) >> 5], 1u << ((keys[p] - lo) & 31));
+        __syncthreads();
+        int mine = 0;
+        for (int w = tid * wpt; w < (tid + 1) * wpt && w < nw; ++w) mine += __popc(bits[w]);
+        scan[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        nnz = scan[255];
+        if (nnz > kClassMaxNnz) {
+            if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
+            return;
+        }
+        int at = scan[tid] - mine;
+        for (int w = tid * wpt; w < (tid + 1) * wpt && w < nw; ++w)
+            for (unsigned mm = bits[w]; mm; mm &= mm - 1) ulist[at++] = lo + (w << 5) + (__ffs((int)mm) - 1);
+    } else {
+        bitonic();
+        // distinct keys: thread t owns srt[t * per .. (t + 1) * per)
+        const int per = (N2 + 255) / 256;
+        int heads = 0;
+        for (int i = tid * per; i < (tid + 1) * per && i < P; ++i) heads += (i == 0 || srt[i] != srt[i - 1]) ? 1 : 0;
+        scan[tid] = heads;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        nnz = scan[255];
+        if (nnz > kClassMaxNnz) {
+            if (tid == 0) { classInfo[s] = make_int4(nA, P, -1, rep); atomicOr(&stats[CS_FLAGS], 2); }
+            return;
+        }
+        int at = scan[tid] - heads;
+        for (int i = tid * per; i < (tid + 1) * per && i < P; ++i)
+            if (i == 0 || srt[i] != srt[i - 1]) ulist[at++] = srt[i];
+    }
     __syncthreads();
     for (int e = tid; e < nnz; e += 256) classRel[(size_t)s * kClassMaxNnz + e] = ulist[e];
     // second sort: the products by (position, product number) -- position << 10 | product
