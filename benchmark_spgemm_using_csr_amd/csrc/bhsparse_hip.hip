@@ -141,7 +141,7 @@ struct bhs_handle {
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
-    int classGridMul = 4, classPerLane = 2, classMinProducts = 256;   // tuning hooks of k_class_rows
+    int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
     int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
     int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
@@ -1250,14 +1250,16 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     SymChoices sc;
     // Row classes first, for data sets whose rows are short on both sides (the hint from bhs_set_data time is
     // verified on the device row by row)
-    // ... and long enough for the classification passes to pay: poisson27pt (729 products per row) runs 4.85 -> 3.1 ms
-    // on the class kernels, poisson9pt (81) 0.58 -> 0.88 ms -- its whole general pipeline costs less than classifying
+    // ... and long enough for the classification passes to pay (round 3's kernels, same box): poisson27pt (729 products
+    // per row) 4.85 -> 2.1 ms on the class kernels, poisson9pt 1024^2 (81) 0.57 -> 0.47 ms, poisson7pt 128^3 (49) 0.73 ->
+    // 0.78 ms, poisson5pt 1024^2 (25) 0.23 -> 0.42 ms: from class_min_products = 64 products per row on
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
                           h->maxRowA <= kClassMaxRowBig && h->maxRowB <= kClassMaxRowBig &&
                           (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
                                                  // ... and enough of them: every block of the classifier meets every class once
-                                                 // (poisson27pt 51^3, 90 M products: 0.46 ms general, 0.50 ms by classes)
-                                                 (double)h->m * h->avgRowA * h->avgRowB >= 2.5e8));
+                                                 // (poisson27pt 51^3, 90 M products: 0.44 ms general, 0.41 ms by classes;
+                                                 // poisson9pt 512^2, 21 M: 0.20 against 0.25)
+                                                 (double)h->m * h->avgRowA * h->avgRowB >= 6e7));
     if (useClass) {
         BHS_TRY(symbolic_class(h));
         sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)

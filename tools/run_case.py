@@ -18,7 +18,8 @@ else:
     st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)), "p27_256": ("poisson27pt", (256, 256, 256)), "p5_1024": ("poisson5pt", (1024, 1024, 1)),
                 "p7_128": ("poisson7pt", (128, 128, 128)), "p9_1024": ("poisson9pt", (1024, 1024, 1)),
                 "p27_slab16": ("poisson27pt", (16, 16, 8192)), "p27_slab32": ("poisson27pt", (32, 32, 2048)),
-                "p27_slab64": ("poisson27pt", (64, 64, 512))}[name]
+                "p27_slab64": ("poisson27pt", (64, 64, 512)), "p27_51": ("poisson27pt", (51, 51, 51)), "p27_72": ("poisson27pt", (72, 72, 72)),
+                "p9_256": ("poisson9pt", (256, 256, 1)), "p9_512": ("poisson9pt", (512, 512, 1))}[name]
     Bp, Bj = gallery.poisson_csr_torch(st, *dims, device=dev)
     Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
 f32 = os.environ.get('BHS_F32') == '1'
