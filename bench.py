@@ -38,7 +38,8 @@ def workload_dims(name, world):
         return "poisson27pt", dims, "weak"
     table = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)),
              "p27_256": ("poisson27pt", (256, 256, 256)), "p27_51": ("poisson27pt", (51, 51, 51)),
-             "p5_1024": ("poisson5pt", (1024, 1024, 1)), "p5_256": ("poisson5pt", (256, 256, 1))}
+             "p5_1024": ("poisson5pt", (1024, 1024, 1)), "p5_256": ("poisson5pt", (256, 256, 1)),
+             "p9_1024": ("poisson9pt", (1024, 1024, 1))}
     st, dims = table[name]
     return st, dims, "strong"
 
@@ -423,9 +424,15 @@ def main():
         bh.free_mem()
         del Ap, Aj, Ax, Bp, Bj, Bx
         torch.cuda.empty_cache()
-        for wname in ("p5_1024", "p27_160"):
-            st2, d2, _ = workload_dims(wname, 1)
-            bp2, bj2 = gallery.poisson_csr_torch(st2, *d2, device=dev)
+        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40"):
+            if wname == "fem3_40":      # 3 unknowns per node on poisson27pt 40^3, every coupling a full block
+                st2, d2 = "poisson27pt (x) ones(3,3)", (40, 40, 40)
+                rp0, col0 = gallery.poisson_csr("poisson27pt", 40, 40, 40)
+                rp3, col3 = gallery.block_expand_csr(rp0, col0, 3)
+                bp2, bj2 = torch.from_numpy(rp3).to(dev), torch.from_numpy(col3).to(dev)
+            else:
+                st2, d2, _ = workload_dims(wname, 1)
+                bp2, bj2 = gallery.poisson_csr_torch(st2, *d2, device=dev)
             bx2 = gallery.fill_values_torch(int(bj2.numel()), device=dev)
             ap2, aj2, ax2 = bp2.clone(), bj2.clone(), bx2.clone()
             m2 = int(bp2.numel()) - 1

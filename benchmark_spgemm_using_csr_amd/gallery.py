@@ -127,6 +127,22 @@ def fill_values_torch(nnz, seed=SEED, offset=0, device="cuda"):
     return (1 + hi % 9).to(torch.float64)
 
 
+def block_expand_csr(rp, col, dof):
+    """(rp, col) (x) ones(dof, dof): the pattern of a grid with `dof` unknowns per node, every coupling a full block
+    (the 3-dof FEM stand-in of DESIGN.md: poisson27pt, 40^3 nodes, dof 3).  Rows and columns of node i are
+    i * dof .. i * dof + dof - 1; columns ascending."""
+    rp = np.asarray(rp, np.int64)
+    col = np.asarray(col, np.int64)
+    nnz_node = np.diff(rp)
+    row0 = np.repeat(col * dof, dof) + np.tile(np.arange(dof, dtype=np.int64), len(col))   # a node's first row, all nodes
+    new_len = np.repeat(nnz_node * dof, dof)                       # entries of every scalar row
+    new_rp = np.zeros(len(new_len) + 1, np.int64)
+    np.cumsum(new_len, out=new_rp[1:])
+    seg_start = np.repeat(rp[:-1] * dof, dof)                      # where that row's copy of row0 begins
+    idx = np.arange(new_rp[-1], dtype=np.int64) - np.repeat(new_rp[:-1], new_len) + np.repeat(seg_start, new_len)
+    return new_rp.astype(np.int32), row0[idx].astype(np.int32)
+
+
 def dense_rows_csr(n, per_row=8, dense=4, dense_nnz=200000, seed=SEED):
     """Seeded sparse square pattern (about per_row uniformly random entries per row) with `dense` rows of dense_nnz
     entries spread evenly over the matrix: in A^2 each of them carries about dense_nnz x per_row products, and every
