@@ -217,3 +217,22 @@ def test_oracle_equals_reference_opencl_digests(oracle, tag, gen):
     assert int((Cj.astype(np.uint64) * t).sum()) == ref["wsum_col"]
     assert float(Cx.sum()) == ref["sum_val"] and float((Cx * t.astype(np.float64)).sum()) == ref["wsum_val"]
     assert oracle.nnzCt(rp, col, rp) == ref["nnzCt"]
+
+
+@pytest.mark.parametrize("dof", [1, 2, 3, 4])
+def test_block_expand_is_the_kronecker_product_with_ones(oracle, dof):
+    """gallery.block_expand_csr (the 3-dof FEM stand-in of bench.py and tools/) == scipy's kron(P, ones(dof, dof)),
+    and its square through the oracle has dof^2 entries for every entry of the node-level square."""
+    import scipy.sparse as sp
+    rp, col = gallery.poisson_csr("poisson27pt", 5, 4, 3)
+    m0 = len(rp) - 1
+    rpb, colb = gallery.block_expand_csr(rp, col, dof)
+    P = sp.csr_matrix((np.ones(len(col)), col, rp), shape=(m0, m0))
+    M = sp.kron(P, np.ones((dof, dof)), format="csr")
+    M.sort_indices()
+    assert np.array_equal(rpb, M.indptr) and np.array_equal(colb, M.indices)
+    val = gallery.fill_values(len(colb))
+    m = m0 * dof
+    Cp, Cj, Cx = oracle.spgemm(m, m, m, rpb, colb, val, rpb, colb, val)
+    node = oracle.spgemm(m0, m0, m0, rp, col, np.ones(len(col)), rp, col, np.ones(len(col)))
+    assert Cp[-1] == node[0][-1] * dof * dof
