@@ -1209,11 +1209,13 @@ __device__ __forceinline__ void wave_sync()
 constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = BHS_MAXB_LONG;
 constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // sizes the LDS mark words
 // Every window of a row costs one exposed memory round trip (~3 us on a loaded chip).  Rows of the 256-slot numeric
-// tables have two windows of 6 batches and live on occupancy (5 waves per SIMD); rows of the larger tables have
+// tables live on occupancy: 5 batches and 6 waves per SIMD (80 VGPRs, no spills) since round 3 -- poisson27pt 128^3
+// numeric_wave<256> 3.43 -> 3.01 ms, 72^3 1.04 -> 0.88 (6 batches at 5 waves: the round-2 setting; 6 at 6: 3.78; 4 at 6:
+// 3.33; anything at 7 or 8 waves spills and takes 4.8 - 6 ms); rows of the larger tables have
 // thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
 // and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
 constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
-constexpr int wave_min_waves(int TS, bool NUM) { return !NUM ? 5 : (TS < 512 ? BHS_NUM_WAVES : (TS >= 1024 ? 3 : BHS_LONG_WAVES)); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
+constexpr int wave_min_waves(int TS, bool NUM) { return !NUM ? BHS_SYM_WAVES : (TS < 512 ? BHS_NUM_WAVES : (TS >= 1024 ? 3 : BHS_LONG_WAVES)); }   // 1024 slots: 3 waves, no spills (3.59 -> 3.48 ms on the 4-dof case)
 
 // PACK32: sort keys are (col << LOG2TS | slot) in 32 bits (legal when every column < 2^(32-LOG2TS));
 // otherwise (col << 32 | slot) in 64 bits.

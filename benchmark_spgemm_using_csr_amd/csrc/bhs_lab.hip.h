@@ -26,6 +26,7 @@
 #undef BHS_MAXB_LONG
 #undef BHS_LONG_WAVES
 #undef BHS_NUM_WAVES
+#undef BHS_SYM_WAVES
 #undef BHS_LANE_S
 #undef BHS_CLS_PARTS
 #undef BHS_CLS_STORE_SC1
@@ -79,7 +80,7 @@
 #define BHS_MAXB_SYM 12
 #endif
 #ifndef BHS_MAXB_NUM      // ... numeric wave kernel
-#define BHS_MAXB_NUM 6
+#define BHS_MAXB_NUM 5
 #endif
 #ifndef BHS_MAXB_LONG      // ... workgroup kernels
 #define BHS_MAXB_LONG 12
@@ -87,8 +88,11 @@
 #ifndef BHS_LONG_WAVES      // workgroup kernels: waves per SIMD asked of the register allocator
 #define BHS_LONG_WAVES 4
 #endif
+#ifndef BHS_SYM_WAVES      // symbolic wave kernel: waves per SIMD asked of the register allocator
+#define BHS_SYM_WAVES 5
+#endif
 #ifndef BHS_NUM_WAVES      // numeric wave kernel: the same
-#define BHS_NUM_WAVES 5
+#define BHS_NUM_WAVES 6
 #endif
 #ifndef BHS_LANE_S      // lane-per-row numeric kernel: LDS staging entries per lane
 #define BHS_LANE_S 16
