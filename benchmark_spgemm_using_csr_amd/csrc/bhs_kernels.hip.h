@@ -1210,8 +1210,8 @@ constexpr int kMaxBSym = BHS_MAXB_SYM, kMaxBNum = BHS_MAXB_NUM, kMaxBNumLong = B
 constexpr int kMaxB = kMaxBSym > kMaxBNumLong ? kMaxBSym : kMaxBNumLong;   // sizes the LDS mark words
 // Every window of a row costs one exposed memory round trip (~3 us on a loaded chip).  Rows of the 256-slot numeric
 // tables live on occupancy: 5 batches and 6 waves per SIMD (80 VGPRs, no spills) since round 3 -- poisson27pt 128^3
-// numeric_wave<256> 3.43 -> 3.01 ms, 72^3 1.04 -> 0.88 (6 batches at 5 waves: the round-2 setting; 6 at 6: 3.78; 4 at 6:
-// 3.33; anything at 7 or 8 waves spills and takes 4.8 - 6 ms); rows of the larger tables have
+// numeric_wave<256> 3.43 -> 3.36 ms, 72^3 1.04 -> 0.98 (6 batches at 5 waves: the round-2 setting; 6 at 6: 3.78; 4 at 6:
+// 3.33; anything at 7 or 8 waves spills and takes 4.8 - 6 ms: the kernel does not fit 64 VGPRs); rows of the larger tables have
 // thousands of products -- a 3-dof FEM row: 6561, i.e. 18 windows of 6 -- and do better with 12 batches in flight
 // and 4 waves per SIMD (numeric_wave<512> on that matrix: 4.88 -> 3.14 ms; poisson27pt would lose 4 %).
 constexpr int wave_window_batches(int TS, bool NUM) { return !NUM ? kMaxBSym : (TS >= 512 ? kMaxBNumLong : kMaxBNum); }
@@ -1682,6 +1682,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                         int cur[GRP];
 #pragma unroll
                         for (int v = 0; v < GRP; ++v) {
+                            if (g + v >= MAXB) continue;             // (a last group of fewer batches: folded at compile time)
                             hh[v] = hash_col(col[g + v], LOG2TS);
                             cur[v] = kEmpty;
 #if BHS_CAS_ONLY
@@ -1692,6 +1693,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                         }
 #pragma unroll
                         for (int v = 0; v < GRP; ++v) {
+                            if (g + v >= MAXB) continue;
                             const int cv = col[g + v];
                             if (cv != kEmpty) {
                                 bool ok = cur[v] == cv;
