@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
     bool same = row - d >= 0 && row < nrows;
     if (same) {
         const int a0 = Rp[row], len = Rp[row + 1] - a0, b0 = Rp[row - d];
-        same = Rp[row - d + 1] - b0 == len && len > 0;
+        same = Rp[row - d + 1] - b0 == len && len > 0 && len <= kClassMaxRowBig;   // (longer rows never classify: no walk through a hub row)
         for (int e = 0; same && e < len; ++e) same = Rj[a0 + e] - (int)row == Rj[b0 + e] - (int)(row - d);
     }
     const unsigned long long votes = __ballot(same);
