@@ -16,7 +16,7 @@
 //   k_class_rows<true>   class id of every row of A: the same over the list of (relative column, class of that B row)
 //   k_class_patterns     per class: the products of the representative row, sorted and made unique -> relative column
 //                        list, entry count, and for every product its {A entry, B entry, position} triple
-//   k_class_counts       rowPtrC counts: the class's entry count
+//   k_class_scan         rowPtrC: the class's entry count of every row, scanned in one pass (look-back over tiles)
 //   k_class_numeric      per row: 1 load of A's entries and rowPtrB, then every product is one load of B's value and
 //                        one fma into a REGISTER: a lane holds consecutive products of the class's position-sorted
 //                        product list, so the products of one entry of C meet in one lane; the running sums go to
@@ -48,7 +48,8 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_MAXNA = 6 /* longest A row of any class */,
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
        CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3 /* words of their longest list */,
-       CS_INTS = 8 + 2 * kClassSumSlots + 4 };
+       CS_SCANTICKET = 8 + 2 * kClassSumSlots + 4 /* tile numbers of k_class_scan */,
+       CS_INTS = 8 + 2 * kClassSumSlots + 5 };
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 {
@@ -758,31 +759,87 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
     }
 }
 
-__global__ __launch_bounds__(256) void k_class_counts(int m, const int* __restrict__ classC,
-                                                      const int4* __restrict__ classInfo, int* __restrict__ cnt,
-                                                      int* __restrict__ stats)
+// ---------------------------------------------------------------------------
+// rowPtrC in one pass: the class's entry count of every row, scanned (replaces k_class_counts + the three scan kernels
+// of the general pipeline on the class path; create_C's host scan in the reference, bhsparse_cuda.h:2783-2811).
+// Tiles of kClassScanTile rows in ticket order; a tile publishes its sum, then its first wave looks back over its
+// predecessors 64 at a time -- a sum (flag 1) is added, a running total (flag 2) ends the walk -- and publishes its own
+// running total.  state[tile] = flag << 62 | value, written and read with relaxed device-scope atomics (one word: no
+// ordering between words is needed).  A tile only waits for tiles with smaller tickets, which are running.
+// ---------------------------------------------------------------------------
+constexpr int kClassScanPer = 8, kClassScanTile = 256 * kClassScanPer;
+__global__ __launch_bounds__(256) void k_class_scan(int m, const int* __restrict__ classC, const int4* __restrict__ classInfo,
+                                                    int* __restrict__ Cp, unsigned long long* __restrict__ state,
+                                                    long long* __restrict__ totalOut, int* __restrict__ stats)
 {
-    __shared__ unsigned long long wsum[4];
+    __shared__ int sTile, wsum[4];
+    __shared__ long long sPrefix;
+    __shared__ unsigned long long wprod[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sTile = atomicAdd(&stats[CS_SCANTICKET], 1);
+    __syncthreads();
+    const int tile = sTile;
+    const long long base = (long long)tile * kClassScanTile + (long long)tid * kClassScanPer;
+    int v[kClassScanPer], mine = 0;
     unsigned long long products = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256) {
-        const int c = classC[i];
-        int v = 0;
+    bool pending = false;
+#pragma unroll
+    for (int j = 0; j < kClassScanPer; ++j) {
+        v[j] = 0;
+        const int c = base + j < m ? classC[base + j] : -1;
         if (c >= 0) {
             const int4 ci = classInfo[c];
-            v = ci.z;
+            v[j] = ci.z > 0 ? ci.z : 0;
             products += (unsigned long long)ci.y;
-            if (v == -2) atomicOr(&stats[CS_FLAGS], 2);           // (a big class nobody worked out: stale hints)
+            pending = pending || ci.z == -2;
         }
-        cnt[i] = v > 0 ? v : 0;
+        mine += v[j];
     }
+    if (pending) atomicOr(&stats[CS_FLAGS], 2);                    // (a big class nobody worked out: stale hints)
+    const int incl = wave_incl_scan_dpp(mine);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) products += __shfl_xor(products, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = products;
+    if (lane == 63) wsum[wv] = incl;
+    if (lane == 0) wprod[wv] = products;
     __syncthreads();
-    // the product total (nnzCt of the reference's stage 1) over kClassSumSlots counters: one address would queue
-    if (threadIdx.x == 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (blockIdx.x % kClassSumSlots),
-                  wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    int before = 0, tileSum = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { before += w < wv ? wsum[w] : 0; tileSum += wsum[w]; }
+    constexpr unsigned long long kVal = (1ull << 62) - 1ull;
+    if (wv == 0) {
+        long long run = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&state[tile], (1ull << 62) | (unsigned long long)tileSum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int back = tile - 1; back >= 0;) {               // (wave-uniform)
+                const int p = back - lane;
+                unsigned long long st = 2ull << 62;               // (before the first tile: a running total of 0)
+                if (p >= 0) st = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long unset = __ballot((st >> 62) == 0), total = __ballot((st >> 62) == 2);
+                const int firstTotal = total ? __ffsll((long long)total) - 1 : 64;      // nearest predecessor with a running total
+                if (unset & ((firstTotal < 64 ? (2ull << firstTotal) : 0ull) - 1ull)) continue;      // one of the nearer ones has not published: again
+                long long part = lane <= firstTotal ? (long long)(st & kVal) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                run += part;
+                if (firstTotal < 64) break;
+                back -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&state[tile], (2ull << 62) | (unsigned long long)(run + tileSum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sPrefix = run;
+        }
+    }
+    __syncthreads();
+    long long at = sPrefix + before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < kClassScanPer; ++j) {
+        if (base + j < m) Cp[base + j] = (int)at;
+        at += v[j];
+    }
+    if (base <= m - 1 && m - 1 < base + kClassScanPer) { Cp[m] = (int)at; *totalOut = at; }   // (the thread of the last row)
+    if (tid == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (tile % kClassSumSlots), wprod[0] + wprod[1] + wprod[2] + wprod[3]);
 }
 
 // ---------------------------------------------------------------------------

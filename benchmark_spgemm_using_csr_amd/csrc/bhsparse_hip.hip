@@ -1118,7 +1118,6 @@ int symbolic_class(bhs_handle* h)
     unsigned long long* tabA = tabB + kClassSlots;
     int* cstats = small + S_CT_SLOTS;
     BHS_TRY(timed_begin(h, "classify_rows", &ep));
-    const unsigned gA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 8));
     // lanes per row: the average row, rounded up to a power of two
     // Three launches per matrix: k_class_heads lists the rows that differ from the row before them (and notes for
     // every other row which head it follows), k_class_rows classifies the listed rows, k_class_propagate hands the
@@ -1203,11 +1202,9 @@ int symbolic_class(bhs_handle* h)
                            h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p, (int*)h->classBigIdx.p,
                            (unsigned*)h->classBigMap.p, (int*)h->classRel.p, cstats);
     }
-    hipLaunchKernelGGL(k_class_counts, dim3(gA), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
-                       (const int4*)h->classInfo.p, (int*)h->Cp.p, cstats);
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
-    h->stats[ep->stat].launches += bigPossible ? 3 : 2;
+    h->stats[ep->stat].launches += bigPossible ? 2 : 1;
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
     return BHS_SUCCESS;
 }
@@ -1273,6 +1270,18 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
 
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
+    if (useClass) {
+        // one pass: every row's count from its class, scanned with look-back over the tiles before (k_class_scan)
+        const int nTiles = (m + kClassScanTile - 1) / kClassScanTile;
+        BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nTiles, nScanBlocks)));
+        BHS_HIP(hipMemsetAsync(h->blockSum.p, 0, sizeof(unsigned long long) * (size_t)nTiles, h->stream));
+        hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
+                           (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
+                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS);
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches += 1;
+    } else {
     hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
                        (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
@@ -1282,6 +1291,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches += 3;
+    }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     if (useClass) {
