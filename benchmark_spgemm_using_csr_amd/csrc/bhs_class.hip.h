@@ -762,19 +762,20 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
 // ---------------------------------------------------------------------------
 // rowPtrC in one pass: the class's entry count of every row, scanned (replaces k_class_counts + the three scan kernels
 // of the general pipeline on the class path; create_C's host scan in the reference, bhsparse_cuda.h:2783-2811).
-// Tiles of kClassScanTile rows in ticket order; a tile publishes its sum, then its first wave looks back over its
+// Tiles of kClassScanTile (8192) rows in ticket order; a tile publishes its sum, then its first wave looks back over its
 // predecessors 64 at a time -- a sum (flag 1) is added, a running total (flag 2) ends the walk -- and publishes its own
 // running total.  state[tile] = flag << 62 | value, written and read with relaxed device-scope atomics (one word: no
 // ordering between words is needed).  A tile only waits for tiles with smaller tickets, which are running.
 // ---------------------------------------------------------------------------
-constexpr int kClassScanPer = 8, kClassScanTile = 256 * kClassScanPer;
-__global__ __launch_bounds__(256) void k_class_scan(int m, const int* __restrict__ classC, const int4* __restrict__ classInfo,
+constexpr int kClassScanBlock = 1024, kClassScanPer = 8, kClassScanTile = kClassScanBlock * kClassScanPer;   // (few tiles: short look-backs)
+__global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int* __restrict__ classC, const int4* __restrict__ classInfo,
                                                     int* __restrict__ Cp, unsigned long long* __restrict__ state,
                                                     long long* __restrict__ totalOut, int* __restrict__ stats)
 {
-    __shared__ int sTile, wsum[4];
+    constexpr int NW = kClassScanBlock / 64;
+    __shared__ int sTile, wsum[NW];
     __shared__ long long sPrefix;
-    __shared__ unsigned long long wprod[4];
+    __shared__ unsigned long long wprod[NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) sTile = atomicAdd(&stats[CS_SCANTICKET], 1);
     __syncthreads();
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256) void k_class_scan(int m, const int* __restrict
     __syncthreads();
     int before = 0, tileSum = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { before += w < wv ? wsum[w] : 0; tileSum += wsum[w]; }
+    for (int w = 0; w < NW; ++w) { before += w < wv ? wsum[w] : 0; tileSum += wsum[w]; }
     constexpr unsigned long long kVal = (1ull << 62) - 1ull;
     if (wv == 0) {
         long long run = 0;
@@ -838,8 +839,11 @@ __global__ __launch_bounds__(256) void k_class_scan(int m, const int* __restrict
         at += v[j];
     }
     if (base <= m - 1 && m - 1 < base + kClassScanPer) { Cp[m] = (int)at; *totalOut = at; }   // (the thread of the last row)
-    if (tid == 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (tile % kClassSumSlots), wprod[0] + wprod[1] + wprod[2] + wprod[3]);
+    if (tid == 0) {
+        unsigned long long all = 0;
+        for (int w = 0; w < NW; ++w) all += wprod[w];
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (tile % kClassSumSlots), all);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -1275,7 +1275,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         const int nTiles = (m + kClassScanTile - 1) / kClassScanTile;
         BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nTiles, nScanBlocks)));
         BHS_HIP(hipMemsetAsync(h->blockSum.p, 0, sizeof(unsigned long long) * (size_t)nTiles, h->stream));
-        hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(256), 0, h->stream, m, (const int*)h->classC.p,
+        hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(kClassScanBlock), 0, h->stream, m, (const int*)h->classC.p,
                            (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
                            (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS);
         BHS_HIP(hipGetLastError());
