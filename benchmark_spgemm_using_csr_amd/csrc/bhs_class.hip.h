@@ -304,6 +304,22 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 // entry by entry, like the table's.  The heads go to kClassHeadSegs lists, a block's with one atomic (a single
 // counter bumped once per wave queues for most of a millisecond).
 // ---------------------------------------------------------------------------
+// Everything the class path wants cleared at the start of a multiply, in one launch (six memsets before): the counter
+// block, the class statistics, the head counters, both class tables (all ones = empty), the big classes' index (all
+// ones = none) and the scan's tile words.
+__global__ __launch_bounds__(256) void k_class_reset(int* __restrict__ small, int nSmall, int* __restrict__ cstats, int nStats,
+                                                     int* __restrict__ headCnt, int nHead, unsigned long long* __restrict__ tab, int nTab,
+                                                     int* __restrict__ bigIdx, int nBig, unsigned long long* __restrict__ scanState, int nScan)
+{
+    const int i0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+    for (int i = i0; i < nSmall; i += step) small[i] = 0;
+    for (int i = i0; i < nStats; i += step) cstats[i] = 0;
+    for (int i = i0; i < nHead; i += step) headCnt[i] = 0;
+    for (int i = i0; i < nTab; i += step) tab[i] = kClassEmpty;
+    for (int i = i0; i < nBig; i += step) bigIdx[i] = -1;
+    for (int i = i0; i < nScan; i += step) scanState[i] = 0ull;
+}
+
 // The period hint: eight rows spread over the matrix, each compared with the rows 1 .. 8 before it; the smallest
 // distance at which a sample repeats, by majority (1 when there is none).  One wave, at hand-over time.
 __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out)

@@ -1104,15 +1104,14 @@ int symbolic_class(bhs_handle* h)
     // classes beyond the register kernels' tables are possible: their lists and the big numeric kernel (bhs_class_big.hip.h)
     const bool bigPossible = h->maxRowA > kClassMaxRow || h->maxRowB > kClassMaxRow || (long long)h->maxRowA * h->maxRowB > kClassMaxP;
     BHS_TRY(ensure(h, h->classBigIdx, sizeof(int) * kClassSlots));
-    if (bigPossible) {
-        BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
-        BHS_HIP(hipMemsetAsync(h->classBigIdx.p, 0xFF, sizeof(int) * kClassSlots, h->stream));
-    }
+    if (bigPossible) BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
     BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
-    BHS_HIP(hipMemsetAsync(h->classHeadCnt.p, 0, sizeof(int) * 2 * 16 * kClassHeadSegs, h->stream));
-    BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
-    BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * CS_INTS, h->stream));
-    BHS_HIP(hipMemsetAsync(h->classTab.p, 0xFF, sizeof(unsigned long long) * 2 * kClassSlots, h->stream));
+    const int nScanTiles = (m + kClassScanTile - 1) / kClassScanTile;           // (k_class_scan's tile words live in blockSum)
+    BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nScanTiles, (int)(((long long)m + 1 + kScanTile - 1) / kScanTile))));
+    hipLaunchKernelGGL(k_class_reset, dim3(32), dim3(256), 0, h->stream, small, (int)S_ZERO_END, small + S_CT_SLOTS, (int)CS_INTS,
+                       (int*)h->classHeadCnt.p, 2 * 16 * kClassHeadSegs, (unsigned long long*)h->classTab.p, 2 * kClassSlots,
+                       (int*)h->classBigIdx.p, bigPossible ? kClassSlots : 0, (unsigned long long*)h->blockSum.p, nScanTiles);
+    BHS_HIP(hipGetLastError());
     for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
     unsigned long long* tabB = (unsigned long long*)h->classTab.p;
     unsigned long long* tabA = tabB + kClassSlots;
@@ -1273,8 +1272,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     if (useClass) {
         // one pass: every row's count from its class, scanned with look-back over the tiles before (k_class_scan)
         const int nTiles = (m + kClassScanTile - 1) / kClassScanTile;
-        BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nTiles, nScanBlocks)));
-        BHS_HIP(hipMemsetAsync(h->blockSum.p, 0, sizeof(unsigned long long) * (size_t)nTiles, h->stream));
+        // (blockSum holds the tile words, cleared by k_class_reset)
         hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(kClassScanBlock), 0, h->stream, m, (const int*)h->classC.p,
                            (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
                            (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS);
