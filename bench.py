@@ -44,8 +44,43 @@ def workload_dims(name, world):
     return st, dims, "strong"
 
 
-def reference_opencl_leg(m, rp, col, val, nnzCt):
-    """One C = A^2 of the same matrix through oracle/_ref/ref_opencl_spgemm (the reference's SpGEMM_opencl, unmodified)."""
+def gpu_state():
+    """Clocks, power and temperature of GPU 0 as rocm-smi reports them (None where it cannot be asked): recorded before
+    and after the timed loop so that a run-to-run difference can be told from a different state of the GPU."""
+    import subprocess
+    try:
+        p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        card = next(iter(json.loads(p.stdout).values()))
+        out = {}
+        for key, val in card.items():
+            kl = key.lower()
+            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "temperature" in kl or "performance level" in kl:
+                out[key] = val
+        return out or None
+    except Exception as e:
+        return {"error": str(e)[-120:]}
+
+
+def device_digest(bh, m, dev):
+    """The sums of oracle/make_ref_golden.digest_of over the library's C, evaluated on the device."""
+    import torch
+    from benchmark_spgemm_using_csr_amd.dist import device_view
+    pr, pc, pv = bh.get_C_device()
+    n = bh.nnzC
+    Cp = device_view(pr, m + 1, torch.int32, dev)
+    Cj = device_view(pc, n, torch.int32, dev)
+    Cx = device_view(pv, n, torch.float64, dev)
+    w = torch.arange(n, device=dev, dtype=torch.int64) % 8191 + 1
+    d = {"nnzC": int(n), "sum_rowptr": int(Cp.long().sum()), "wsum_col": int((Cj.long() * w).sum()) & 0xFFFFFFFFFFFFFFFF,
+         "sum_val": float(Cx.sum()), "wsum_val": float((Cx * w.double()).sum())}
+    del w
+    return d
+
+
+def reference_opencl_leg(m, rp, col, val, nnzCt, mine=None):
+    """One C = A^2 of the same matrix through oracle/_ref/ref_opencl_spgemm (the reference's SpGEMM_opencl, unmodified);
+    `mine`: digests of this library's C for the same input -- compared with the digests of the reference's C."""
     import re
     import subprocess
     import tempfile
@@ -64,14 +99,22 @@ def reference_opencl_leg(m, rp, col, val, nnzCt):
                 for a, dt in ((rp, np.int32), (col, np.int32), (rp, np.int32), (col, np.int32), (val, np.float64), (val, np.float64)):
                     np.ascontiguousarray(a, dt).tofile(f)
             env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND="-Dinline=static")     # see oracle/make_ref_golden.py
-            p = subprocess.run([exe, fin, "-"], cwd=ref_dir, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+            p = subprocess.run([exe, fin, "=" if mine else "-"], cwd=ref_dir, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                timeout=240, env=env)
         mt = re.search(r"SpGEMM time: ([0-9.eE+-]+) ms\. Gflops = ([0-9.eE+-]+)", p.stdout)
         mn = re.search(r"-> nnzC=(\d+)", p.stdout)
         if p.returncode != 0 or not mt:
             return {"error": "rc %d" % p.returncode, "stdout_tail": p.stdout.strip().splitlines()[-4:]}
-        return {"ms": float(mt.group(1)), "gflops": float(mt.group(2)), "nnzC": int(mn.group(1)) if mn else None,
-                "what": "SpGEMM_opencl's own timer around its spgemm() (stages 1-4, incl. its host statistics and buffer allocation)"}
+        res = {"ms": float(mt.group(1)), "gflops": float(mt.group(2)), "nnzC": int(mn.group(1)) if mn else None,
+               "what": "SpGEMM_opencl's own timer around its spgemm() (stages 1-4, incl. its host statistics and buffer allocation)"}
+        md = re.search(r"ref_opencl_digest: nnzC=(\d+) sum_rowptr=(\d+) wsum_col=(\d+) sum_val=(\S+) wsum_val=(\S+) rows_sorted=(\d)", p.stdout)
+        if mine and md:
+            theirs = {"nnzC": int(md.group(1)), "sum_rowptr": int(md.group(2)), "wsum_col": int(md.group(3)),
+                      "sum_val": float(md.group(4)), "wsum_val": float(md.group(5))}
+            res["digest"] = theirs
+            res["rows_sorted_by_reference"] = bool(int(md.group(6)))
+            res["hip_digest_equals_reference"] = bool(theirs == mine)
+        return res
     except Exception as e:                                  # a baseline that cannot run must not take the bench line down
         return {"error": str(e)[-300:]}
 
@@ -193,8 +236,8 @@ def main():
         if native is not None:
             try:
                 return native_step()
-            except Exception as e:
-                leave_native(e)
+            except bdist.CollectiveError as e:          # every rank is here in the same step; a local failure (spgemm,
+                leave_native(e)                         # out of memory, bad argument) propagates: its peers would wait in RCCL
         return torch_step()
 
     def native_step():
@@ -214,8 +257,8 @@ def main():
                                  torch.empty(capn, dtype=torch.float64, device=dev))
             rp, cc, vv = gather_out[0]
             tq = time.perf_counter()
-            if os.environ.get("BENCH_NATIVE_FAIL") == "step":       # (test hook)
-                raise RuntimeError("injected")
+            if os.environ.get("BENCH_NATIVE_FAIL") == "step":       # (test hook: injected on every rank)
+                raise bdist.CollectiveError("injected")
             ct, cn = native.spgemm_allgatherv(r1 - r0, m, rp, cc, vv, sub_blocks=sub_blocks)
             bh.time_ms = (time.perf_counter() - tq) * 1e3 - native.ms[2]      # multiply + overlapped part
             for i in range(3):
@@ -248,6 +291,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    state_before = gpu_state() if rank == 0 else None
     kstats = {}
     stage = np.zeros(4)
     t_compute = 0.0
@@ -267,6 +311,7 @@ def main():
         t_compute += bh.time_ms
     barrier()
     elapsed = time.perf_counter() - t0
+    state_after = gpu_state() if rank == 0 else None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -393,7 +438,7 @@ def main():
         # Its own process, after the timed steps above; skipped when the binary is absent.  Reported beside the CPU
         # figure, never as `value`.
         if not args.no_reference:
-            cpu["reference_opencl_same_gpu"] = reference_opencl_leg(m, hBp, hBj, hBx, bh.nnzCt)
+            cpu["reference_opencl_same_gpu"] = reference_opencl_leg(m, hBp, hBj, hBx, bh.nnzCt, mine=device_digest(bh, m, dev))
 
     # ---- second headline: the same multiply with every launch shortcut that rests on per-dataset row bounds
     # switched off (no row classes, no lane-first / wave-first / numeric-first: upper-bound pass, host round trip and
@@ -417,6 +462,44 @@ def main():
         for key in ("class_path", "wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 1) == 0
 
+    # ---- what a caller pays who multiplies each data set ONCE (bhs_set_data_device's scans -- longest rows, period hint,
+    # sortedness of B: the choices of the direct launches and of the class path rest on them -- plus the multiply), and
+    # the spread of the steady-state figure over fresh handles in this same process
+    incl_setup, fresh = None, None
+    if world == 1 and not args.no_general:
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            assert bh.initData_device(r1 - r0, m, m, nnzA, Ax, Ap, Aj, nnzB, Bx, Bp, Bj) == 0
+            assert bh.spgemm() == 0
+            ts.append((time.perf_counter() - tq) * 1e3)
+        incl_setup = {"ms_median": round(float(np.median(ts)), 4), "ms_min": round(float(np.min(ts)), 4),
+                      "what": "bhs_set_data_device + bhs_spgemm on a warm handle, same arrays"}
+        meds, firsts = [], []
+        for _ in range(3):
+            b2 = facade.bhsparse()
+            assert b2.initPlatform(plats, device=local_rank) == 0
+            assert b2.set_option("kernel_stats", 0) == 0
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            assert b2.initData_device(r1 - r0, m, m, nnzA, Ax, Ap, Aj, nnzB, Bx, Bp, Bj) == 0
+            assert b2.spgemm() == 0
+            firsts.append(round((time.perf_counter() - tq) * 1e3, 4))       # incl. the handle's workspace allocations
+            for _ in range(3):
+                assert b2.spgemm() == 0
+            tt = []
+            for _ in range(max(10, args.steps)):
+                tq = time.perf_counter()
+                assert b2.spgemm() == 0
+                tt.append((time.perf_counter() - tq) * 1e3)
+            meds.append(round(float(np.median(tt)), 4))
+            b2.free_mem()
+            b2.freePlatform()
+        fresh = {"handles": len(meds), "ms_median_each": meds, "ms_min": min(meds), "ms_median": float(np.median(meds)),
+                 "ms_max": max(meds), "first_multiply_ms_each": firsts,
+                 "what": "new handle each: set_data + first multiply (allocations), 3 warm-ups, median of the timed multiplies; kernel_stats off"}
+
     # ---- the other single-GPU configurations of BASELINE.json, short runs, reported beside the headline
     extra = None
     if world == 1 and not args.no_extra and args.workload == "p27_weak":
@@ -424,8 +507,12 @@ def main():
         bh.free_mem()
         del Ap, Aj, Ax, Bp, Bj, Bx
         torch.cuda.empty_cache()
-        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40"):
-            if wname == "fem3_40":      # 3 unknowns per node on poisson27pt 40^3, every coupling a full block
+        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40", "weblike_1m"):
+            if wname == "weblike_1m":   # stand-in for configs[3] (SuiteSparse webbase-1M is not in the image): same size, compression 1.35
+                st2, d2 = "web-like power-law (gallery.weblike_csr)", (1000005,)
+                rpw, colw = gallery.weblike_csr()
+                bp2, bj2 = torch.from_numpy(rpw).to(dev), torch.from_numpy(colw).to(dev)
+            elif wname == "fem3_40":      # 3 unknowns per node on poisson27pt 40^3, every coupling a full block
                 st2, d2 = "poisson27pt (x) ones(3,3)", (40, 40, 40)
                 rp0, col0 = gallery.poisson_csr("poisson27pt", 40, 40, 40)
                 rp3, col3 = gallery.block_expand_csr(rp0, col0, 3)
@@ -466,7 +553,9 @@ def main():
                              else ("torch batch_isend_irecv" if (world > 1 or force_gather) and not args.no_gather else None),
                    "row_blocks": "balanced by products" if world > 1 else "single"},
         "ms_min": round(float(np.min(step_ms)), 4), "ms_median": round(float(np.median(step_ms)), 4),
-        "setup_ms": round(setup_ms, 4), "setup_ms_warm": round(setup_ms_warm, 4), "general_path": general,
+        "setup_ms": round(setup_ms, 4), "setup_ms_warm": round(setup_ms_warm, 4),
+        "ms_per_step_incl_setup": incl_setup, "fresh_handles": fresh, "gpu_state": {"before": state_before, "after": state_after},
+        "general_path": general,
         "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
         "stage_ms": [round(float(x) / args.steps, 4) for x in stage],

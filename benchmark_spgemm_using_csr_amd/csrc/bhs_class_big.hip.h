@@ -226,7 +226,9 @@ __device__ __forceinline__ void class_big_rows(const unsigned* sDesc, int words,
                                                int accStride, int lane)
 {
     constexpr int UN = T >= 3 ? 2 : 4;                             // (6 to 8 loads per lane and batch)
-    auto load = [&](int base, unsigned (&d)[UN], acc_t (&b)[UN][T]) {
+    if (words <= 0) return;                                        // (an empty row of A, or only empty B rows behind it: no list word
+                                                                   //  to clamp to -- the row leaves with its 0 entries)
+    auto load =[&](int base, unsigned (&d)[UN], acc_t (&b)[UN][T]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) d[u] = sDesc[min(base + u * 64 + lane, words - 1)];   // (beyond the list: its last word again)
 #pragma unroll

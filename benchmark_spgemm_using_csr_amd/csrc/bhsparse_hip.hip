@@ -228,6 +228,7 @@ struct bhs_handle {
     } ps;
     // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
     int* extCj = nullptr;
+    const int* resCj = nullptr;          // the colIndC array the finished multiply wrote (own or bound): get_C serves no other
     value_t* extCx = nullptr;
     long long extCap = 0;
 };
@@ -247,7 +248,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SMALL_INTS = 448 };
+       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B */,
+       S_SMALL_INTS = 452 };
 
 int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
 {
@@ -1181,7 +1183,6 @@ int symbolic_class(bhs_handle* h)
             else BHS_CLASS_ROWS(true, 64, 4, rows_grid(m, 64), m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, headsL, nHeadsA);
             break;
     }
-#undef BHS_CLASS_ROWS
 #undef BHS_CLASS_ROWS_G
 #undef BHS_CLASS_ROWS
     BHS_HIP(hipGetLastError());
@@ -1536,6 +1537,7 @@ int pipeline_finish(bhs_handle* h)
         h->stats[h->evPool[i].stat].ms += ms;
     }
     h->hasC = true;
+    h->resCj = out_cj(h);
     return BHS_SUCCESS;
 }
 
@@ -1608,76 +1610,68 @@ int finish_set_data(bhs_handle* h)
     const double avgA = h->m > 0 ? (double)h->nnzA / h->m : 1.0;
     const double avgB = h->k > 0 ? (double)h->nnzB / h->k : 1.0;
     BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
-    int maxRowA = 0;
-    h->maxRowA = 0;
+    // the scans of the data set (longest rows, the period hint, sortedness of B's rows) are queued together and read
+    // back with ONE synchronisation
+    int* small0 = (int*)h->small.p;
+    BHS_HIP(hipMemsetAsync(small0 + S_SCAN, 0, sizeof(int) * 4, h->stream));
+    h->periodA = h->periodB = 1;
     if (h->m > 0) {
-        int* small0 = (int*)h->small.p;
-        BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
         const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 2);
-        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_MAXROW);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_SCAN);
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1);
         BHS_HIP(hipGetLastError());
-        BHS_HIP(hipMemcpyAsync(&maxRowA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
-        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_MAXROW);
-        BHS_HIP(hipGetLastError());
-        BHS_HIP(hipMemcpyAsync(&h->periodA, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
     }
-    // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
-    // that the longest row is walked in <= 32 passes
-    h->maxRowA = maxRowA;
+    if (h->k > 0) {
+        const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 2);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_SCAN + 2);
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_SCAN + 3);
+        BHS_HIP(hipGetLastError());
+    }
     h->avgRowA = avgA;
     h->avgRowB = avgB;
-    h->maxRowB = 0;
-    if (h->k > 0) {
-        int* small0 = (int*)h->small.p;
-        BHS_HIP(hipMemsetAsync(small0 + S_MAXROW, 0, sizeof(int), h->stream));
-        const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 2);
-        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_MAXROW);
-        BHS_HIP(hipGetLastError());
-        BHS_HIP(hipMemcpyAsync(&h->maxRowB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
-        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_MAXROW);
-        BHS_HIP(hipGetLastError());
-        BHS_HIP(hipMemcpyAsync(&h->periodB, small0 + S_MAXROW, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
-    }
-    h->ubG = pow2_at_least(std::max(avgA, std::min(maxRowA, kUbLongA) / 32.0), 1, 64);   // (longer rows: k_upper_bound_long)
     int L = pow2_at_least(avgB, 1, 64);
     int lg = 0;
     while ((1 << lg) < L) ++lg;
     h->logL = lg;
-    BHS_TRY(ensure(h, h->small, sizeof(int) * S_SMALL_INTS));
     h->bSorted = 1;
     h->cmpState = 0;
     h->specFailed = false;
     h->classState = 0;
-    if (h->nnzB > 1 && h->k > 0) {
-        int* small = (int*)h->small.p;
-        BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
-        const int logG = std::min(h->logL, 6);                  // lanes per row of B: its average length
-        long long grid = std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16);
-        grid = std::max<long long>(grid, 1);
-        // rows of B beyond kSortedLongB entries are listed and checked by k_check_sorted_long, 16 workgroups per row
-        int2* longB = nullptr;
-        if (h->maxRowB > kSortedLongB) {
-            BHS_TRY(ensure(h, h->longList, ((size_t)h->nnzB / 2048 + 2) * sizeof(int2)));
-            longB = (int2*)h->longList.p;
-        }
-        auto check_sorted = [&]() -> int {
-            BHS_HIP(hipMemsetAsync(small + S_LONG_B, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)grid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
-                               small + S_SORTED, longB, small + S_LONG_B);
-            if (longB)
-                hipLaunchKernelGGL(k_check_sorted_long, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream,
-                                   (const int2*)longB, (const int*)(small + S_LONG_B), h->dBp, h->dBj, small + S_SORTED);
-            BHS_HIP(hipGetLastError());
-            return BHS_SUCCESS;
-        };
+    const bool checkB = h->nnzB > 1 && h->k > 0;
+    // rows of B beyond kSortedLongB entries are listed and checked by k_check_sorted_long, 16 workgroups per row
+    int2* longB = nullptr;
+    const int logG = std::min(h->logL, 6);                      // lanes per row of B: its average length
+    const long long sortGrid = std::max<long long>(1, std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16));
+    auto check_sorted = [&]() -> int {
+        BHS_HIP(hipMemsetAsync(small0 + S_SORTED, 0, sizeof(int), h->stream));
+        BHS_HIP(hipMemsetAsync(small0 + S_LONG_B, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)sortGrid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
+                           small0 + S_SORTED, longB, small0 + S_LONG_B);
+        hipLaunchKernelGGL(k_check_sorted_long, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream,
+                           (const int2*)longB, (const int*)(small0 + S_LONG_B), h->dBp, h->dBj, small0 + S_SORTED);
+        BHS_HIP(hipGetLastError());
+        return BHS_SUCCESS;
+    };
+    if (checkB) {
+        BHS_TRY(ensure(h, h->longList, ((size_t)h->nnzB / 2048 + 2) * sizeof(int2)));
+        longB = (int2*)h->longList.p;
         BHS_TRY(check_sorted());
-        int flag = 0;
-        BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
+    }
+    int* hscan = (int*)h->hostSmall;                                // (pinned)
+    BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 4, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    const int maxRowA = hscan[0];
+    h->maxRowA = maxRowA;
+    h->maxRowB = hscan[2];
+    if (h->m > 0) h->periodA = hscan[1];
+    if (h->k > 0) h->periodB = hscan[3];
+    // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
+    // that the longest row is walked in <= 32 passes
+    h->ubG = pow2_at_least(std::max(avgA, std::min(maxRowA, kUbLongA) / 32.0), 1, 64);   // (longer rows: k_upper_bound_long)
+    if (checkB) {
+        int* small = small0;
+        int flag = hscan[4];
         h->bSorted = flag ? 0 : 1;
         if (!h->bSorted && h->sortB) {
             // Unsorted rows of B: sort them once here (the reference's driver does this on the host before
@@ -1692,7 +1686,6 @@ int finish_set_data(bhs_handle* h)
                 h->dBx = (const value_t*)h->ownB[2].p;
             }
             BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
-            BHS_HIP(hipMemsetAsync(small + S_SORTED, 0, sizeof(int), h->stream));
             BHS_TRY(check_sorted());
             BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             BHS_HIP(hipStreamSynchronize(h->stream));
@@ -1819,6 +1812,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->longList); release(h->longPart);
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
     release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
+    release(h->classBigIdx); release(h->classBigMap);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -2013,6 +2007,7 @@ int bhs_get_C(bhs_handle* h, int* csrColIndC, bhs_value_t* csrValC)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasC) return BHS_ERR_NOT_READY;
+    if (h->nnzC && out_cj(h) != h->resCj) return BHS_ERR_NOT_READY;   // (the result went to arrays that were unbound since: it lives there)
     if (h->nnzC && (!csrColIndC || !csrValC)) return BHS_ERR_INVALID_ARG;
     BHS_HIP(hipSetDevice(h->device));
     if (h->nnzC) {
@@ -2037,6 +2032,7 @@ int bhs_get_C_device(bhs_handle* h, const int** d_rowPtrC, const int** d_colIndC
 {
     if (!h) return BHS_ERR_INVALID_ARG;
     if (!h->hasC && !h->ps.open) return BHS_ERR_NOT_READY;        // (between the halves rowPtrC is already final)
+    if (h->hasC && h->nnzC && out_cj(h) != h->resCj && (d_colIndC || d_valC)) return BHS_ERR_NOT_READY;   // (see bhs_get_C)
     if (d_rowPtrC) *d_rowPtrC = (const int*)h->Cp.p;
     if (d_colIndC) *d_colIndC = (const int*)out_cj(h);
     if (d_valC) *d_valC = (const bhs_value_t*)out_cx(h);

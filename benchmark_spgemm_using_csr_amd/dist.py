@@ -50,6 +50,11 @@ def row_blocks_balanced(rowptr_a, col_a, rowptr_b, world):
     return starts
 
 
+class CollectiveError(RuntimeError):
+    """A failure of the library's all-gatherv that EVERY rank of the call returns from (so every rank may react to it
+    in the same step); anything else raised on the way is local to one rank and must not be answered with a collective."""
+
+
 class NativeDist(object):
     """ctypes binding of libbhsparse_dist.so (include/bhsparse_dist.h): the multiply of this rank's row block and the
     RCCL all-gatherv of C issued by the library itself (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on its own
@@ -105,7 +110,10 @@ class NativeDist(object):
                                                  int(col.numel()), C.byref(ct), C.byref(cc), ms)
         if err:
             from . import _lib
-            raise RuntimeError("bhs_dist_spgemm_allgatherv: %d (%s)" % (err, _lib.strerror(err)))
+            msg = "bhs_dist_spgemm_allgatherv: %d (%s)" % (err, _lib.strerror(err))
+            # BHS_ERR_INVALID_ARG is returned before the first agreement (this rank only); every other code is
+            # reached by all ranks of the call together (include/bhsparse_dist.h)
+            raise (RuntimeError if err == _lib.BHS_ERR_INVALID_ARG else CollectiveError)(msg)
         self.ms = tuple(ms)
         return int(ct.value), int(cc.value)
 

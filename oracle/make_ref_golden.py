@@ -65,6 +65,78 @@ def run_reference(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, timeout=600):
     return Cp, Cj, Cx, p.stdout
 
 
+def run_reference_digest(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, timeout=1200):
+    """The same through the binary's digest mode ("="): C stays in the reference's process, which prints the sums of
+    digest_of() over it (BASELINE.json's full sizes: a 3 GB dump per case would not fit gpurun_out)."""
+    import re
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.bin")
+        with open(fin, "wb") as f:
+            np.array([m, k, n, len(Aj), len(Bj)], np.int32).tofile(f)
+            for a, dt in ((Ap, np.int32), (Aj, np.int32), (Bp, np.int32), (Bj, np.int32),
+                          (Ax, np.float64), (Bx, np.float64)):
+                np.ascontiguousarray(a, dt).tofile(f)
+        p = subprocess.run([REF_BIN, fin, "="], cwd=REF_DIR, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout, text=True, env=REF_ENV)
+    mt = re.search(r"ref_opencl_digest: nnzC=(\d+) sum_rowptr=(\d+) wsum_col=(\d+) sum_val=(\S+) wsum_val=(\S+) rows_sorted=(\d)", p.stdout)
+    if p.returncode != 0 or not mt:
+        raise RuntimeError("reference binary failed (%d):\n%s" % (p.returncode, p.stdout[-2000:]))
+    d = {"nnzC": int(mt.group(1)), "sum_rowptr": int(mt.group(2)), "wsum_col": int(mt.group(3)),
+         "sum_val": float(mt.group(4)), "wsum_val": float(mt.group(5))}
+    return d, bool(int(mt.group(6))), p.stdout
+
+
+def full_size_cases():
+    """BASELINE.json's own sizes (digest only): configs[1], configs[2], the 3-dof FEM stand-in and the web-like
+    stand-in for configs[3] (its longest row of C, 13 k entries, stays below the 25 600 where the reference's OpenCL
+    merge stops -- bhsparse.cpp:469, 498-502 -- so the reference can do it)."""
+    out = []
+
+    def stencil(tag, name, dims, dof=1):
+        rp, col = gallery.poisson_csr(name, *dims)
+        if dof > 1:
+            rp, col = gallery.block_expand_csr(rp, col, dof)
+        val = gallery.fill_values(len(col))
+        m = len(rp) - 1
+        out.append((tag, m, (rp, col, val)))
+
+    stencil("p5_1024", "poisson5pt", (1024, 1024, 1))
+    stencil("p27_128", "poisson27pt", (128, 128, 128))
+    stencil("fem3_40", "poisson27pt", (40, 40, 40), dof=3)
+    rp, col = gallery.weblike_csr()
+    out.append(("weblike_1m", len(rp) - 1, (rp, col, gallery.fill_values(len(col)))))
+    return out
+
+
+def full_size(args, report):
+    for tag, m, A in full_size_cases():
+        if args.only and tag not in args.only.split(","):
+            continue
+        Ap, Aj, Ax = A
+        entry = {"m": m, "k": m, "n": m, "nnzA": int(len(Aj)), "nnzB": int(len(Aj)), "full_size": True}
+        try:
+            d, was_sorted, log = run_reference_digest(m, m, m, Ap, Aj, Ax, Ap, Aj, Ax)
+        except Exception as e:
+            entry["error"] = str(e)[-1500:]
+            report[tag] = entry
+            print(tag, "REFERENCE FAILED:", entry["error"], flush=True)
+            continue
+        entry.update(d)
+        entry["rows_sorted_by_reference"] = was_sorted
+        entry["nnzCt"] = oracle.nnzCt(Ap, Aj, Ap)
+        # the oracle on the same input (all host cores): digests must agree
+        oCp, oCj, oCx = oracle.spgemm(m, m, m, Ap, Aj, Ax, Ap, Aj, Ax)
+        od = digest_of(oCp, oCj, oCx)
+        entry["oracle_digest_equal"] = bool(all(od[k2] == d[k2] for k2 in od))
+        entry["oracle_rowptr_equal"] = entry["oracle_col_equal"] = entry["oracle_digest_equal"]
+        if not entry["oracle_digest_equal"]:
+            entry["oracle_digest"] = od
+        entry["reference_stdout_tail"] = log.strip().splitlines()[-8:]
+        report[tag] = entry
+        print(tag, {k2: v for k2, v in entry.items() if k2 != "reference_stdout_tail"}, flush=True)
+        del oCp, oCj, oCx
+
+
 def sort_rows(Cp, Cj, Cx):
     """Stable per-row sort by column (ref_spgemm.h:37-62 does the same to inputs); returns copies + 'was sorted'."""
     row = np.repeat(np.arange(len(Cp) - 1, dtype=np.int64), np.diff(Cp.astype(np.int64)))
@@ -148,9 +220,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_opencl"))
     ap.add_argument("--only", default="")
+    ap.add_argument("--full-size", action="store_true", help="only BASELINE.json's own sizes (digests; merged into the report of --out)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     report = {}
+    if args.full_size:
+        path = os.path.join(args.out, "ref_opencl_digests.json")
+        if os.path.exists(path):
+            report = json.load(open(path))
+        elif os.path.exists(os.path.join(GOLD, "ref_opencl_digests.json")):
+            report = json.load(open(os.path.join(GOLD, "ref_opencl_digests.json")))
+        full_size(args, report)
+        with open(path, "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        bad = [t for t, e in report.items() if "error" in e or not (e["oracle_rowptr_equal"] and e["oracle_col_equal"])]
+        print("cases:", len(report), "reference/oracle disagreements or failures:", bad, flush=True)
+        return
     for tag, full, m, k, n, A, B in cases():
         if args.only and tag not in args.only.split(","):
             continue

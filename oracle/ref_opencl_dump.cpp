@@ -15,8 +15,11 @@
 // The reference opens its six .cl kernel files by bare name (bhsparse_opencl.cpp:108-120), so the binary
 // has to run from a directory that holds them: oracle/_ref/ (git-ignored), staged there by the recipe.
 //
-// usage: ref_opencl_spgemm <in.bin> <out.bin | ->      ("-": no dump, only the reference's own timing lines --
-//                                                          bench.py's `reference_opencl` leg reads "SpGEMM time")
+// usage: ref_opencl_spgemm <in.bin> <out.bin | - | =>  ("-": no dump, only the reference's own timing lines --
+//                                                          bench.py's `reference_opencl` leg reads "SpGEMM time";
+//                                                          "=": no dump, C is fetched and its digests are printed --
+//                                                          the same sums as make_ref_golden.digest_of, bench.py and
+//                                                          tests/test_full_size_gpu.py compare the HIP result with them)
 //   in.bin : int32 m,k,n,nnzA,nnzB | rowPtrA[m+1] colIndA[nnzA] | rowPtrB[k+1] colIndB[nnzB] | f64 valA[nnzA] valB[nnzB]
 //   out.bin: int32 nnzC | rowPtrC[m+1] colIndC[nnzC] | f64 valC[nnzC]
 #include "bhsparse.h"
@@ -74,6 +77,27 @@ int main(int argc, char **argv)
     err = bh->get_C(ciC.data(), vC.data());                  // also re-reads rowPtrC (bhsparse_opencl.cpp:1182-1185)
     if (err != BHSPARSE_SUCCESS) { fprintf(stderr, "get_C error %d\n", err); return 14; }
 
+    if (argv[2][0] == '=' && argv[2][1] == 0) {
+        // digests of the reference's C as it left the device (rows are not re-sorted: `rows_sorted` says whether
+        // every row was ascending); integer-valued inputs keep every sum below 2^53, i.e. exact in any order
+        unsigned long long sumRp = 0, wsumCol = 0;
+        double sumVal = 0.0, wsumVal = 0.0;
+        int sorted = 1;
+        for (int i = 0; i <= m; i++) sumRp += (unsigned long long)rpC[i];
+        for (int i = 0; i < m; i++)
+            for (int p = rpC[i] + 1; p < rpC[i + 1]; p++) if (ciC[p] <= ciC[p - 1]) sorted = 0;
+        for (long long p = 0; p < nnzC; p++) {
+            const unsigned long long w = (unsigned long long)p % 8191ull + 1ull;
+            wsumCol += (unsigned long long)ciC[p] * w;
+            sumVal += vC[p];
+            wsumVal += vC[p] * (double)w;
+        }
+        printf("ref_opencl_digest: nnzC=%d sum_rowptr=%llu wsum_col=%llu sum_val=%.17g wsum_val=%.17g rows_sorted=%d\n",
+               nnzC, sumRp, wsumCol, sumVal, wsumVal, sorted);
+        printf("ref_opencl_spgemm: m=%d k=%d n=%d nnzA=%d nnzB=%d -> nnzC=%d\n", m, k, n, nnzA, nnzB, nnzC);
+        fflush(stdout);
+        _exit(0);
+    }
     FILE *fo = fopen(argv[2], "wb");
     if (!fo) { perror(argv[2]); return 2; }
     ok = wr(fo, &nnzC, sizeof(int)) && wr(fo, rpC.data(), sizeof(int) * (m + 1)) &&

@@ -112,11 +112,16 @@ def full_size():
     path = os.path.join(HERE, "checksums.json")
     sums = json.load(open(path))
     for tag, name, dims in (("p5_1024", "poisson5pt", (1024, 1024, 1)), ("p27_128", "poisson27pt", (128, 128, 128)),
-                            ("powerlaw_1m", "powerlaw", (1000005, 3105536, 4700))):
+                            ("powerlaw_1m", "powerlaw", (1000005, 3105536, 4700)),
+                            ("weblike_1m", "weblike", (1000005,)), ("fem3_40", "fem3", (40, 40, 40))):
         if tag in sums and "--force" not in sys.argv:
             continue
         if name == "powerlaw":        # stand-in for configs[3] (webbase-1M: the SuiteSparse file is not in the image)
             rp, col = gallery.powerlaw_csr(dims[0], dims[0], dims[1], dims[2])
+        elif name == "weblike":       # the stand-in with webbase-1M's compression (nnzCt / nnzC = 1.35; published 1.36)
+            rp, col = gallery.weblike_csr(dims[0])
+        elif name == "fem3":          # poisson27pt (x) ones(3, 3): 3 unknowns per node
+            rp, col = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", *dims), 3)
         else:
             rp, col = gallery.poisson_csr(name, *dims)
         val = gallery.fill_values(len(col))

@@ -22,7 +22,9 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 CASES = {"p5_1024": ("poisson5pt", (1024, 1024, 1)), "p27_128": ("poisson27pt", (128, 128, 128)),
-         "powerlaw_1m": ("powerlaw", (1000005, 3105536, 4700))}   # stand-in for configs[3] (webbase-1M, file absent)
+         "powerlaw_1m": ("powerlaw", (1000005, 3105536, 4700)),   # round 1-3 stand-in for configs[3]: hub-heavy, compression 1.007
+         "weblike_1m": ("weblike", (1000005,)),                   # stand-in for configs[3] (webbase-1M, file absent) with its compression: 1.35
+         "fem3_40": ("fem3", (40, 40, 40))}                       # poisson27pt (x) ones(3, 3): the big-class kernels
 
 
 def _spmv(rp, col, val, x):
@@ -34,7 +36,12 @@ def _spmv(rp, col, val, x):
     return y
 
 
-@pytest.mark.parametrize("tag", ["p5_1024", "p27_128", "powerlaw_1m"])
+# cases the REFERENCE ITSELF multiplied at this size on an MI355X (oracle/make_ref_golden.py --full-size; its OpenCL merge
+# truncates rows beyond 25 600 entries, which powerlaw_1m has and weblike_1m does not)
+REF_AT_FULL_SIZE = ("p5_1024", "p27_128", "weblike_1m", "fem3_40")
+
+
+@pytest.mark.parametrize("tag", ["p5_1024", "p27_128", "powerlaw_1m", "weblike_1m", "fem3_40"])
 def test_full_size_digests_and_properties(hiplib, tag):
     import torch
     from benchmark_spgemm_using_csr_amd import gallery, facade
@@ -46,6 +53,12 @@ def test_full_size_digests_and_properties(hiplib, tag):
     dev = torch.device("cuda", 0)
     if stencil == "powerlaw":
         rp, col = gallery.powerlaw_csr(dims[0], dims[0], dims[1], dims[2])
+        Bp, Bj = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    elif stencil == "weblike":
+        rp, col = gallery.weblike_csr(dims[0])
+        Bp, Bj = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    elif stencil == "fem3":
+        rp, col = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", *dims), 3)
         Bp, Bj = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     else:
         Bp, Bj = gallery.poisson_csr_torch(stencil, *dims, device=dev)
@@ -86,6 +99,14 @@ def test_full_size_digests_and_properties(hiplib, tag):
     assert wsum_col == ref["wsum_col"]
     assert float(Cx.sum()) == ref["sum_val"]
     assert float((Cx * w.double()).sum()) == ref["wsum_val"]
+    # ... and against the digests of the REFERENCE's own C for this input (tests/golden/ref_opencl_digests.json)
+    if tag in REF_AT_FULL_SIZE:
+        rref = json.load(open(os.path.join(GOLDEN, "ref_opencl_digests.json"))).get(tag)
+        assert rref is not None and "error" not in rref, "run oracle/make_ref_golden.py --full-size on an MI355X box"
+        assert rref["rows_sorted_by_reference"] and rref["oracle_digest_equal"]
+        assert (nnzC, int(cp64.sum()), wsum_col) == (rref["nnzC"], rref["sum_rowptr"], rref["wsum_col"])
+        assert float(Cx.sum()) == rref["sum_val"] and float((Cx * w.double()).sum()) == rref["wsum_val"]
+        assert bh.nnzCt == rref["nnzCt"]
 
     # linearity
     ones = torch.ones(m, dtype=torch.float64, device=dev)

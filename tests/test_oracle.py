@@ -149,6 +149,31 @@ def test_webbase_standin_matches_published_shape():
     assert np.all((d > 0) | starts[1:])                             # rows sorted, duplicate-free
 
 
+def test_weblike_standin_has_webbase_shape_and_compression(oracle):
+    """The second configs[3] stand-in (gallery.weblike_csr): webbase-1M's dimensions AND its duplicate accumulation --
+    published (Liu & Vinter): 3 105 536 entries, longest row 4700, ~69.5 M products ->
+    ~51.1 M entries of A^2 (1.36).  The oracle's A^2 must reproduce the digest scipy computed (checksums.json)."""
+    rp, col = gallery.weblike_csr()
+    lens = np.diff(rp)
+    m = len(rp) - 1
+    assert m == 1000005 and abs(len(col) - 3105536) <= 0.01 * 3105536 and 4600 <= lens.max() <= 4800
+    assert lens.min() >= 1 and (lens <= 3).mean() > 0.6
+    ref = json.load(open(os.path.join(GOLDEN, "checksums.json")))["weblike_1m"]
+    val = gallery.fill_values(len(col))
+    ct = oracle.nnzCt(rp, col, rp)
+    Cp, Cj, Cx = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    assert ct == ref["nnzCt"] and len(Cj) == ref["nnzC"]
+    assert 1.30 <= ct / len(Cj) <= 1.42                              # (webbase-1M: 1.36; the round 1-3 stand-in: 1.007)
+    assert abs(ct - 69.5e6) <= 0.03 * 69.5e6 and abs(len(Cj) - 51.1e6) <= 0.03 * 51.1e6
+    t = np.arange(len(Cj), dtype=np.uint64) % np.uint64(8191) + np.uint64(1)
+    assert int(Cp.astype(np.uint64).sum()) == ref["sum_rowptr"] and int((Cj.astype(np.uint64) * t).sum()) == ref["wsum_col"]
+    assert float(Cx.sum()) == ref["sum_val"] and float((Cx * t.astype(np.float64)).sum()) == ref["wsum_val"]
+    # long rows WITH duplicates: rows of more than 3072 products compress too
+    _, ub = oracle.nnzCt(rp, col, rp, want_ub=True)
+    big = ub > 3072
+    assert big.sum() > 1500 and ub[big].sum() / np.diff(Cp)[big].sum() > 1.3
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Pins against outputs of the reference itself (SpGEMM_opencl on MI355X; generator: oracle/make_ref_golden.py).
 # Structure bit-exact; values bit-exact for the integer-valued inputs, 1e-6 relative (north_star) for cage4's reals.

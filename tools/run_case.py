@@ -10,6 +10,10 @@ if name == "webbase":
     rp, col = gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
     val = gallery.fill_values(len(col))
     Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
+elif name == "weblike":
+    rp, col = gallery.weblike_csr()
+    val = gallery.fill_values(len(col))
+    Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 elif name == "denserows":
     rp, col = gallery.dense_rows_csr(1 << 20, 8, 4, 200000)
     val = gallery.fill_values(len(col))
