@@ -28,6 +28,14 @@ namespace bhs {
 //   the waits    a row's order is: arithmetic (LDS only) -> s_waitcnt vmcnt(0) -> request the slab two rows ahead ->
 //                store the row.  Whatever the vmcnt(0) waits for -- the slab requested during the row before, that
 //                row's stores, the next run's metadata -- was issued a whole row's arithmetic earlier.
+// Round 4, fewer vector-memory instructions per row (the CU's memory pipe is what the waves queue for: a VMEM instruction
+// took ~230 cycles to ISSUE in round 3's phase timers):
+//   * colIndA / rowPtrB of a run are only requested when a stretch STARTS in that run (first run of a super-run, or a
+//     class change): inside a stretch the kernel needs A's values and nothing else of A -- the columns of C come from
+//     the class's relative list, the B rows from the ring.  A's values are loaded two per lane;
+//   (Rows leaving in PAIRS -- the first row's sums kept in registers, both rows written with 8- / 16-byte stores per
+//   lane, half the store instructions -- measured 15 % SLOWER: 1.78 against 1.51 ms on one box; the 16-byte stores start
+//   at 8-byte-aligned addresses.  Removed.)
 // Round 2's form (k_class_numeric_atomic: 64-lane batches in A-entry-major order, one ds_add_f64 per product) stands at
 // two walls of equal height: 30 LDS cycles per atomic (3.6 lanes per bank pair) and the CU's L1-miss parallelism
 // (profiles/r03_class_numeric_forms.md, which also has the forms of this kernel that staged whole stretches of rows
@@ -42,10 +50,12 @@ typedef __attribute__((address_space(3))) void bhs_lds_void;
 typedef __attribute__((address_space(1))) const void bhs_glb_void;
 __device__ __forceinline__ unsigned ringBaseOf(const value_t* ring) { return (unsigned)(size_t)ring; }
 
-template <int MAXU, int MAXV, int SE, int MAXJ>   // SE: 64-entry passes over a run's A entries; MAXJ: load instructions per slab
+typedef value_t bhs_val2 __attribute__((ext_vector_type(2), aligned(sizeof(value_t))));   // two consecutive values of A: one load
+
+template <int MAXU, int MAXV, int SE, int MAXJ>   // SE: 64-entry passes over a run's A entries (even); MAXJ: load instructions per slab
 __global__ __launch_bounds__(64) void k_class_numeric(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
-    const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
+    long long nnzA, const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classMap, const int* __restrict__ classRel,
     const int* __restrict__ classLane, const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx,
     int accStride, int stageCap, int ringCap, int rowBase)     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     // of C (bits 0-15), the A entry's place in a row's staged values (16-24), the B entry (25-30; read where a stretch
     // begins), and the sign bit: the running sum restarts here.  A step without a product reads A's and the ring's first
     // value and stores to the dump slot; the product behind it restarts the sum.
-    int desc[MAXU], rel[MAXV];
+    int desc[MAXU];
     int ent = 0;                                                 // the class's chain table: this lane as A entry (k_class_patterns)
     // ... its slab as seen by this lane's share of the MAXJ load instructions: the chain's first A entry, the
     // lane's place in that chain's row (-1: a padding lane), the row's length
@@ -105,31 +115,63 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     int loadSlot = 0, lastRow = -2, wrapB = 0;
     unsigned at[MAXU];
     bool ringOK = false;
+    int rel[MAXV];                                               // the columns of this lane's entries of a row, relative to the row
 #if BHS_PHASES_CLS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tPh = __builtin_readcyclecounter();
 #endif
-    // prologue: run 0 staged in half 0, run 1's A entries and run 2's pointers in registers
+    // Does a stretch start in the i-th run of this wave (rows of classes cls, nrI of them; the run before ended in class
+    // prevLast)?  Only then are its column indices and their rowPtrB words needed.
+    constexpr bool LEAN = !(BHS_CLS_LAB & 8);
+    auto starts_in = [&](int i, int cls, int nrI, int prevLast) -> bool {
+        if (!LEAN || i % RPS == 0) return true;
+        int before = __shfl_up(cls, 1, 64);
+        if (lane == 0) before = prevLast;
+        return __ballot(lane < nrI && cls != before) != 0ull;
+    };
+    auto last_class = [&](const int cls, int nrI) { return nrI > 0 ? __builtin_amdgcn_readlane(cls, nrI - 1) : -3; };
+    // two consecutive values of A per lane (the last value of valA is not read as the first half of a pair)
+    constexpr int SP = SE / 2;
+    auto load_ax = [&](int base, int nE, bhs_val2 (&ax)[SP]) {
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const int e = i * 128 + 2 * lane;
+            ax[i] = bhs_val2{(value_t)0, (value_t)0};
+            if (e < nE) {
+                if ((long long)base + e + 1 < nnzA) ax[i] = *reinterpret_cast<const bhs_val2*>(Ax + base + e);
+                else ax[i].x = Ax[base + e];
+            }
+        }
+    };
+    auto stage_ax = [&](int nE, const bhs_val2 (&ax)[SP]) {
+        typedef acc_t a2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const int e = i * 128 + 2 * lane;
+            if (e < nE) *reinterpret_cast<a2*>(sAx + e) = a2{(acc_t)ax[i].x, (acc_t)ax[i].y};   // (stageCap is even: e + 1 is inside)
+        }
+    };
+    // prologue: run 0 staged, run 1's A entries and run 2's pointers in registers
     RunPtrs p0 = load_ptrs(run_of(0)), p1 = load_ptrs(run_of(1)), p2 = load_ptrs(run_of(2));
-    int aj1[SE], bp0[SE];                                        // (bp0: B row start of every A entry of the run at hand)
-    acc_t ax1[SE];
+    int aj1[SE], bp0[SE];                                        // (bp0: B row start of every A entry of the run at hand -- if a stretch starts in it)
+    bhs_val2 ax1[SP];
+    bool ns1 = true;                                             // a stretch starts in the next run: aj1 holds its columns
     {
         const int nr0 = rows_of(run_of(0)), nr1 = rows_of(run_of(1));
         const int b0 = __builtin_amdgcn_readlane(p0.ap, 0), nE0 = nr0 ? entries_of(p0, nr0) : 0;
         const int b1 = __builtin_amdgcn_readlane(p1.ap, 0), nE1 = nr1 ? entries_of(p1, nr1) : 0;
         int aj0[SE];
-        acc_t ax0[SE];
+        bhs_val2 ax0[SP];
 #pragma unroll
         for (int i = 0; i < SE; ++i) {
             aj0[i] = aj1[i] = -1;
-            ax0[i] = ax1[i] = 0.0;
-            if (i * 64 + lane < nE0) { aj0[i] = Aj[b0 + i * 64 + lane]; ax0[i] = (acc_t)Ax[b0 + i * 64 + lane]; }
-            if (i * 64 + lane < nE1) { aj1[i] = Aj[b1 + i * 64 + lane]; ax1[i] = (acc_t)Ax[b1 + i * 64 + lane]; }
+            if (i * 64 + lane < nE0) aj0[i] = Aj[b0 + i * 64 + lane];
+            if (i * 64 + lane < nE1) aj1[i] = Aj[b1 + i * 64 + lane];
         }
+        load_ax(b0, nE0, ax0);
+        load_ax(b1, nE1, ax1);
 #pragma unroll
-        for (int i = 0; i < SE; ++i) {
-            bp0[i] = aj0[i] >= 0 ? Bp[aj0[i]] : 0;
-            if (i * 64 + lane < nE0) sAx[i * 64 + lane] = ax0[i];
-        }
+        for (int i = 0; i < SE; ++i) bp0[i] = aj0[i] >= 0 ? Bp[aj0[i]] : 0;
+        stage_ax(nE0, ax0);
     }
     wave_sync();
     for (int it = 0;; ++it) {
@@ -141,27 +183,35 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         const RunPtrs p3 = load_ptrs(run_of(it + 3));
         const int nr1 = rows_of(run_of(it + 1)), nr2 = rows_of(run_of(it + 2));
         const int nE1 = nr1 ? entries_of(p1, nr1) : 0;
+        const bool ns2 = nr2 > 0 && starts_in(it + 2, p2.cls, nr2, last_class(p1.cls, nr1));
         int aj2[SE], bp1[SE];
-        acc_t ax2[SE];
+        bhs_val2 ax2[SP];
         {
             const int b2 = __builtin_amdgcn_readlane(p2.ap, 0), nE2 = nr2 ? entries_of(p2, nr2) : 0;
 #pragma unroll
-            for (int i = 0; i < SE; ++i) {
-                aj2[i] = -1;
-                ax2[i] = 0.0;
-                if (i * 64 + lane < nE2) { aj2[i] = Aj[b2 + i * 64 + lane]; ax2[i] = (acc_t)Ax[b2 + i * 64 + lane]; }
-            }
+            for (int i = 0; i < SE; ++i) aj2[i] = -1;
+            if (ns2) {
 #pragma unroll
-            for (int i = 0; i < SE; ++i) bp1[i] = aj1[i] >= 0 ? Bp[aj1[i]] : 0;
+                for (int i = 0; i < SE; ++i)
+                    if (i * 64 + lane < nE2) aj2[i] = Aj[b2 + i * 64 + lane];
+            }
+            load_ax(b2, nE2, ax2);
+#pragma unroll
+            for (int i = 0; i < SE; ++i) bp1[i] = 0;
+            if (ns1) {
+#pragma unroll
+                for (int i = 0; i < SE; ++i) bp1[i] = aj1[i] >= 0 ? Bp[aj1[i]] : 0;
+            }
         }
         auto stage_next = [&]() {               // (behind the last row's vmcnt(0): the requests above have arrived, the row is done)
+            stage_ax(nE1, ax1);
 #pragma unroll
             for (int i = 0; i < SE; ++i) {
-                if (i * 64 + lane < nE1) sAx[i * 64 + lane] = ax1[i];
                 bp0[i] = bp1[i];
                 aj1[i] = aj2[i];
-                ax1[i] = ax2[i];
             }
+#pragma unroll
+            for (int i = 0; i < SP; ++i) ax1[i] = ax2[i];
         };
         // one slab: this lane's 16 bytes of each of its load instructions, if they are a piece of a B row
         auto request_slab = [&]() {
@@ -297,6 +347,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         stage_next();
         wave_sync();
         p0 = p1; p1 = p2; p2 = p3;
+        ns1 = ns2;
     }
 #if BHS_PHASES_CLS
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], ph[i]);
