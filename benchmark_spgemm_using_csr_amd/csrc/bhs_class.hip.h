@@ -92,7 +92,7 @@ __device__ __forceinline__ unsigned group_sum_u32(unsigned v)
     return v;
 }
 
-constexpr int kClassRowsBlock = 512;       // (1024 until round 4: the batched table part wants more than 128 registers)
+constexpr int kClassRowsBlock = 1024;      // large blocks: fewer block-local class caches to warm up
 template <bool IS_A, int G, int E>         // G lanes per row, E entries per lane: rows of up to G * E entries
 __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                     const int* __restrict__ classB,
@@ -196,112 +196,75 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
             if (IS_A && (__ballot(bad) & gmask)) ok[r] = false;    // a B row without a class: none for this row either
             h[r] = group_sum_u32<G>(hp) + (unsigned)len[r] * 0x9E3779B1u + 1u;
         }
-        // 1. the block's cache (LDS only), every row set
-        int cls[R], sl[R];
-        bool searching[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const long long row = rowv[r];
             const unsigned hr = h[r];
             const int lenr = len[r];
-            cls[r] = -1;
-            searching[r] = ok[r];
-            sl[r] = (int)(hr & (kClassSlots - 1));
-            const int ci = (int)(hr & (NC - 1));
-            unsigned tg = 0xFFFFFFFFu;
-            if (searching[r] && g == 0) tg = __hip_atomic_load(&ctag[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tg = (unsigned)__shfl((int)tg, leaderLane, 64);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the pattern is read after its tag, never before
-            const bool cand = searching[r] && tg < kBusy && (tg & 0xFFFFFu) == (hr >> 12);
-            bool same = clen[ci] == lenr;
-            int pc[E], pb[E];
+            int cls = -1;
+            // does this row equal row `rep` entry by entry?  (one entry per lane and pass; the group votes)
+            auto equals = [&](bool cand, int rep) {
+                bool same = true;
+                if (__any(cand && rep != (int)row)) {               // (rare: a class this block meets for the first time)
+                    const int rp = cand ? rep : 0;
+                    const int r0 = Rp[rp], r1 = Rp[rp + 1];
+                    const int lastR = r1 > r0 ? r1 - 1 : 0;
+                    int cr[E], cbr[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) { pc[e] = cpat[ci][e * G + g]; pb[e] = IS_A ? cpatB[ci][e * G + g] : 0; }
+                    for (int e = 0; e < E; ++e) cr[e] = Rj[min(r0 + e * G + g, lastR)];
+                    if (IS_A) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const bool in = e * G + g < lenr;
-                same = same && (!in || (el[r][e] == pc[e] && (!IS_A || cb[r][e] == pb[e])));
-            }
-            if (cand && !(__ballot(cand && !same) & gmask)) { cls[r] = (int)(tg >> 20); searching[r] = false; }
-        }
-        // 2. the device-wide table, probe by probe, the R row sets TOGETHER: a probe is four dependent round trips (table
-        // word -> the representative's row pointers -> its columns -> their classes), and with the heads of a grid matrix
-        // nearly every row set of a workgroup's one pass meets its class for the first time (round 3 went through the
-        // row sets one after the other: 8 x 4 round trips).
-        for (int probe = 0; probe < kClassProbe; ++probe) {
-            bool anySearching = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) anySearching = anySearching || __any(searching[r]);
-            if (!anySearching) break;
-            // An entry changes once (empty -> final).  The load is device-coherent: a plain one could keep
-            // returning the "empty" line this XCD's L2 cached before another XCD claimed the slot.
-            unsigned long long v[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                v[r] = kClassEmpty;
-                if (searching[r] && g == 0) v[r] = __hip_atomic_load(&table[sl[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (searching[r] && g == 0 && v[r] == kClassEmpty) {
-                    const unsigned long long mine = ((unsigned long long)h[r] << 32) | (unsigned)rowv[r];
-                    const unsigned long long old = atomicCAS(&table[sl[r]], kClassEmpty, mine);
-                    v[r] = old == kClassEmpty ? mine : old;
-                }
-                v[r] = (unsigned long long)__shfl((long long)v[r], leaderLane, 64);
-            }
-            // does a row equal the representative of the slot, entry by entry?  (one entry per lane and pass; the group votes)
-            bool cand[R], need[R];
-            int rep[R];
-            bool anyNeed = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                rep[r] = (int)(unsigned)v[r];
-                cand[r] = searching[r] && (unsigned)(v[r] >> 32) == h[r];
-                need[r] = cand[r] && rep[r] != (int)rowv[r];       // (the row that claimed the slot is its own representative)
-                anyNeed = anyNeed || __any(need[r]);
-            }
-            bool same[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) same[r] = true;
-            if (anyNeed) {                                         // (rare once the block's cache is warm)
-                int q0[R], q1[R], cr[R][E], cbr[R][E];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int rp = need[r] ? rep[r] : 0;
-                    q0[r] = Rp[rp];
-                    q1[r] = Rp[rp + 1];
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int lastR = q1[r] > q0[r] ? q1[r] - 1 : 0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) cr[r][e] = Rj[min(q0[r] + e * G + g, lastR)];
-                }
-                if (IS_A) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int e = 0; e < E; ++e) cbr[r][e] = classB[cr[r][e]];
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    bool sm = q1[r] - q0[r] == len[r];
+                        for (int e = 0; e < E; ++e) cbr[e] = classB[cr[e]];
+                    }
+                    same = r1 - r0 == lenr;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
-                        const bool in = e * G + g < len[r];
-                        sm = sm && (!in || (el[r][e] == cr[r][e] - rep[r] && (!IS_A || cb[r][e] == cbr[r][e])));
+                        const bool in = e * G + g < lenr;
+                        same = same && (!in || (el[r][e] == cr[e] - rp && (!IS_A || cb[r][e] == cbr[e])));
                     }
-                    same[r] = sm || !need[r];
+                    same = same || rep == (int)row;
                 }
-            }
+                return cand && !(__ballot(cand && !same) & gmask);
+            };
+            bool searching = ok[r];
+            const int ci = (int)(hr & (NC - 1));
+            {
+                unsigned tg = 0xFFFFFFFFu;
+                if (searching && g == 0) tg = __hip_atomic_load(&ctag[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tg = (unsigned)__shfl((int)tg, leaderLane, 64);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the pattern is read after its tag, never before
+                const bool cand = searching && tg < kBusy && (tg & 0xFFFFFu) == (hr >> 12);
+                bool same = clen[ci] == lenr;
+                int pc[E], pb[E];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (cand[r] && !(__ballot(cand[r] && !same[r]) & gmask)) {
-                    cls[r] = sl[r];
-                    searching[r] = false;
+                for (int e = 0; e < E; ++e) { pc[e] = cpat[ci][e * G + g]; pb[e] = IS_A ? cpatB[ci][e * G + g] : 0; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool in = e * G + g < lenr;
+                    same = same && (!in || (el[r][e] == pc[e] && (!IS_A || cb[r][e] == pb[e])));
+                }
+                if (cand && !(__ballot(cand && !same) & gmask)) { cls = (int)(tg >> 20); searching = false; }
+            }
+            const unsigned long long mine = ((unsigned long long)hr << 32) | (unsigned)row;
+            int s = (int)(hr & (kClassSlots - 1));
+            for (int probe = 0; probe < kClassProbe; ++probe) {
+                if (!__any(searching)) break;
+                // An entry changes once (empty -> final).  The load is device-coherent: a plain one could keep
+                // returning the "empty" line this XCD's L2 cached before another XCD claimed the slot.
+                unsigned long long v = kClassEmpty;
+                if (searching && g == 0) {
+                    v = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == kClassEmpty) {
+                        const unsigned long long old = atomicCAS(&table[s], kClassEmpty, mine);
+                        v = old == kClassEmpty ? mine : old;
+                    }
+                }
+                v = (unsigned long long)__shfl((long long)v, leaderLane, 64);
+                const int rep = (int)(unsigned)v;
+                if (equals(searching && (unsigned)(v >> 32) == hr, rep)) {
+                    cls = s;
+                    searching = false;
                     // publish in the block's cache if its cell is still free
-                    const unsigned hr = h[r];
-                    const int ci = (int)(hr & (NC - 1));
                     unsigned won = 0;
                     if (g == 0) won = atomicCAS(&ctag[ci], 0xFFFFFFFFu, kBusy) == 0xFFFFFFFFu ? 1u : 0u;
                     won = (unsigned)__shfl((int)won, leaderLane, 64);
@@ -309,23 +272,20 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             const int pos = e * G + g;
-                            if (pos < len[r]) {
+                            if (pos < lenr) {
                                 cpat[ci][pos] = el[r][e];
                                 if (IS_A) cpatB[ci][pos] = cb[r][e];
                             }
                         }
-                        if (g == 0) clen[ci] = len[r];
+                        if (g == 0) clen[ci] = lenr;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (g == 0) ctag[ci] = ((unsigned)sl[r] << 20) | (hr >> 12);
+                        if (g == 0) ctag[ci] = ((unsigned)s << 20) | (hr >> 12);
                     }
                 }
-                sl[r] = (sl[r] + 1) & (kClassSlots - 1);
+                s = (s + 1) & (kClassSlots - 1);
             }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (live[r] && g == 0) classOut[rowv[r]] = cls[r];
-            if (__any(live[r] && cls[r] < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
+            if (live[r] && g == 0) classOut[row] = cls;
+            if (__any(live[r] && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
         }
     }
 }
@@ -349,8 +309,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
 // ones = none) and the scan's tile words.
 __global__ __launch_bounds__(256) void k_class_reset(int* __restrict__ small, int nSmall, int* __restrict__ cstats, int nStats,
                                                      int* __restrict__ headCnt, int nHead, unsigned long long* __restrict__ tab, int nTab,
-                                                     int* __restrict__ bigIdx, int nBig, unsigned long long* __restrict__ scanState, int nScan,
-                                                     unsigned* __restrict__ headBits, int nBits)
+                                                     int* __restrict__ bigIdx, int nBig, unsigned long long* __restrict__ scanState, int nScan)
 {
     const int i0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
     for (int i = i0; i < nSmall; i += step) small[i] = 0;
@@ -359,7 +318,6 @@ __global__ __launch_bounds__(256) void k_class_reset(int* __restrict__ small, in
     for (int i = i0; i < nTab; i += step) tab[i] = kClassEmpty;
     for (int i = i0; i < nBig; i += step) bigIdx[i] = -1;
     for (int i = i0; i < nScan; i += step) scanState[i] = 0ull;
-    for (int i = i0; i < nBits; i += step) headBits[i] = 0u;
 }
 
 // The period hint: eight rows spread over the matrix, each compared with the rows 1 .. 8 before it; the smallest
@@ -395,9 +353,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
                                                      const int* __restrict__ classB, int* __restrict__ classOut,
                                                      int* __restrict__ headList, int* __restrict__ headCount, int segCap,
                                                      const int* __restrict__ range,     // rows [range[0], range[1]] only (nullptr: all)
-                                                     int period,                        // a row is compared with the row `period` before it
-                                                     unsigned* __restrict__ bitsOut,    // rows of B: bit (row) set where the row REALLY differs from the row before (zeroed by k_class_reset)
-                                                     const unsigned* __restrict__ bitsIn)   // rows of A: that bitmap of B's rows instead of classB (nullptr: classB, final)
+                                                     int period)                        // a row is compared with the row `period` before it
 {
     constexpr int GPW = 64 / G;                                    // lane groups per wave
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);               // consecutive rows per lane group
@@ -427,36 +383,6 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
     for (int seq = 0; seq < period; ++seq) {
     auto row_at = [&](int q) { return pieceBegin + (long long)q * period + seq; };
     followP = -1;
-    // The row before the sequence's first row belongs to another wave's piece.  The first row is a head by decree (its
-    // followers need a head in THIS piece), but whether it really differs is found out here -- only rows that really
-    // differ leave a bit in B's bitmap, which is what the rows of A are compared through.
-    {
-        const long long pr = row_at(0) - period;
-        okP = false;
-        lenP = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { elP[e] = 0; cbP[e] = 0; }
-        if (pr >= first && row_at(0) < pieceEnd) {                 // (wave-uniform)
-            const int p0 = Rp[pr];
-            lenP = Rp[pr + 1] - p0;
-            okP = lenP <= G * E;
-            const int lastPos = okP && lenP > 0 ? p0 + lenP - 1 : 0;
-            int cP[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) cP[e] = Rj[min(p0 + e * G + g, lastPos)];
-            bool bad = false;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const bool in = okP && e * G + g < lenP;
-                elP[e] = in ? cP[e] - (int)pr : 0;
-                if (IS_A && bitsIn == nullptr) {
-                    cbP[e] = in ? classB[cP[e]] : 0;
-                    bad = bad || cbP[e] < 0;
-                }
-            }
-            if (IS_A && bitsIn == nullptr && (__ballot(bad) & gmask)) okP = false;
-        }
-    }
     for (int qbase = 0; qbase < perSeq && row_at(qbase) < pieceEnd; qbase += RPW) {
         const bool firstPass = qbase == 0;                         // (of this sequence: its first row is a head by decree)
         long long rowv[R];
@@ -480,29 +406,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
 #pragma unroll
             for (int e = 0; e < E; ++e) cc[r][e] = Rj[min(a0[r] + e * G + g, lastPos)];
         }
-        // Rows of A: the B row behind entry e of a row that repeats the row before (same relative columns) is the B row
-        // behind that row's entry e, plus `period`: it has the same class unless it really differs from ITS row before --
-        // its bit in B's bitmap (the R rows of a lane group look at consecutive bits: one 64-bit window per entry).
-        // Without the bitmap (the periods of A and B differ, or the window is too short): the classes of B, compared.
-        bool hb[R];                                                // (an entry of this lane hits such a bit)
-#pragma unroll
-        for (int r = 0; r < R; ++r) hb[r] = false;
-        if (IS_A && bitsIn != nullptr) {
-            unsigned w0[E], w1[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) { w0[e] = bitsIn[cc[0][e] >> 5]; w1[e] = bitsIn[(cc[0][e] >> 5) + 1]; }
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const unsigned long long win = (((unsigned long long)w1[e] << 32) | w0[e]) >> (cc[0][e] & 31);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int idx = cc[r][e] - cc[0][e];
-                    const bool bit = idx < 0 || idx > 32 || ((win >> (idx & 63)) & 1ull) != 0ull;   // (beyond the window: as if set)
-                    hb[r] = hb[r] || (bit && ok[r] && e * G + g < len[r]);
-                    cb[r][e] = 0;
-                }
-            }
-        } else if (IS_A) {
+        if (IS_A) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -529,7 +433,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
                 const int src = max(lane - G, 0);
                 const bool okB = grp ? (bool)__shfl((int)ok[R - 1], src, 64) : okP;
                 const int lenB = grp ? __shfl(len[R - 1], src, 64) : lenP;
-                differs = hb[0] || !ok[0] || !okB || len[0] != lenB;
+                differs = (grp == 0 && firstPass) || !ok[0] || !okB || len[0] != lenB;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int elB = __shfl(el[R - 1][e], src, 64);
@@ -540,13 +444,11 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_heads(int nrows, con
                     }
                 }
             } else {
-                differs = hb[r] || !ok[r] || !ok[r - 1] || len[r] != len[r - 1];
+                differs = !ok[r] || !ok[r - 1] || len[r] != len[r - 1];
 #pragma unroll
                 for (int e = 0; e < E; ++e) differs = differs || el[r][e] != el[r - 1][e] || (IS_A && cb[r][e] != cb[r - 1][e]);
             }
-            const bool really = live[r] && (__ballot(differs) & gmask) != 0;
-            head[r] = really || (live[r] && r == 0 && grp == 0 && firstPass);   // (a piece's first row: a head by decree)
-            if (!IS_A && bitsOut != nullptr && really && g == 0) atomicOr(&bitsOut[rowv[r] >> 5], 1u << (rowv[r] & 31));
+            head[r] = live[r] && (__ballot(differs) & gmask) != 0;
         }
         // the head every row follows: the last head at or before it in the wave's walk (as positions of the walk)
         int lastIn = -1;

@@ -143,11 +143,10 @@ struct bhs_handle {
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
     int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
-    int classBitsOn = 1;                 // ... and find A's heads through the bitmap of B rows that really differ (B's table pass runs beside them)
     int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
-    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt, classHeadBits, classBigIdx, classBigMap;
+    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt, classBigIdx, classBigMap;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -1100,7 +1099,6 @@ int class_entries_per_lane(int G, int maxRow)
     if (full >= 2 && maxRow <= kClassMaxRow / 2) return full / 2;
     return full;
 }
-int class_rows_per_group(int E) { return E >= 8 ? 2 : (E >= 4 ? 4 : 8); }   // (R of k_class_heads / k_class_rows)
 template <typename F>
 int class_dispatch(int G, int E, F&& f)
 {
@@ -1139,9 +1137,7 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
     BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
-    BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(m, 1) + (size_t)std::max(k, 1) + 2 * (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
-    const int nBitWords = (std::max(k, 1) + 31) / 32 + 2;
-    BHS_TRY(ensure(h, h->classHeadBits, sizeof(unsigned) * (size_t)nBitWords));
+    BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
     // classes beyond the register kernels' tables are possible: their lists and the big numeric kernel (bhs_class_big.hip.h)
     const bool bigPossible = h->maxRowA > kClassMaxRow || h->maxRowB > kClassMaxRow || (long long)h->maxRowA * h->maxRowB > kClassMaxP;
     BHS_TRY(ensure(h, h->classBigIdx, sizeof(int) * kClassSlots));
@@ -1151,8 +1147,7 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nScanTiles, (int)(((long long)m + 1 + kScanTile - 1) / kScanTile))));
     hipLaunchKernelGGL(k_class_reset, dim3(32), dim3(256), 0, h->stream, small, (int)S_ZERO_END, small + S_CT_SLOTS, (int)CS_INTS,
                        (int*)h->classHeadCnt.p, 2 * 16 * kClassHeadSegs, (unsigned long long*)h->classTab.p, 2 * kClassSlots,
-                       (int*)h->classBigIdx.p, bigPossible ? kClassSlots : 0, (unsigned long long*)h->blockSum.p, nScanTiles,
-                       (unsigned*)h->classHeadBits.p, nBitWords);
+                       (int*)h->classBigIdx.p, bigPossible ? kClassSlots : 0, (unsigned long long*)h->blockSum.p, nScanTiles);
     BHS_HIP(hipGetLastError());
     for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
     unsigned long long* tabB = (unsigned long long*)h->classTab.p;
@@ -1163,9 +1158,6 @@ int symbolic_class(bhs_handle* h)
     // Three launches per matrix: k_class_heads lists the rows that differ from the row before them (and notes for
     // every other row which head it follows), k_class_rows classifies the listed rows, k_class_propagate hands the
     // classes on.  (class_heads = 0: k_class_rows over all rows, round 2's form.)
-    // Round 4: the heads of A's rows do not wait for B's classes -- they are found through the bitmap of B rows that
-    // really differ from the row before them (k_class_heads of B) -- so B's table pass and propagation run on a side
-    // stream beside them.
     auto rows_grid = [&](int n, int G) {
         return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
     };
@@ -1181,61 +1173,36 @@ int symbolic_class(bhs_handle* h)
         hipLaunchKernelGGL(k_class_col_range, dim3(gr), dim3(256), 0, h->stream, (long long)h->nnzA, h->dAj, rg);
         bRange = rg;
     }
-    int* headsB = (int*)h->classHeads.p;                            // (the two matrices' lists: B's may still be read while A's is written)
-    int* headsA = headsB + ((size_t)std::max(k, 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece);
+    int* headsL = (int*)h->classHeads.p;                            // (one list area: B's is used up before A's is written)
     int* nHeadsB = (int*)h->classHeadCnt.p;
     int* nHeadsA = nHeadsB + 16 * kClassHeadSegs;
-    unsigned* bits = (unsigned*)h->classHeadBits.p;
     // (~2 entries per lane in flight; a data set with rows of more than kClassMaxRow entries: 64 lanes, 2 or 4 entries each)
     const int GB = h->maxRowB > kClassMaxRow ? 64 : pow2_at_least(h->avgRowB / h->classPerLane, 4, 64);
     const int GA = h->maxRowA > kClassMaxRow ? 64 : pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);
-    const int EB = class_entries_per_lane(GB, h->maxRowB), EA = class_entries_per_lane(GA, h->maxRowA);
     const int periodA = std::max(1, std::min(8, h->periodA)), periodB = std::max(1, std::min(8, h->periodB));
-    // the bitmap serves when both matrices repeat at the same distance and a lane group's rows fit its 33-bit window
-    const bool useBits = h->classHeadsOn && h->classBitsOn && periodA == periodB && periodA * (class_rows_per_group(EA) - 1) <= 32;
-    hipStream_t side = useBits ? h->binStream[0] : h->stream;
-    int rc = BHS_SUCCESS;
-    if (h->classHeadsOn) {
-        const unsigned rowsGridList = (unsigned)std::max(1, h->numCU / kClassHeadSegs);
-        const unsigned propGrid = (unsigned)std::max<long long>(1, std::min<long long>(((long long)std::max(m, k) + 255) / 256, (long long)h->numCU * 8));
-        rc = class_dispatch(GB, EB, [&](auto gc, auto ec) {
-            constexpr int G = decltype(gc)::value, E = decltype(ec)::value;
-            hipLaunchKernelGGL((k_class_heads<false, G, E>), dim3(heads_grid(k, G)), dim3(kClassHeadsBlock), 0, h->stream, k, h->dBp, h->dBj,
-                               (const int*)nullptr, (int*)h->classB.p, headsB, nHeadsB, heads_cap(k, G), bRange, periodB, bits, (const unsigned*)nullptr);
-            if (useBits) {
-                if (hipEventRecord(h->evFork, h->stream) != hipSuccess || hipStreamWaitEvent(side, h->evFork, 0) != hipSuccess) return (int)BHS_ERR_LAUNCH;
-            }
-            hipLaunchKernelGGL((k_class_rows<false, G, E>), dim3(rowsGridList, kClassHeadSegs), dim3(kClassRowsBlock), 0, side, k, h->dBp, h->dBj,
-                               (const int*)nullptr, tabB, (int*)h->classB.p, cstats, (const int*)nullptr, (const int*)headsB, (const int*)nHeadsB, heads_cap(k, G));
-            hipLaunchKernelGGL(k_class_propagate, dim3(propGrid), dim3(256), 0, side, k, (int*)h->classB.p, bRange);
-            if (useBits && hipEventRecord(h->evJoin[0], side) != hipSuccess) return (int)BHS_ERR_LAUNCH;
+    const unsigned rowsGridList = (unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs));
+    const unsigned propGrid = (unsigned)std::max<long long>(1, std::min<long long>(((long long)std::max(m, k) + 255) / 256, (long long)h->numCU * 8));
+    // one matrix: its heads, their classes, the classes handed on -- or, without heads, every row through the table
+    auto classify = [&](auto isA, int n, const int* Rp, const int* Rj, const int* cb, unsigned long long* tab, int* out,
+                        const int* rng, int* nHeads, int G, int maxRow, int period) {
+        constexpr bool IS_A = decltype(isA)::value != 0;
+        return class_dispatch(G, class_entries_per_lane(G, maxRow), [&](auto gc, auto ec) {
+            constexpr int GG = decltype(gc)::value, E = decltype(ec)::value;
+            if (h->classHeadsOn) {
+                hipLaunchKernelGGL((k_class_heads<IS_A, GG, E>), dim3(heads_grid(n, GG)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out,
+                                   headsL, nHeads, heads_cap(n, GG), rng, period);
+                hipLaunchKernelGGL((k_class_rows<IS_A, GG, E>), dim3(rowsGridList, kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb,
+                                   tab, out, cstats, (const int*)nullptr, (const int*)headsL, (const int*)nHeads, heads_cap(n, GG));
+                hipLaunchKernelGGL(k_class_propagate, dim3(propGrid), dim3(256), 0, h->stream, n, out, rng);
+            } else
+                hipLaunchKernelGGL((k_class_rows<IS_A, GG, E>), dim3(rows_grid(n, GG)), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out,
+                                   cstats, rng, (const int*)nullptr, (const int*)nullptr, 0);
             return (int)BHS_SUCCESS;
         });
-        if (rc == BHS_SUCCESS) rc = class_dispatch(GA, EA, [&](auto gc, auto ec) {
-            constexpr int G = decltype(gc)::value, E = decltype(ec)::value;
-            hipLaunchKernelGGL((k_class_heads<true, G, E>), dim3(heads_grid(m, G)), dim3(kClassHeadsBlock), 0, h->stream, m, h->dAp, h->dAj,
-                               (const int*)h->classB.p, (int*)h->classC.p, headsA, nHeadsA, heads_cap(m, G), (const int*)nullptr, periodA,
-                               (unsigned*)nullptr, useBits ? (const unsigned*)bits : (const unsigned*)nullptr);
-            if (useBits && hipStreamWaitEvent(h->stream, h->evJoin[0], 0) != hipSuccess) return (int)BHS_ERR_LAUNCH;
-            hipLaunchKernelGGL((k_class_rows<true, G, E>), dim3(rowsGridList, kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, m, h->dAp, h->dAj,
-                               (const int*)h->classB.p, tabA, (int*)h->classC.p, cstats, (const int*)nullptr, (const int*)headsA, (const int*)nHeadsA, heads_cap(m, G));
-            hipLaunchKernelGGL(k_class_propagate, dim3(propGrid), dim3(256), 0, h->stream, m, (int*)h->classC.p, (const int*)nullptr);
-            return (int)BHS_SUCCESS;
-        });
-    } else {
-        rc = class_dispatch(GB, EB, [&](auto gc, auto ec) {
-            constexpr int G = decltype(gc)::value, E = decltype(ec)::value;
-            hipLaunchKernelGGL((k_class_rows<false, G, E>), dim3(rows_grid(k, G)), dim3(kClassRowsBlock), 0, h->stream, k, h->dBp, h->dBj,
-                               (const int*)nullptr, tabB, (int*)h->classB.p, cstats, bRange, (const int*)nullptr, (const int*)nullptr, 0);
-            return (int)BHS_SUCCESS;
-        });
-        if (rc == BHS_SUCCESS) rc = class_dispatch(GA, EA, [&](auto gc, auto ec) {
-            constexpr int G = decltype(gc)::value, E = decltype(ec)::value;
-            hipLaunchKernelGGL((k_class_rows<true, G, E>), dim3(rows_grid(m, G)), dim3(kClassRowsBlock), 0, h->stream, m, h->dAp, h->dAj,
-                               (const int*)h->classB.p, tabA, (int*)h->classC.p, cstats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0);
-            return (int)BHS_SUCCESS;
-        });
-    }
+    };
+    int rc = classify(template_int<0>{}, k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, nHeadsB, GB, h->maxRowB, periodB);
+    if (rc == BHS_SUCCESS)
+        rc = classify(template_int<1>{}, m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, nHeadsA, GA, h->maxRowA, periodA);
     if (rc != BHS_SUCCESS) return rc;
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
@@ -1864,7 +1831,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->longList); release(h->longPart);
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
     release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
-    release(h->classBigIdx); release(h->classBigMap); release(h->classHeadBits);
+    release(h->classBigIdx); release(h->classBigMap);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -2149,7 +2116,6 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_heads")) { h->classHeadsOn = value ? 1 : 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "class_bits")) { h->classBitsOn = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }

@@ -234,9 +234,6 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     bhs_class_big.hip.h whatever this says.
  *   "class_heads"     1 (default): only rows that differ from the row `period` rows before them are looked up in
  *                     the class table (period: sampled at bhs_set_data time, the unknowns per node); 0: every row
- *   "class_bits"      1 (default): A's rows are compared with the row before them through the bitmap of B rows that really
- *                     differ from theirs (B's table pass then runs on a side stream beside A's heads pass); 0: through
- *                     B's final classes, one pass after the other (round 3's form)
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),
