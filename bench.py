@@ -37,7 +37,7 @@ def workload_dims(name, world):
             dims = (128, 128, 128 * world)
         return "poisson27pt", dims, "weak"
     table = {"p27_128": ("poisson27pt", (128, 128, 128)), "p27_160": ("poisson27pt", (160, 160, 160)),
-             "p27_256": ("poisson27pt", (256, 256, 256)), "p27_51": ("poisson27pt", (51, 51, 51)),
+             "p27_256": ("poisson27pt", (256, 256, 256)), "p27_51": ("poisson27pt", (51, 51, 51)), "p27_72": ("poisson27pt", (72, 72, 72)),
              "p5_1024": ("poisson5pt", (1024, 1024, 1)), "p5_256": ("poisson5pt", (256, 256, 1)),
              "p9_1024": ("poisson9pt", (1024, 1024, 1))}
     st, dims = table[name]
@@ -49,8 +49,11 @@ def gpu_state():
     and after the timed loop so that a run-to-run difference can be told from a different state of the GPU."""
     import subprocess
     try:
+        # (a clean environment: under rocprofv3 the profiler's preloaded library would initialise the GPU in the child
+        # before rocm-smi's `#!/usr/bin/env python3` hop, and the GPU boxes refuse an exec after that)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
         p = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20, env=env)
         card = next(iter(json.loads(p.stdout).values()))
         out = {}
         for key, val in card.items():
@@ -180,6 +183,12 @@ def main():
     bh = facade.bhsparse()
     err = bh.initPlatform(plats, device=local_rank)
     assert err == 0, facade._lib.strerror(err)
+    # BENCH_LIB_OPTS=key=value,..: library options for a MEASUREMENT run (tools/prof.sh of the general pipeline); the line says so
+    lib_opts = os.environ.get("BENCH_LIB_OPTS", "")
+    for kv in lib_opts.split(","):
+        if kv:
+            k_, v_ = kv.split("=")
+            assert bh.set_option(k_, int(v_)) == 0, kv
     t_setup = time.perf_counter()
     err = bh.initData_device(r1 - r0, m, m, nnzA, Ax, Ap, Aj, nnzB, Bx, Bp, Bj)
     setup_ms = (time.perf_counter() - t_setup) * 1e3     # bhs_set_data_device: row-length and sortedness scans (host-synchronous)
@@ -204,6 +213,10 @@ def main():
             if os.environ.get("BENCH_NATIVE_FAIL") == "init":       # (test hook)
                 raise RuntimeError("injected")
             native = bdist.NativeDist(bh, world=world, rank=rank)
+            # BENCH_VALUES_ONLY=1: column indices of the other ranks' blocks rebuilt from their row classes instead of
+            # received (include/bhsparse_dist.h, option "values_only"): 8 instead of 12 bytes per entry on every link
+            if os.environ.get("BENCH_VALUES_ONLY", "1") == "1":
+                assert native.set_option("values_only", 1) == 0
         except Exception as e:
             why = "init: %s" % e
         if world > 1:
@@ -551,7 +564,8 @@ def main():
                    "values": "1+lcg%9 seed 20140519", "gather_in_step": bool((world > 1 or force_gather) and not args.no_gather),
                    "gather": ("native ncclSend/ncclRecv groups, %d row ranges overlapped" % sub_blocks) if native is not None
                              else ("torch batch_isend_irecv" if (world > 1 or force_gather) and not args.no_gather else None),
-                   "row_blocks": "balanced by products" if world > 1 else "single"},
+                   "row_blocks": "balanced by products" if world > 1 else "single",
+                   "library_options": lib_opts or None},
         "ms_min": round(float(np.min(step_ms)), 4), "ms_median": round(float(np.median(step_ms)), 4),
         "setup_ms": round(setup_ms, 4), "setup_ms_warm": round(setup_ms_warm, 4),
         "ms_per_step_incl_setup": incl_setup, "fresh_handles": fresh, "gpu_state": {"before": state_before, "after": state_after},
@@ -563,6 +577,7 @@ def main():
         "gather_ms_per_step": round(ms_per_step - t_compute / args.steps, 4) if (world > 1 or force_gather) else 0.0,
         "gather_link_floor_ms": round(native.link_floor_ms(), 4) if native is not None else None,
         "nranks_seen": native.nranks() if native is not None else None,
+        "gather_values_only": native.values_only_used() if native is not None else None,
         "native_fallback": native_fallback[0],
         "native_ms_per_step": [round(x / args.steps, 4) for x in gather_ms] if native is not None else None,
         "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),

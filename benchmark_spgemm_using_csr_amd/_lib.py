@@ -55,6 +55,8 @@ SYMBOLS = {
     "bhs_get_kernel_stats": (_i, [_vp, C.POINTER(KernelStat), _i]),
     "bhs_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "bhs_get_info": (_i, [_vp, C.c_char_p, C.POINTER(_i64)]),
+    "bhs_get_class_tables_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "bhs_expand_class_columns_device": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "bhs_strerror": (C.c_char_p, [_i]),
     "bhs_version": (C.c_char_p, []),
 }

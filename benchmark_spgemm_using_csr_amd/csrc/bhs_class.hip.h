@@ -49,7 +49,8 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_SUMS = 8 /* kClassSumSlots x u64: products */, CS_RANGE = 8 + 2 * kClassSumSlots /* 2 ints: columns of A */,
        CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3 /* words of their longest list */,
        CS_SCANTICKET = 8 + 2 * kClassSumSlots + 4 /* tile numbers of k_class_scan */,
-       CS_INTS = 8 + 2 * kClassSumSlots + 5 };
+       CS_HEADS = 8 + 2 * kClassSumSlots + 5 /* rows of A that went through the class table (k_class_rows on the heads' lists) */,
+       CS_INTS = 8 + 2 * kClassSumSlots + 6 };
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 {
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     if (rowList != nullptr) {                                      // (positions in the segment's list from here on)
         rowList += (size_t)blockIdx.y * segCap;
         nrows = rowCount[16 * blockIdx.y];
+        if (IS_A && blockIdx.x == 0 && tid == 0) atomicAdd(&stats[CS_HEADS], nrows);   // (the host's verdict: rows in stretches, or every row for itself?)
     } else if (range != nullptr) {                                 // (wave-uniform values)
         const int lo = range[0], hi = range[1];
         first = lo <= hi ? lo : 0;
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(256) void k_class_reset(int* __restrict__ small, in
 
 // The period hint: eight rows spread over the matrix, each compared with the rows 1 .. 8 before it; the smallest
 // distance at which a sample repeats, by majority (1 when there is none).  One wave, at hand-over time.
-__global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out)
+__global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out,
+                                                   int* __restrict__ local = nullptr, int ncols = 0)
 {
     const int lane = threadIdx.x, smp = lane >> 3, d = (lane & 7) + 1;
     const long long row = (long long)(smp + 1) * nrows / 9;
@@ -341,6 +344,23 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
     int best = 1;
     for (int q = 2; q <= 8; ++q) if (count[q] > count[best]) best = q;
     if (lane == 0) *out = count[best] >= 4 ? best : 1;
+    // Second hint (round 4), for the lane-per-row kernels: do the entries of a row stay near its diagonal?  Those kernels
+    // give a row to a lane; the 64 lanes of a wave then read the B rows behind 64 consecutive rows of A -- neighbouring
+    // memory on a grid or a band, 64 different places for random columns (uniform random, 8 per row, 2^20 rows: 3.8 ms
+    // on the lane kernels, 1.4 ms on the wave kernels).  64 sampled rows: mean |column - row| < columns / 16.
+    if (local != nullptr) {
+        const long long row = (long long)(lane + 1) * nrows / 65;
+        long long dist = 0;
+        int cnt = 0;
+        if (row < nrows) {
+            const int a0 = Rp[row], len = min(Rp[row + 1] - a0, 64);
+            for (int e = 0; e < len; ++e) { const long long dd = (long long)Rj[a0 + e] - row; dist += dd < 0 ? -dd : dd; }
+            cnt = len;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dist += __shfl_xor(dist, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+        if (lane == 0) *local = (cnt == 0 || dist * 16 < (long long)cnt * ncols) ? 1 : 0;
+    }
 }
 
 constexpr int kClassHeadSegs = 8;
@@ -772,6 +792,25 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         atomicMax(&stats[CS_MAXNNZ], nnz);
         atomicMax(&stats[CS_MAXNA], nA);
         atomicAdd(&stats[CS_CLASSES], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// colIndC of rows from their classes alone (bhs_expand_class_columns_device: the values-only all-gatherv of the
+// multi-GPU layer rebuilds the columns of the other ranks' blocks instead of receiving them).  One wave per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_class_expand_columns(int n, int row0, const int* __restrict__ classC,
+                                                              const int4* __restrict__ classInfo, const int* __restrict__ classRel,
+                                                              int relStride, const int* __restrict__ Cp, int* __restrict__ Cj)
+{
+    const int lane = threadIdx.x & 63;
+    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
+        const int cls = classC[i];
+        if (cls < 0) continue;
+        const int nnz = classInfo[cls].z;
+        const long long out = Cp[i];
+        const int* rel = classRel + (size_t)cls * relStride;
+        for (int s = lane; s < nnz; s += 64) Cj[out + s] = rel[s] + row0 + (int)i;
     }
 }
 

@@ -32,12 +32,21 @@ struct bhs_dist {
     bhs_value_t* ownCx = nullptr;
     long long ownRows = 0, ownCap = 0, lastTotal = 0;
     int lastRows = 0;
+    // values-only mode (option "values_only"): when every rank's multiply went by row classes, colIndC of the other
+    // ranks' blocks is REBUILT from their classes (4 bytes per row + the class tables) instead of received (4 bytes per
+    // entry): two thirds of the bytes on every link
+    int valuesOnly = 0, lastValuesOnly = 0;
+    int* classAll = nullptr;            // class of every row of the job (this rank's block copied in, the others received)
+    long long classAllRows = 0;
+    int* tablesAll = nullptr;           // world x (classInfo | classRel) of every rank
+    long long tablesAllInts = 0;
 };
 
 namespace {
 
 constexpr int kMaxSub = 16;
-constexpr int kSizeSlots = kMaxSub + 4;   // m_local (or an error code < 0), nnzCt, capacity (-1: own), cut[0..S]
+constexpr int kSizeSlots = kMaxSub + 5;   // m_local (or an error code < 0), nnzCt, capacity (-1: own), cut[0..S], [kMaxSub + 4]: this rank can serve the values-only mode
+constexpr int kFlagSlot = kMaxSub + 4;
 
 #define DIST_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); return (int)BHS_ERR_LAUNCH; } } while (0)
 #define DIST_NCCL(call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { fprintf(stderr, "[bhsparse_dist] %s: %s\n", #call, ncclGetErrorString(r__)); return (int)BHS_ERR_LAUNCH; } } while (0)
@@ -63,9 +72,12 @@ __global__ void k_gather_cuts(int S, int m_local, const int* __restrict__ rowPtr
 // tests replay the plans of all ranks of a job against each other (every send must meet a receive of the same size, in
 // the same order, between the same two ranks; the received pieces must tile the assembled arrays exactly once) --
 // the N > 1 transfers cannot run on the one-GPU development boxes.
-struct PlanOp { long long kind, peer, array, offset, count, group; };   // kind 0 send / 1 recv; array 0 col, 1 val, 2 rowPtr
+struct PlanOp { long long kind, peer, array, offset, count, group; };   // kind 0 send / 1 recv; array 0 col, 1 val, 2 rowPtr, 3 class of every row, 4 class tables
 
-static int build_plan(int W, int me, int S, const long long* sizes /* W x kSizeSlots */, PlanOp* out, int cap)
+// valuesOnly: no colInd transfers; instead, with the first range, the classes of the block's rows (array 3, in rows)
+// and the rank's class tables (array 4: tableInts ints per rank, rank r's at r * tableInts)
+static int build_plan(int W, int me, int S, const long long* sizes /* W x kSizeSlots */, PlanOp* out, int cap,
+                      bool valuesOnly = false, long long tableInts = 0)
 {
     std::vector<long long> rowOff(W + 1, 0), nnzOff(W + 1, 0);
     for (int r = 0; r < W; ++r) {
@@ -83,18 +95,22 @@ static int build_plan(int W, int me, int S, const long long* sizes /* W x kSizeS
             const int dst = (me + step) % W, src = (me - step + W) % W;
             const long long a = cut_nnz(me, s), b = cut_nnz(me, s + 1);
             if (b > a) {
-                put(0, dst, 0, nnzOff[me] + a, b - a, s);
+                if (!valuesOnly) put(0, dst, 0, nnzOff[me] + a, b - a, s);
                 put(0, dst, 1, nnzOff[me] + a, b - a, s);
             }
             const long long ra = cut_nnz(src, s), rb = cut_nnz(src, s + 1);
             if (rb > ra) {
-                put(1, src, 0, nnzOff[src] + ra, rb - ra, s);
+                if (!valuesOnly) put(1, src, 0, nnzOff[src] + ra, rb - ra, s);
                 put(1, src, 1, nnzOff[src] + ra, rb - ra, s);
             }
             if (s == 0) {                                       // row pointers travel with the first range
                 const long long mm = rowOff[me + 1] - rowOff[me], rm = rowOff[src + 1] - rowOff[src];
                 if (mm > 0) put(0, dst, 2, rowOff[me], mm, s);
                 if (rm > 0) put(1, src, 2, rowOff[src], rm, s);
+                if (valuesOnly) {                               // ... and what the columns are rebuilt from
+                    if (mm > 0) { put(0, dst, 3, rowOff[me], mm, s); put(0, dst, 4, (long long)me * tableInts, tableInts, s); }
+                    if (rm > 0) { put(1, src, 3, rowOff[src], rm, s); put(1, src, 4, (long long)src * tableInts, tableInts, s); }
+                }
             }
         }
     return n;
@@ -161,6 +177,8 @@ int bhs_dist_destroy(bhs_dist* d)
     if (d->ownRp) (void)hipFree(d->ownRp);
     if (d->ownCj) (void)hipFree(d->ownCj);
     if (d->ownCx) (void)hipFree(d->ownCx);
+    if (d->classAll) (void)hipFree(d->classAll);
+    if (d->tablesAll) (void)hipFree(d->tablesAll);
     delete d;
     return BHS_SUCCESS;
 }
@@ -258,14 +276,24 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
         open = err == BHS_SUCCESS;
     }
     if (!err) err = bhs_get_C_device(d->h, &lp, nullptr, nullptr);
+    // values-only mode: can this rank's block be rebuilt from its row classes?
+    const int* cC = nullptr;
+    const void* cInfo = nullptr;
+    const int* cRel = nullptr;
+    int cSlots = 0, cStride = 0, cUsable = 0;
+    if (bhs_get_class_tables_device(d->h, &cC, &cInfo, &cRel, &cSlots, &cStride, &cUsable) != BHS_SUCCESS) cUsable = 0;   // (the table geometry comes back either way)
+    if (err || !d->valuesOnly) cUsable = 0;
+    const long long tableInts = (long long)cSlots * 4 + (long long)cSlots * cStride;   // (classInfo | classRel, the same on every rank of one build)
 
     // ---- (1) sizes of every rank: status | rows, products, capacity, rowPtrC at the sub-block boundaries
     long long* mine = d->dSizes + (size_t)me * kSizeSlots;
     {
         // (error codes are negative: slot 0 < 0 tells the others that this rank's symbolic half failed, and how)
-        long long head[3] = {err ? (long long)(err < 0 ? err : -1) : (long long)m_local, (long long)nnzCt, own ? -1 : (long long)capacity};
+        long long head[4] = {err ? (long long)(err < 0 ? err : -1) : (long long)m_local, (long long)nnzCt, own ? -1 : (long long)capacity,
+                             cUsable ? tableInts : 0};                                     // [3] -> the flag slot: 0, or the table size
         memcpy(d->hSizes, head, sizeof(head));
-        bool okc = hipMemcpyAsync(mine, d->hSizes, sizeof(head), hipMemcpyHostToDevice, d->hstream) == hipSuccess;
+        bool okc = hipMemcpyAsync(mine, d->hSizes, 3 * sizeof(long long), hipMemcpyHostToDevice, d->hstream) == hipSuccess &&
+                   hipMemcpyAsync(mine + kFlagSlot, d->hSizes + 3, sizeof(long long), hipMemcpyHostToDevice, d->hstream) == hipSuccess;
         if (okc && !err) {
             hipLaunchKernelGGL(k_gather_cuts, dim3(1), dim3(64), 0, d->hstream, S, m_local, lp, mine + 3);
             okc = hipGetLastError() == hipSuccess;
@@ -296,6 +324,15 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
         caps[r] = sz[2];
     }
     const long long total = nnzOff[W];
+    // values-only: every rank asked for it and can serve it (same table size everywhere); a rank without rows does not matter
+    // (judged from the exchanged numbers alone, so that every rank -- also one without rows or without the option -- agrees)
+    bool vo = tableInts > 0, anyRows = false;
+    for (int r = 0; r < W && vo; ++r) {
+        const long long* sz = sizes.data() + (size_t)r * kSizeSlots;
+        if (sz[0] > 0) { anyRows = true; if (sz[kFlagSlot] != tableInts) vo = false; }
+    }
+    vo = vo && anyRows;
+    d->lastValuesOnly = vo ? 1 : 0;
     if (!verdict && rowOff[W] != m_total) verdict = BHS_ERR_INVALID_ARG;
     if (!verdict && total > 0x7fffffffLL) verdict = BHS_ERR_NNZ_OVERFLOW;
     for (int r = 0; r < W && !verdict; ++r)
@@ -321,11 +358,33 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
     d->lastTotal = total;
     d->lastRows = m_total;
     if (!ready && total > 0 && (!d_colIndC || !d_valC)) ready = BHS_ERR_INVALID_ARG;
+    if (!ready && vo) {                                             // where the others' classes and tables land
+        if ((long long)m_total > d->classAllRows) {
+            if (d->classAll) (void)hipFree(d->classAll);
+            d->classAll = nullptr; d->classAllRows = 0;
+            if (hipMalloc((void**)&d->classAll, sizeof(int) * (size_t)std::max(m_total, 1)) != hipSuccess) { (void)hipGetLastError(); ready = BHS_ERR_ALLOC; }
+            else d->classAllRows = m_total;
+        }
+        if (!ready && tableInts * W > d->tablesAllInts) {
+            if (d->tablesAll) (void)hipFree(d->tablesAll);
+            d->tablesAll = nullptr; d->tablesAllInts = 0;
+            if (hipMalloc((void**)&d->tablesAll, sizeof(int) * (size_t)(tableInts * W)) != hipSuccess) { (void)hipGetLastError(); ready = BHS_ERR_ALLOC; }
+            else d->tablesAllInts = tableInts * W;
+        }
+        if (!ready && m_local > 0) {                                // this rank's share of both, in place (the sends read them there)
+            int* tb = d->tablesAll + (size_t)me * tableInts;
+            if (hipMemcpyAsync(d->classAll + rowOff[me], cC, sizeof(int) * (size_t)m_local, hipMemcpyDeviceToDevice, d->hstream) != hipSuccess ||
+                hipMemcpyAsync(tb, cInfo, sizeof(int) * 4 * (size_t)cSlots, hipMemcpyDeviceToDevice, d->hstream) != hipSuccess ||
+                hipMemcpyAsync(tb + (size_t)cSlots * 4, cRel, sizeof(int) * (size_t)cSlots * cStride, hipMemcpyDeviceToDevice, d->hstream) != hipSuccess)
+                ready = BHS_ERR_LAUNCH;
+        }
+    }
     // per-link floor: the largest block this rank receives over one link
     long long worst = 0;
     for (int r = 0; r < W; ++r)
-        if (r != me) worst = std::max(worst, (nnzOff[r + 1] - nnzOff[r]) * (long long)(sizeof(int) + sizeof(bhs_value_t)) +
-                                                 (rowOff[r + 1] - rowOff[r]) * (long long)sizeof(int));
+        if (r != me) worst = std::max(worst, (nnzOff[r + 1] - nnzOff[r]) * (long long)((vo ? 0 : sizeof(int)) + sizeof(bhs_value_t)) +
+                                                 (rowOff[r + 1] - rowOff[r]) * (long long)sizeof(int) * (vo ? 2 : 1) +
+                                                 (vo && rowOff[r + 1] > rowOff[r] ? tableInts * (long long)sizeof(int) : 0));
     d->linkFloorMs = (double)worst / 153.0e9 * 1e3;
     // this rank's block is produced in place: the numeric kernels write into the assembled arrays
     if (!ready) ready = bhs_set_output_device(d->h, d_colIndC ? d_colIndC + nnzOff[me] : nullptr,
@@ -352,8 +411,8 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
     auto cut_row = [&](int r, int s) { return (int)((long long)(rowOff[r + 1] - rowOff[r]) * s / S); };
     std::vector<PlanOp> plan;
     if (W > 1) {
-        plan.resize((size_t)S * (W - 1) * 6);
-        const int np = build_plan(W, me, S, sizes.data(), plan.data(), (int)plan.size());
+        plan.resize((size_t)S * (W - 1) * 10);
+        const int np = build_plan(W, me, S, sizes.data(), plan.data(), (int)plan.size(), vo, tableInts);
         plan.resize((size_t)np);
     }
     size_t next = 0;
@@ -376,7 +435,9 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
             ncclDataType_t type = ncclInt32;
             if (op.array == 0) { ptr = d_colIndC + op.offset; count = (size_t)op.count; }
             else if (op.array == 1) { ptr = d_valC + op.offset; count = (size_t)op.count * sizeof(bhs_value_t); type = ncclInt8; }
-            else { ptr = d_rowPtrC + op.offset; count = (size_t)op.count; }
+            else if (op.array == 2) { ptr = d_rowPtrC + op.offset; count = (size_t)op.count; }
+            else if (op.array == 3) { ptr = d->classAll + op.offset; count = (size_t)op.count; }
+            else { ptr = d->tablesAll + op.offset; count = (size_t)op.count; }
             const ncclResult_t r = op.kind == 0 ? ncclSend(ptr, count, type, (int)op.peer, d->comm, d->cstream)
                                                 : ncclRecv(ptr, count, type, (int)op.peer, d->comm, d->cstream);
             if (r != ncclSuccess && first == ncclSuccess) first = r;   // remembered; the group is closed before anything else
@@ -389,6 +450,18 @@ int bhs_dist_spgemm_allgatherv(bhs_dist* d, int m_local, int m_total, int sub_bl
         const int rcFin = bhs_spgemm_finish(d->h, nullptr);
         open = false;
         if (rcFin != BHS_SUCCESS && !numErr) numErr = rcFin;
+    }
+    if (vo && W > 1) {
+        // the other ranks' column indices, rebuilt behind their receives: entry s of a row = its class's relative column
+        // s + the row's number in ITS rank's block (the classes were made on that block's local row numbers)
+        for (int r = 0; r < W; ++r) {
+            const long long rows = rowOff[r + 1] - rowOff[r];
+            if (r == me || rows == 0) continue;
+            const int* tb = d->tablesAll + (size_t)r * tableInts;
+            const int rcE = bhs_expand_class_columns_device((void*)d->cstream, (int)rows, 0, d->classAll + rowOff[r], (const void*)tb,
+                                                            tb + (size_t)cSlots * 4, cStride, d_rowPtrC + rowOff[r], d_colIndC);
+            if (rcE != BHS_SUCCESS && !numErr) numErr = rcE;
+        }
     }
     const double t2 = now_ms();
     if (hipEventRecord(d->evDone, d->cstream) != hipSuccess || hipStreamSynchronize(d->cstream) != hipSuccess)
@@ -419,7 +492,32 @@ int bhs_dist_nranks(bhs_dist* d, int* nranks_out)
 
 double bhs_dist_last_link_floor_ms(bhs_dist* d) { return d ? d->linkFloorMs : 0.0; }
 
+int bhs_dist_set_option(bhs_dist* d, const char* key, int64_t value)
+{
+    if (!d || !key) return BHS_ERR_INVALID_ARG;
+    if (!strcmp(key, "values_only")) { d->valuesOnly = value ? 1 : 0; return BHS_SUCCESS; }
+    return BHS_ERR_INVALID_ARG;
+}
+
+int bhs_dist_last_values_only(bhs_dist* d) { return d ? d->lastValuesOnly : 0; }
+
+static int plan_impl(int world, int rank, int sub_blocks, const int64_t* rows, const int64_t* cuts, int64_t* ops_out, int cap_ops,
+                     bool valuesOnly, long long tableInts);
+
 int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t* rows, const int64_t* cuts, int64_t* ops_out, int cap_ops)
+{
+    return plan_impl(world, rank, sub_blocks, rows, cuts, ops_out, cap_ops, false, 0);
+}
+
+int bhs_dist_plan_values_only(int world, int rank, int sub_blocks, const int64_t* rows, const int64_t* cuts, int64_t table_ints,
+                              int64_t* ops_out, int cap_ops)
+{
+    if (table_ints <= 0) return BHS_ERR_INVALID_ARG;
+    return plan_impl(world, rank, sub_blocks, rows, cuts, ops_out, cap_ops, true, table_ints);
+}
+
+static int plan_impl(int world, int rank, int sub_blocks, const int64_t* rows, const int64_t* cuts, int64_t* ops_out, int cap_ops,
+                     bool valuesOnly, long long tableInts)
 {
     if (world < 1 || rank < 0 || rank >= world || sub_blocks < 1 || sub_blocks > kMaxSub || !rows || !cuts) return BHS_ERR_INVALID_ARG;
     std::vector<long long> sizes((size_t)world * kSizeSlots, 0);
@@ -428,7 +526,7 @@ int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t* rows, cons
         for (int s = 0; s <= sub_blocks; ++s) sizes[(size_t)r * kSizeSlots + 3 + s] = cuts[(size_t)r * (sub_blocks + 1) + s];
     }
     std::vector<PlanOp> plan((size_t)std::max(cap_ops, 0));
-    const int n = build_plan(world, rank, sub_blocks, sizes.data(), plan.data(), (int)plan.size());
+    const int n = build_plan(world, rank, sub_blocks, sizes.data(), plan.data(), (int)plan.size(), valuesOnly, tableInts);
     for (int i = 0; i < n && i < cap_ops; ++i) memcpy(ops_out + (size_t)i * 6, &plan[i], sizeof(PlanOp));
     return n;
 }

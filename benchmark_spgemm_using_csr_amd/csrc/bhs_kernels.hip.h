@@ -89,7 +89,7 @@ __device__ __forceinline__ int wave_sum(int v) { return wave_sum_dpp(v); }
 // rows each lane group keeps in flight: short rows (G <= 8 lanes per row: poisson5pt, web graphs) are pure
 // latency, 8 rows hide it (poisson5pt 1024^2: 0.109 -> 0.066 ms); longer rows are gather-bound and 4 is best
 __host__ __device__ constexpr int ub_rows_in_flight(int G) { return G <= 8 ? 8 : 4; }
-constexpr int kUbLongA = 512;       // A rows beyond this go to k_upper_bound_long (when the launch provides the list)
+constexpr int kUbLongA = 512;       // A rows beyond this go to k_upper_bound_long (when the launch provides the list); less where rows are short: 32 passes of the row's lane group
 constexpr int kLongParts = 16;      // workgroups that share one such row (also: one long B row in k_check_sorted_long)
 __host__ __device__ constexpr int long_parts(long long len)     // parts of >= 2048 entries
 {
@@ -109,9 +109,9 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
                                                      int* __restrict__ binCount, BinSpec spec,
                                                      const int2* __restrict__ cLen, int* __restrict__ keyOut,
                                                      int keyMax, int2* __restrict__ longList,
-                                                     int* __restrict__ longCount)
+                                                     int* __restrict__ longCount, int longThresh)
 {
-    // Rows of A with more than kUbLongA entries would be walked by their G lanes alone while the rest of the device
+    // Rows of A with more than longThresh (<= kUbLongA) entries would be walked by their G lanes alone while the rest of the device
     // idles (a 180 k-entry row: 7 ms); with a list to put them on (longList != nullptr) they are left to
     // k_upper_bound_long, which spreads every such row over 16 workgroups.
     // The per-row work is a chain of three dependent loads (rowPtrA -> colIndA -> rowPtrB) and little
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_upper_bound(int m, const int* __restric
             if (r < m) { a0_[k] = Ap[r]; a1_[k] = Ap[r + 1]; }
         }
     };
-    auto deferred = [&](int a0_, int a1_) { return longList != nullptr && a1_ - a0_ > kUbLongA; };
+    auto deferred = [&](int a0_, int a1_) { return longList != nullptr && a1_ - a0_ > longThresh; };
     auto load_aj = [&](const int (&a0_)[R], const int (&a1_)[R], int (&c_)[R]) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_spa(
 // ---------------------------------------------------------------------------
 constexpr int kLdsBitmapCols = 1 << 20;
 constexpr int kLdsBitmapBlock = 1024, kLdsBitmapChunk = 512;
+constexpr int kLdsBitmapEntryMajor = 256;      // average B row of a chunk from which the products are taken entry by entry
 
 template <bool NUM>
 constexpr size_t lds_bitmap_smem(int nWords)
@@ -1061,6 +1062,22 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                 sBase[tid] = b0 - (incl - len);
             }
             __syncthreads();
+            const int nE = min(CH, a1 - ca);
+            if ((long long)total >= (long long)nE * kLdsBitmapEntryMajor) {
+                // long B rows behind this chunk (a portal row of a web graph: a handful of directory pages): entry by
+                // entry, the whole workgroup along one B row -- coalesced loads, no search for the product's entry
+                for (int l = 0; l < nE; ++l) {
+                    const int end = sIncl[l], beg = l ? sIncl[l - 1] : 0;
+                    const long long bb = sBase[l];
+                    for (int p = beg + tid; p < end; p += BLOCK * 2) {
+                        const long long i0 = bb + p, i1 = i0 + BLOCK;
+                        const bool two = p + BLOCK < end;
+                        const int c0 = Bj[i0], c1 = Bj[two ? i1 : i0];
+                        f(c0, i0, ca + l);
+                        if (two) f(c1, i1, ca + l);
+                    }
+                }
+            } else {
             for (int p0 = 0; p0 < total; p0 += BLOCK * U) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1072,6 +1089,7 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
                         f(Bj[idx], idx, ca + l);
                     }
                 }
+            }
             }
             __syncthreads();
         }

@@ -127,7 +127,7 @@ struct bhs_handle {
     const value_t *dAx = nullptr, *dBx = nullptr;
     DevBuf ownA[3], ownB[3];
     int bSorted = 1;
-    int logL = 5, ubG = 8;
+    int logL = 5, ubG = 8, ubLong = kUbLongA;   // k_upper_bound: lanes per row of A, rows beyond ubLong entries go to its long list
     // C
     DevBuf Cp, Cj, Cx;
     long long nnzC = 0;
@@ -167,6 +167,7 @@ struct bhs_handle {
     int allowSmallB = 1;
     int waveFirst = 1;                   // same idea for rows bounded by maxRow(A) x maxRow(B) <= a wave table
     double avgRowA = 1.0, avgRowB = 1.0;
+    int localA = 1;                      // hint from bhs_set_data: A's entries stay near the diagonal (k_row_period) -- the lane kernels want that
     int laneFirst = 1;                   // matrices of tiny rows: no upper-bound pass, the lane symbolic kernel counts products too
     int maxRowB = 0;
     int kernelStats = 0;                 // per-kernel-family hipEvent pairs (bhs_get_kernel_stats): off unless asked for -- they cost
@@ -248,8 +249,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B */,
-       S_SMALL_INTS = 452 };
+       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal */,
+       S_SMALL_INTS = 454 };
 
 template <int V> struct template_int { static constexpr int value = V; };
 
@@ -831,10 +832,10 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
     int* small = (int*)h->small.p;
     // rows of A beyond kUbLongA entries (if the data set has any: maxRowA is the hint) are listed and summed by
     // k_upper_bound_long, 16 workgroups per row
-    const bool useLong = h->maxRowA > kUbLongA;
+    const bool useLong = h->maxRowA > h->ubLong;
     int2* longList = nullptr;
     if (useLong) {
-        const size_t cap = (size_t)h->nnzA / kUbLongA + 2;       // a listed row of len entries takes <= len / 512 entries
+        const size_t cap = (size_t)h->nnzA / h->ubLong + 2;       // a listed row of len entries takes <= len / ubLong entries
         BHS_TRY(ensure(h, h->longList, cap * sizeof(int2)));
         BHS_TRY(ensure(h, h->longPart, cap * 2 * sizeof(long long)));
         longList = (int2*)h->longList.p;
@@ -846,12 +847,12 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
                                h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
                                (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
                                (const int2*)h->cLen.p, (int*)h->symKey.p, keyMax, longList,              \
-                               small + S_UB_LONG);                                                       \
+                               small + S_UB_LONG, h->ubLong);                                            \
         else                                                                                             \
             hipLaunchKernelGGL((k_upper_bound<GG, false>), dim3((unsigned)grid), dim3(256), 0, h->stream,\
                                h->m, h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,               \
                                (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, spec,     \
-                               (const int2*)nullptr, (int*)nullptr, 0, longList, small + S_UB_LONG);     \
+                               (const int2*)nullptr, (int*)nullptr, 0, longList, small + S_UB_LONG, h->ubLong); \
         break;
     switch (G) {
         BHS_UB(1) BHS_UB(2) BHS_UB(4) BHS_UB(8) BHS_UB(16) BHS_UB(32) BHS_UB(64)
@@ -860,7 +861,7 @@ int launch_upper_bound(bhs_handle* h, const BinSpec& spec, bool cmp, int keyMax)
 #undef BHS_UB
     BHS_HIP(hipGetLastError());
     if (useLong) {
-        const unsigned g1 = (unsigned)(h->numCU * 4), g2 = (unsigned)std::min<size_t>(((size_t)h->nnzA / kUbLongA + 257) / 256, 1024);
+        const unsigned g1 = (unsigned)(h->numCU * 4), g2 = (unsigned)std::min<size_t>(((size_t)h->nnzA / h->ubLong + 257) / 256, 1024);
         if (cmp) {
             hipLaunchKernelGGL(k_upper_bound_long<true>, dim3(g1), dim3(256), 0, h->stream, (const int2*)longList,
                                (const int*)(small + S_UB_LONG), h->dAp, h->dAj, h->dBp, (const int2*)h->cLen.p,
@@ -941,7 +942,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     // ------------------------------------------------------------ stage 1
     // lane bin (k_row_lane): matrices whose A rows are all tiny, B rows strictly ascending
     int laneK = 0;
-    if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || h->maxRowA <= kLaneMaxK))
+    if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || (h->maxRowA <= kLaneMaxK && h->localA)))
         laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
     // hub bin: rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
     const int hubMin = (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25))
@@ -1320,6 +1321,16 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
             if (h->verbose > 1) printf("  [row classes: flags %d, %d classes: general pipeline]\n", cs[CS_FLAGS], cs[CS_CLASSES]);
             return pipeline_symbolic(h, true);
         }
+        // The class kernels take rows in stretches -- consecutive rows of one class; a matrix whose rows classify but
+        // each for itself (block-diagonal with dense blocks: every row of a block has its own relative pattern) makes
+        // them change class every row: 3.4 ms against 1.9 ms on the general pipeline for 2^20 rows in blocks of 4..32.
+        // More than a quarter of the rows through the table: this data set goes to the general pipeline (class_path = 2
+        // insists on the classes).
+        if (h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && (long long)cs[CS_HEADS] * 4 > (long long)m) {
+            h->classState = -1;
+            if (h->verbose > 1) printf("  [row classes: %d of %d rows start a stretch: general pipeline]\n", cs[CS_HEADS], m);
+            return pipeline_symbolic(h, true);
+        }
         unsigned long long t = 0, v;
         for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, cs + CS_SUMS + 2 * i, 8); t += v; }
         h->nnzCt = (long long)t;
@@ -1632,18 +1643,18 @@ int finish_set_data(bhs_handle* h)
     // the scans of the data set (longest rows, the period hint, sortedness of B's rows) are queued together and read
     // back with ONE synchronisation
     int* small0 = (int*)h->small.p;
-    BHS_HIP(hipMemsetAsync(small0 + S_SCAN, 0, sizeof(int) * 4, h->stream));
+    BHS_HIP(hipMemsetAsync(small0 + S_SCAN, 0, sizeof(int) * 5, h->stream));
     h->periodA = h->periodB = 1;
     if (h->m > 0) {
         const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 2);
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_SCAN);
-        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1);
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1, small0 + S_SCAN + 4, h->k);
         BHS_HIP(hipGetLastError());
     }
     if (h->k > 0) {
         const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 2);
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_SCAN + 2);
-        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_SCAN + 3);
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_SCAN + 3, (int*)nullptr, 0);
         BHS_HIP(hipGetLastError());
     }
     h->avgRowA = avgA;
@@ -1677,20 +1688,30 @@ int finish_set_data(bhs_handle* h)
         BHS_TRY(check_sorted());
     }
     int* hscan = (int*)h->hostSmall;                                // (pinned)
-    BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
-    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 4, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 5, hipMemcpyDeviceToHost, h->stream));
+    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 5, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     const int maxRowA = hscan[0];
     h->maxRowA = maxRowA;
     h->maxRowB = hscan[2];
     if (h->m > 0) h->periodA = hscan[1];
+    h->localA = h->m > 0 ? hscan[4] : 1;
     if (h->k > 0) h->periodB = hscan[3];
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
-    h->ubG = pow2_at_least(std::max(avgA, std::min(maxRowA, kUbLongA) / 32.0), 1, 64);   // (longer rows: k_upper_bound_long)
+    // (round 4: the lanes follow the AVERAGE row and rows of more than 32 passes go to k_upper_bound_long -- a web graph's
+    // rows of 3 entries were walked by 16 lanes each because a few rows have hundreds: 0.12 ms for 3 M entries)
+    // Measured on the two web-graph stand-ins (weblike / power-law, avg 3 entries, longest row 4.7 k): 16 lanes 0.138 / 0.187 ms,
+    // 8 lanes and rows beyond 128 entries listed 0.078 / 0.179, 4 lanes 0.066 / 0.223.
+    h->ubG = pow2_at_least(avgA, 1, 64);
+    h->ubLong = kUbLongA;
+    if (maxRowA > 32 * h->ubG) {                                // skewed: twice the lanes, rows beyond 16 passes listed
+        h->ubG = std::min(64, 2 * h->ubG);
+        h->ubLong = std::max(64, std::min(kUbLongA, 16 * h->ubG));
+    }
     if (checkB) {
         int* small = small0;
-        int flag = hscan[4];
+        int flag = hscan[5];
         h->bSorted = flag ? 0 : 1;
         if (!h->bSorted && h->sortB) {
             // Unsorted rows of B: sort them once here (the reference's driver does this on the host before
@@ -1713,7 +1734,9 @@ int finish_set_data(bhs_handle* h)
     }
     // compressed pattern of B: decide now whether it pays (the multiply itself re-runs the compression inside its
     // timed region; this pass only yields the pair count)
-    if (h->compressB == 1 && (avgA * avgB <= 1536.0 || !h->bSorted)) h->cmpState = -1;
+    // (round 4: the pair count is also taken for rows of 256 to 1536 products: where B's entries come in long runs -- banded
+    // matrices, dense diagonal blocks: a tenth as many pairs as entries -- the compressed pass pays from there on)
+    if (h->compressB == 1 && (avgA * avgB < 256.0 || !h->bSorted)) h->cmpState = -1;
     else if (h->compressB == 1 && h->nnzB > 0 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)h->k));
@@ -1724,7 +1747,7 @@ int finish_set_data(bhs_handle* h)
         unsigned long long pairs = 0;
         BHS_HIP(hipMemcpyAsync(&pairs, small + S_PAIRS, 8, hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipStreamSynchronize(h->stream));
-        h->cmpState = (double)pairs <= 0.6 * (double)h->nnzB ? 1 : -1;
+        h->cmpState = ((avgA * avgB > 1536.0 && (double)pairs <= 0.6 * (double)h->nnzB) || (double)pairs <= 0.25 * (double)h->nnzB) ? 1 : -1;
         if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpState > 0 ? "used" : "not used");
     }
     if (h->useSpa) BHS_TRY(ensure_spa(h));
@@ -1794,14 +1817,20 @@ int bhs_set_verbose(bhs_handle* h, int level)
     return BHS_SUCCESS;
 }
 
-int bhs_free_data(bhs_handle* h)
+// (keepOutput: bhs_set_data[_device] replaces the data set but keeps the output arrays of the grow-only pool -- a hipFree
+// and hipMalloc of 3 GB cost 0.5 ms per hand-over on poisson27pt 128^3, and where the new arrays land moves the numeric
+// kernel's time by several per cent; the caller's bhs_free_data releases them as the reference's
+// free_mem does, bhsparse_cuda.h:3006-3020)
+static int free_data(bhs_handle* h, bool keepOutput)
 {
     if (!h) return BHS_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 3; ++i) { release(h->ownA[i]); release(h->ownB[i]); }
-    release(h->Cj);
-    release(h->Cx);
+    if (!keepOutput) {
+        release(h->Cj);
+        release(h->Cx);
+    }
     h->dAp = h->dAj = h->dBp = h->dBj = nullptr;
     h->dAx = h->dBx = nullptr;
     h->hasData = h->hasC = h->ownAB = false;
@@ -1809,6 +1838,8 @@ int bhs_free_data(bhs_handle* h)
     h->ps.open = false;
     return BHS_SUCCESS;
 }
+
+int bhs_free_data(bhs_handle* h) { return free_data(h, false); }
 
 int bhs_destroy(bhs_handle* h)
 {
@@ -1864,7 +1895,7 @@ int bhs_set_data(bhs_handle* h, int m, int k, int n, int nnzA, const bhs_value_t
     if (!csrRowPtrA || !csrRowPtrB || (nnzA && (!csrValA || !csrColIndA)) || (nnzB && (!csrValB || !csrColIndB)))
         return BHS_ERR_INVALID_ARG;
     BHS_HIP(hipSetDevice(h->device));
-    bhs_free_data(h);
+    free_data(h, true);
     h->m = m; h->k = k; h->n = n; h->nnzA = nnzA; h->nnzB = nnzB;
     BHS_TRY(ensure(h, h->ownA[0], sizeof(int) * ((size_t)m + 1)));
     BHS_TRY(ensure(h, h->ownA[1], sizeof(int) * (size_t)std::max(nnzA, 1)));
@@ -1898,7 +1929,7 @@ int bhs_set_data_device(bhs_handle* h, int m, int k, int n, int nnzA, const bhs_
     if (!d_rowPtrA || !d_rowPtrB || (nnzA && (!d_valA || !d_colIndA)) || (nnzB && (!d_valB || !d_colIndB)))
         return BHS_ERR_INVALID_ARG;
     BHS_HIP(hipSetDevice(h->device));
-    bhs_free_data(h);
+    free_data(h, true);
     h->m = m; h->k = k; h->n = n; h->nnzA = nnzA; h->nnzB = nnzB;
     h->dAp = d_rowPtrA; h->dAj = d_colIndA; h->dAx = d_valA;
     h->dBp = d_rowPtrB; h->dBj = d_colIndB; h->dBx = d_valB;
@@ -2112,6 +2143,14 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "ub_lanes")) {      // (tuning hook) lanes per row of A in k_upper_bound, a power of two; rows beyond 32 passes go to its long list
+        int g = 1;
+        while (g < value && g < 64) g <<= 1;
+        h->ubG = g;
+        h->ubLong = std::max(64, std::min(kUbLongA, 16 * g));
+        return BHS_SUCCESS;
+    }
+    if (!strcmp(key, "ub_long")) { h->ubLong = (int)std::max<int64_t>(16, std::min<int64_t>(value, kUbLongA)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
@@ -2138,7 +2177,38 @@ int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
     if (!strcmp(key, "b_sorted")) { *value_out = h->bSorted; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
+    if (!strcmp(key, "local_a")) { *value_out = h->localA; return BHS_SUCCESS; }
+    if (!strcmp(key, "compress_b_used")) { *value_out = h->cmpState > 0 ? 1 : 0; return BHS_SUCCESS; }
     return BHS_ERR_INVALID_ARG;
+}
+
+int bhs_get_class_tables_device(bhs_handle* h, const int** d_classC, const void** d_classInfo, const int** d_classRel,
+                                int* slots_out, int* rel_stride_out, int* usable_out)
+{
+    if (!h || !usable_out) return BHS_ERR_INVALID_ARG;
+    *usable_out = 0;
+    if (slots_out) *slots_out = kClassSlots;                       // (the table geometry is a property of the build)
+    if (rel_stride_out) *rel_stride_out = kClassMaxNnz;
+    if (!h->hasC && !h->ps.open) return BHS_ERR_NOT_READY;
+    const bool usable = h->ps.useClass && !h->ps.classBig && !h->ps.empty;
+    *usable_out = usable ? 1 : 0;
+    if (d_classC) *d_classC = usable ? (const int*)h->classC.p : nullptr;
+    if (d_classInfo) *d_classInfo = usable ? (const void*)h->classInfo.p : nullptr;
+    if (d_classRel) *d_classRel = usable ? (const int*)h->classRel.p : nullptr;
+    if (slots_out) *slots_out = kClassSlots;
+    if (rel_stride_out) *rel_stride_out = kClassMaxNnz;
+    return BHS_SUCCESS;
+}
+
+int bhs_expand_class_columns_device(void* stream, int n, int row0, const int* d_classC, const void* d_classInfo,
+                                    const int* d_classRel, int rel_stride, const int* d_rowPtrC, int* d_colIndC)
+{
+    if (n < 0 || rel_stride <= 0 || (n > 0 && (!d_classC || !d_classInfo || !d_classRel || !d_rowPtrC || !d_colIndC))) return BHS_ERR_INVALID_ARG;
+    if (n == 0) return BHS_SUCCESS;
+    const unsigned grid = (unsigned)std::min<long long>(((long long)n + 3) / 4, 1 << 16);
+    hipLaunchKernelGGL(k_class_expand_columns, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, row0, d_classC,
+                       (const int4*)d_classInfo, d_classRel, rel_stride, d_rowPtrC, d_colIndC);
+    return hipGetLastError() == hipSuccess ? (int)BHS_SUCCESS : (int)BHS_ERR_LAUNCH;
 }
 
 const char* bhs_strerror(int status)

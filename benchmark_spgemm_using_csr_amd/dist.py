@@ -82,6 +82,8 @@ class NativeDist(object):
         L.bhs_dist_nranks.restype = C.c_int
         L.bhs_dist_last_link_floor_ms.argtypes = [vp]
         L.bhs_dist_last_link_floor_ms.restype = C.c_double
+        L.bhs_dist_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.bhs_dist_last_values_only.argtypes = [vp]
         idbuf = C.create_string_buffer(128)
         if rank == 0:
             err = L.bhs_dist_unique_id(idbuf)
@@ -116,6 +118,14 @@ class NativeDist(object):
             raise (RuntimeError if err == _lib.BHS_ERR_INVALID_ARG else CollectiveError)(msg)
         self.ms = tuple(ms)
         return int(ct.value), int(cc.value)
+
+    def set_option(self, key, value):
+        """bhs_dist_set_option: "values_only" 1 -- where every rank's multiply went by row classes, the other ranks'
+        column indices are rebuilt from their classes instead of received (8 instead of 12 bytes per entry and link)."""
+        return self._L.bhs_dist_set_option(self._d, key.encode(), int(value))
+
+    def values_only_used(self):
+        return bool(self._L.bhs_dist_last_values_only(self._d))
 
     def nranks(self):
         """Ranks RCCL counts in the communicator (ncclCommCount)."""

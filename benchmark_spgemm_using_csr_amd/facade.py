@@ -195,6 +195,21 @@ class bhsparse(object):
             raise BhsparseError("bhs_get_C_device", err)
         return tuple(int(x.value or 0) for x in p)
 
+    def class_tables_device(self):
+        """bhs_get_class_tables_device: (classC, classInfo, classRel) device addresses, slots, rel stride, usable."""
+        p = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+        slots, stride, usable = C.c_int(0), C.c_int(0), C.c_int(0)
+        err = self._lib.bhs_get_class_tables_device(self._h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(slots),
+                                                    C.byref(stride), C.byref(usable))
+        if err != BHSPARSE_SUCCESS:
+            raise BhsparseError("bhs_get_class_tables_device", err)
+        return tuple(int(x.value or 0) for x in p) + (slots.value, stride.value, bool(usable.value))
+
+    def expand_class_columns_device(self, n, row0, d_classC, d_classInfo, d_classRel, rel_stride, d_rowPtrC, d_colIndC, stream=0):
+        """bhs_expand_class_columns_device: colIndC of n rows from their classes (asynchronous on `stream`)."""
+        return self._lib.bhs_expand_class_columns_device(C.c_void_p(stream), n, row0, C.c_void_p(d_classC), C.c_void_p(d_classInfo),
+                                                         C.c_void_p(d_classRel), rel_stride, C.c_void_p(d_rowPtrC), C.c_void_p(d_colIndC))
+
     def csr_sort_indices_device(self, n_row, d_rowPtr, d_colInd, d_val):
         """In-place, stable per-row sort by column of a device-resident CSR matrix
         (ref_spgemm::csr_sort_indices, SpGEMM_cuda/ref_spgemm.h:37-62, on the GPU)."""

@@ -246,3 +246,96 @@ def weblike_csr(m=1000005, max_row=4700, seed=SEED, host_alpha=1.5, max_host=300
     rowptr = np.zeros(m + 1, np.int64)
     np.cumsum(np.bincount(r, minlength=m), out=rowptr[1:])
     return rowptr.astype(np.int32), (key - r * m).astype(np.int32)
+
+
+# ---------------------------------------------------------------- the results table's inputs (tools/suite_table.py)
+# No SuiteSparse file is in the image (no network): structurally distinct seeded stand-ins of about a million rows.
+def _csr_from_pairs(m, n, rows, cols):
+    key = np.unique(rows.astype(np.int64) * n + cols.astype(np.int64))
+    r = key // n
+    rowptr = np.zeros(m + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=m), out=rowptr[1:])
+    return rowptr.astype(np.int32), (key - r * n).astype(np.int32)
+
+
+def rmat_csr(scale=20, edge_factor=2, a=0.57, b=0.19, c=0.19, seed=SEED):
+    """R-MAT / Kronecker graph (Graph500 parameters), 2^scale rows, ~edge_factor entries per row before duplicates
+    collapse; vertices are not permuted: the hubs sit at the low indices."""
+    rng = np.random.default_rng(seed)
+    ne = edge_factor << scale
+    rows = np.zeros(ne, np.int64)
+    cols = np.zeros(ne, np.int64)
+    for _ in range(scale):
+        u = rng.random(ne)
+        rbit = u >= a + b
+        cbit = ((u >= a) & (u < a + b)) | (u >= a + b + c)
+        rows = (rows << 1) | rbit
+        cols = (cols << 1) | cbit
+    n = 1 << scale
+    return _csr_from_pairs(n, n, rows, cols)
+
+
+def banded_csr(n=1 << 20, lo=3, hi=24, seed=SEED):
+    """Banded matrix with an irregular bandwidth: row i holds every column within h(i) of the diagonal, h a random
+    walk between lo and hi (1-D finite elements of varying order / a reordered FEM band)."""
+    rng = np.random.default_rng(seed)
+    h = np.clip(np.cumsum(rng.integers(-1, 2, n)) % (2 * (hi - lo)), 0, None)
+    h = lo + np.where(h > hi - lo, 2 * (hi - lo) - h, h)
+    left = np.maximum(0, np.arange(n) - h)
+    right = np.minimum(n - 1, np.arange(n) + h)
+    lens = right - left + 1
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    cols = np.arange(rowptr[-1], dtype=np.int64) - np.repeat(rowptr[:-1], lens) + np.repeat(left, lens)
+    return rowptr.astype(np.int32), cols.astype(np.int32)
+
+
+def mesh2d_csr(npoints=1 << 20, seed=SEED):
+    """Adjacency (plus diagonal) of the Delaunay triangulation of random points in the unit square, points numbered
+    along a 1024 x 1024 grid of cells: an unstructured 2-D mesh with a locality-preserving numbering (~7 per row)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    pts = rng.random((npoints, 2))
+    cell = (np.minimum(1023, (pts[:, 1] * 1024).astype(np.int64)) << 10) | np.minimum(1023, (pts[:, 0] * 1024).astype(np.int64))
+    pts = pts[np.argsort(cell, kind="stable")]
+    tri = Delaunay(pts).simplices.astype(np.int64)
+    e = np.concatenate((tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]))
+    d = np.arange(npoints, dtype=np.int64)
+    rows = np.concatenate((e[:, 0], e[:, 1], d))
+    cols = np.concatenate((e[:, 1], e[:, 0], d))
+    return _csr_from_pairs(npoints, npoints, rows, cols)
+
+
+def blockdiag_csr(n=1 << 20, bmin=4, bmax=32, seed=SEED):
+    """Block-diagonal with dense blocks of bmin..bmax rows (independent subsystems / supernodes)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(bmin, bmax + 1, 3 * n // (bmin + bmax) + 16)
+    cs = np.cumsum(sizes)
+    nb = int(np.searchsorted(cs, n)) + 1
+    sizes = sizes[:nb].astype(np.int64)
+    sizes[-1] -= cs[nb - 1] - n
+    start = np.concatenate(([0], np.cumsum(sizes)[:-1]))
+    blk = np.repeat(np.arange(nb), sizes)
+    lens = sizes[blk]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    cols = np.arange(rowptr[-1], dtype=np.int64) - np.repeat(rowptr[:-1], lens) + np.repeat(start[blk], lens)
+    return rowptr.astype(np.int32), cols.astype(np.int32)
+
+
+def uniform_csr(n=1 << 20, per_row=8, seed=SEED):
+    """Uniformly random columns, per_row draws per row (Erdos-Renyi: no structure at all)."""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    return _csr_from_pairs(n, n, rows, rng.integers(0, n, rows.size))
+
+
+def roadlike_csr(nx=1024, ny=1024, keep=0.62, seed=SEED):
+    """Road-network-like: the 4-neighbour grid graph with 38 % of its edges removed, symmetric, plus the diagonal
+    (average 3.5 entries per row, long paths, no hubs)."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(nx * ny, dtype=np.int64).reshape(ny, nx)
+    e = np.concatenate((np.stack((idx[:, :-1].ravel(), idx[:, 1:].ravel()), 1), np.stack((idx[:-1, :].ravel(), idx[1:, :].ravel()), 1)))
+    e = e[rng.random(len(e)) < keep]
+    d = np.arange(nx * ny, dtype=np.int64)
+    return _csr_from_pairs(nx * ny, nx * ny, np.concatenate((e[:, 0], e[:, 1], d)), np.concatenate((e[:, 1], e[:, 0], d)))

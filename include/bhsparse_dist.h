@@ -81,6 +81,23 @@ BHS_API int bhs_dist_get_C_host(bhs_dist *d, int *csrColIndC, bhs_value_t *csrVa
 BHS_API int bhs_dist_plan(int world, int rank, int sub_blocks, const int64_t *rows, const int64_t *cuts,
                           int64_t *ops_out, int cap_ops);
 
+/* The same plan in the values-only mode (option "values_only"): no colInd operations; with the first group the classes
+ * of a block's rows (array 3, offsets in rows) and its rank's class tables (array 4: table_ints int32 per rank, rank
+ * r's at r * table_ints) travel instead.                                                                            */
+BHS_API int bhs_dist_plan_values_only(int world, int rank, int sub_blocks, const int64_t *rows, const int64_t *cuts,
+                                      int64_t table_ints, int64_t *ops_out, int cap_ops);
+
+/* Options of the multi-GPU layer:
+ *   "values_only"  1: when EVERY rank's multiply went by row classes (grid matrices; bhs_get_class_tables_device), the
+ *                  column indices of the other ranks' blocks are not transferred but rebuilt on this GPU from their
+ *                  classes -- 4 bytes per row and 8.4 MB of tables per rank cross xGMI instead of 4 bytes per entry:
+ *                  8 instead of 12 bytes per entry of C on every link (poisson27pt 256^3 at 8 GPUs: 13.6 instead of
+ *                  20.3 ms per link).  Decided collectively per call from the sizes exchange; any rank that cannot
+ *                  serve it sends everyone to the ordinary all-gatherv.  Default 0.
+ * bhs_dist_last_values_only: 1 when the last call ran that way.                                                   */
+BHS_API int bhs_dist_set_option(bhs_dist *d, const char *key, int64_t value);
+BHS_API int bhs_dist_last_values_only(bhs_dist *d);
+
 /* per-link lower bound of the all-gatherv in ms: bytes this rank receives from its largest peer / 153 GB/s (one xGMI
  * link; /opt/skills/guides/MI355X_MICROARCH.md), for the sizes of the last bhs_dist_spgemm_allgatherv               */
 BHS_API double bhs_dist_last_link_floor_ms(bhs_dist *d);

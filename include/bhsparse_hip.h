@@ -246,8 +246,30 @@ BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
 /* What the library found out about the bound data set (after bhs_set_data[_device]):
  *   "b_sorted"   1 when every row of B (as multiplied: after the optional sort) is strictly ascending
  *   "max_row_a", "max_row_b"   longest row of A / B
+ *   "local_a"    1 when sampled rows of A keep their entries near the diagonal (mean |column - row| < columns / 16): the
+ *                lane-per-row kernels are only chosen then
+ *   "compress_b_used"  1 when the symbolic pass of the general pipeline runs on B's pattern compressed to (column block,
+ *                mask) pairs for this data set
  * Returns BHS_ERR_INVALID_ARG for unknown keys, BHS_ERR_NOT_READY without data.  */
 BHS_API int bhs_get_info(bhs_handle *h, const char *key, int64_t *value_out);
+
+/* Row classes of the open / last multiply, for a caller that rebuilds column indices itself instead of moving them
+ * (bhs_dist's values-only all-gatherv: on a grid matrix colIndC of a row is its class's relative column list plus the
+ * row number, so only valC has to cross xGMI).  No reference counterpart (the reference has no classes, no second GPU).
+ *   d_classC      int32[m]: class of every row of A (= row of C); valid from bhs_spgemm_symbolic until the next multiply
+ *   d_classInfo   16 bytes per class slot: int32 {entries of the A row, products, entries of the C row, representative}
+ *   d_classRel    int32[slots * rel_stride]: the class's columns relative to the row, ascending
+ *   usable_out    0: that multiply did not go by row classes with register-sized tables -- nothing above is valid
+ * Device pointers into the handle's workspace.  BHS_ERR_NOT_READY without an open or finished multiply.            */
+BHS_API int bhs_get_class_tables_device(bhs_handle *h, const int **d_classC, const void **d_classInfo,
+                                        const int **d_classRel, int *slots_out, int *rel_stride_out, int *usable_out);
+
+/* colIndC of n consecutive rows from their classes, on `stream` (a hipStream_t; NULL: the device's null stream) of the
+ * CURRENT device: row i of the n rows has class d_classC[i], classInfo[class].z entries, and its entry s is column
+ * d_classRel[class * rel_stride + s] + row0 + i, written at d_colIndC[d_rowPtrC[i] + s].  The tables may be another
+ * handle's or another GPU's, copied over (bhs_dist).  Asynchronous.                                                  */
+BHS_API int bhs_expand_class_columns_device(void *stream, int n, int row0, const int *d_classC, const void *d_classInfo,
+                                            const int *d_classRel, int rel_stride, const int *d_rowPtrC, int *d_colIndC);
 
 BHS_API const char *bhs_strerror(int status);
 BHS_API const char *bhs_version(void);

@@ -51,3 +51,19 @@ def test_rccl_allgatherv_world_size_1(workload, gather):
     assert out["gather_ms_per_step"] > 0.0
     if workload == "p27_51":
         assert out["config"]["nnzCt"] == (9 * 51 - 10) ** 3 and out["config"]["nnzC"] == (5 * 51 - 6) ** 3
+    if gather == "native":
+        # the values-only mode (bench.py asks for it): taken where the multiply went by row classes (poisson27pt 51^3 is
+        # below the class path's work threshold: ordinary mode), and the gathered copy equals the local result either way
+        assert out["gather_values_only"] in (True, False)
+
+
+def test_rccl_allgatherv_values_only_world_size_1():
+    """The same through the values-only mode on an input that takes the row classes (poisson27pt 72^3): the library
+    decides for it from the sizes exchange, copies its classes and tables into place, and the assembled C still equals
+    the local result (world 1: no peers whose columns would be rebuilt -- that kernel is covered by
+    test_columns_rebuilt_from_row_classes, the plan by tests/test_dist_cpu.py)."""
+    out = _bench_rank("p27_72", {"BENCH_GATHER": "native", "BENCH_VALUES_ONLY": "1"})
+    assert out["config"]["gather"].startswith("native") and out["gather_values_only"] is True
+    assert out["config"]["nnzC"] == (5 * 72 - 6) ** 3
+    out = _bench_rank("p27_72", {"BENCH_GATHER": "native", "BENCH_VALUES_ONLY": "0"})
+    assert out["gather_values_only"] is False and out["config"]["nnzC"] == (5 * 72 - 6) ** 3

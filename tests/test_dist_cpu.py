@@ -201,3 +201,55 @@ def test_native_allgatherv_plans_match_across_ranks(world, S):
                 assert (cover == 1).all(), (r, array)
             groups = plans[r][:, 5]
             assert (np.diff(groups) >= 0).all()                    # issued group by group
+
+
+@pytest.mark.parametrize("world,S", [(2, 1), (3, 3), (8, 4)])
+def test_native_allgatherv_values_only_plans(world, S):
+    """The plan of the values-only mode (include/bhsparse_dist.h, option "values_only"), replayed for all ranks: no
+    column-index operation at all; values, row pointers and row classes tile their arrays exactly once per rank; every
+    rank receives the class tables of every other rank that has rows, once, at that rank's place; sends meet receives
+    in order.  (The columns themselves are rebuilt by bhs_expand_class_columns_device: tests/test_parity_gpu.py.)"""
+    import ctypes as C
+    from benchmark_spgemm_using_csr_amd import _lib
+    so = os.path.join(_lib.CSRC, "libbhsparse_dist.so")
+    if not os.path.exists(so):
+        pytest.skip("libbhsparse_dist.so not built")
+    L = C.CDLL(so)
+    L.bhs_dist_plan_values_only.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    T = 4096 * 4 + 4096 * 512
+    rng = np.random.default_rng(7 * world + S)
+    for trial in range(4):
+        rows = rng.integers(1, 50, world).astype(np.int64)
+        if trial == 0:
+            rows[rng.integers(0, world)] = 0
+        cuts = np.zeros((world, S + 1), np.int64)
+        for r in range(world):
+            cuts[r, 1:] = np.cumsum(rng.integers(0, 40, S) * (rows[r] > 0))
+        row_off = np.concatenate([[0], np.cumsum(rows)])
+        nnz_off = np.concatenate([[0], np.cumsum(cuts[:, -1])])
+        plans = []
+        for r in range(world):
+            cap = 10 * S * world
+            buf = (C.c_int64 * (6 * cap))()
+            n = L.bhs_dist_plan_values_only(world, r, S, rows.ctypes.data_as(C.c_void_p), cuts.ctypes.data_as(C.c_void_p), T, buf, cap)
+            assert 0 <= n <= cap
+            plans.append(np.array(buf[:6 * n], np.int64).reshape(n, 6))
+            assert not (plans[-1][:, 2] == 0).any()                  # no column indices on the wire
+        for x in range(world):
+            for y in range(world):
+                if x != y:
+                    sends = [tuple(op[2:]) for op in plans[x] if op[0] == 0 and op[1] == y]
+                    recvs = [tuple(op[2:]) for op in plans[y] if op[0] == 1 and op[1] == x]
+                    assert sends == recvs, (x, y)
+        for r in range(world):
+            for array, total, own in ((1, nnz_off[-1], (nnz_off[r], nnz_off[r + 1])), (2, row_off[-1], (row_off[r], row_off[r + 1])),
+                                      (3, row_off[-1], (row_off[r], row_off[r + 1]))):
+                cover = np.zeros(int(total), np.int32)
+                cover[own[0]:own[1]] += 1
+                for op in plans[r]:
+                    if op[0] == 1 and op[2] == array:
+                        cover[op[3]:op[3] + op[4]] += 1
+                assert (cover == 1).all(), (r, array)
+            got = sorted(int(op[3]) // T for op in plans[r] if op[0] == 1 and op[2] == 4)
+            assert got == [q for q in range(world) if q != r and rows[q] > 0]
+            assert all(op[4] == T and op[3] % T == 0 for op in plans[r] if op[2] == 4)

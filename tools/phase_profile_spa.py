@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from benchmark_spgemm_using_csr_amd import gallery, facade, _lib
 dev = torch.device("cuda", 0)
-rp, col = gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
+rp, col = gallery.weblike_csr() if (len(sys.argv) > 1 and sys.argv[1] == "weblike") else gallery.powerlaw_csr(1000005, 1000005, 3105536, 4700)
 val = gallery.fill_values(len(col))
 Bp, Bj, Bx = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
 Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
