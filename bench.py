@@ -345,6 +345,22 @@ def main():
         rp, cc, vv = full
         assert int(rp[-1].item()) == nnzC_total and int(rp[0].item()) == 0
         assert bool((rp[1:] >= rp[:-1]).all())
+        if stencil == "poisson27pt":                     # closed form of the 27-point stencil's square
+            assert nnzC_total == (5 * dims[0] - 6) * (5 * dims[1] - 6) * (5 * dims[2] - 6), (nnzC_total, dims)
+        if world > 1:
+            # the assembled columns (in the values-only mode the other ranks' are REBUILT here from their row classes):
+            # inside the matrix and strictly ascending in every row, checked in chunks of 2^26 entries
+            n_all = int(cc.numel())
+            starts = rp[1:-1].long()
+            for c0 in range(0, n_all, 1 << 26):
+                c1 = min(n_all, c0 + (1 << 26) + 1)
+                seg = cc[c0:c1]
+                assert int(seg.min()) >= 0 and int(seg.max()) < m
+                inc = seg[1:] > seg[:-1]
+                st = starts[(starts > c0) & (starts < c1)] - c0 - 1          # a row's first column may be anything
+                inc[st] = True
+                assert bool(inc.all()), "assembled colIndC: a row is not strictly ascending"
+                del seg, inc, st
         if world == 1:      # forced self-test: the gathered copy must equal the local result bit for bit
             if native is not None:                # ... of an ordinary multiply into the library's own arrays
                 rp, cc, vv = rp.clone(), cc.clone(), vv.clone()

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { dist += __shfl_xor(dist, o, 64); cnt += __shfl_xor(cnt, o, 64); }
-        if (lane == 0) *local = (cnt == 0 || dist * 16 < (long long)cnt * ncols) ? 1 : 0;
+        if (lane == 0) *local = (cnt == 0 || ncols <= 4096 || dist * 16 < (long long)cnt * ncols) ? 1 : 0;   // (a small B sits in the caches anyway)
     }
 }
 

@@ -256,7 +256,7 @@ def test_compressed_symbolic_pass(oracle, case):
         assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
 
 
-@pytest.mark.parametrize("case", ["p5", "p7", "p9", "tiny_random", "cancel", "unsorted_b"])
+@pytest.mark.parametrize("case", ["p5", "p7", "p9", "tiny_random", "wide_random", "cancel", "unsorted_b"])
 def test_lane_per_row_kernel(oracle, case):
     """k_row_lane (one row per lane, K-way merge of sorted B rows in registers) against the oracle and against
     the table kernels; it must step aside for unsorted B."""
@@ -270,6 +270,10 @@ def test_lane_per_row_kernel(oracle, case):
         m, k, n = 777, 300, 2000
         A = random_csr(m, k, 0.02, rng, empty_rows=(0, 5, 776), max_row=12)
         B = random_csr(k, n, 0.008, rng, empty_rows=(1, 2), max_row=30)
+    elif case == "wide_random":                  # the same with 20 000 columns: 64 lanes would read 64 far-apart B rows
+        m, k, n = 3000, 20000, 20000
+        A = random_csr(m, k, 0.0003, rng, empty_rows=(0, 5), max_row=12)
+        B = random_csr(k, n, 0.0002, rng, empty_rows=(1, 2), max_row=30)
     elif case == "cancel":                       # exact cancellation keeps the structural zero
         m = k = n = 3
         A = (np.array([0, 2, 2, 3], np.int32), np.array([0, 1, 2], np.int32), np.array([1.0, -1.0, 2.0]))
@@ -289,9 +293,10 @@ def test_lane_per_row_kernel(oracle, case):
         got = _check(oracle, m, k, n, A, B, options={"lane_rows": mode, "lane_numeric": num, "sort_b": sb})
         assert all(np.array_equal(x, y) for x, y in zip(ref[:3], got[:3]))
         names = {s["name"] for s in got[3]["kernels"] if s["launches"]}
-        # (round 4: lane_rows = 1 leaves the lane kernels to inputs whose rows of A stay near the diagonal -- the hint
-        # "local_a" of bhs_set_data; the random columns of `tiny_random` take them only when lane_rows = 2 insists)
-        wanted = kernels_wanted and (mode == 2 or case != "tiny_random")
+        # (round 4: lane_rows = 1 leaves the lane kernels to inputs whose rows of A stay near the diagonal, or whose B is
+        # small -- the hint "local_a" of bhs_set_data; the random columns of `wide_random` take them only when
+        # lane_rows = 2 insists)
+        wanted = kernels_wanted and (mode == 2 or case != "wide_random")
         assert ("symbolic_lane" in names) == wanted, names
         assert ("numeric_lane" in names) == (wanted and num == 1), names
     if case == "cancel":
