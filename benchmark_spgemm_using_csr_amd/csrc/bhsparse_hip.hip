@@ -1014,7 +1014,10 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     if (cmpRun) {
         unsigned long long pairs;
         memcpy(&pairs, hs + S_PAIRS, 8);
-        if (h->cmpState == 0) h->cmpState = (double)pairs <= 0.6 * (double)h->nnzB ? 1 : -1;
+        if (h->cmpState == 0) {
+            const double avgP = h->avgRowA * h->avgRowB;          // (the rule of bhs_set_data's count)
+            h->cmpState = ((avgP > 1536.0 && (double)pairs <= 0.6 * (double)h->nnzB) || (double)pairs <= 0.25 * (double)h->nnzB) ? 1 : -1;
+        }
         h->cmpActive = cmpBins;
         if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpActive ? "used" : "not used");
     }
@@ -1736,7 +1739,14 @@ int finish_set_data(bhs_handle* h)
     // timed region; this pass only yields the pair count)
     // (round 4: the pair count is also taken for rows of 256 to 1536 products: where B's entries come in long runs -- banded
     // matrices, dense diagonal blocks: a tenth as many pairs as entries -- the compressed pass pays from there on)
+    // A data set that will try the row classes first (pipeline_symbolic's test) and has rows below the old gate leaves the
+    // count to its first multiply on the general pipeline, if it ever gets there (cmpState 0: that multiply measures the
+    // ratio, the ones after it use the verdict) -- poisson27pt's hand-over does not pay a pass over B for nothing.
+    const bool classFirst = h->classPath && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->maxRowA <= kClassMaxRowBig &&
+                            h->maxRowB <= kClassMaxRowBig &&
+                            (h->classPath == 2 || (avgA * avgB >= (double)h->classMinProducts && (double)h->m * avgA * avgB >= 6e7));
     if (h->compressB == 1 && (avgA * avgB < 256.0 || !h->bSorted)) h->cmpState = -1;
+    else if (h->compressB == 1 && classFirst && avgA * avgB <= 1536.0) h->cmpState = 0;
     else if (h->compressB == 1 && h->nnzB > 0 && h->k > 0) {
         int* small = (int*)h->small.p;
         BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)h->k));

@@ -379,19 +379,24 @@ def test_wave_first_symbolic_pass(oracle):
     rng = np.random.default_rng(3)
     m, rp, col, val = poisson_case("poisson27pt", 9, 8, 10)
     A = (rp, col, val)
-    r1 = _check(oracle, m, m, m, A, A)
+    # (compress_b = 0: on a 9 x 8 x 10 grid a row's 27 columns fall into 3 blocks of 32 -- the compressed symbolic pass, chosen
+    # since round 4 where B has <= 25 % as many (block, mask) pairs as entries, would take this input with its upper-bound pass)
+    r1 = _check(oracle, m, m, m, A, A, options={"compress_b": 0})
+    rc = _check(oracle, m, m, m, A, A)
+    assert "compress_b" in {s["name"] for s in rc[3]["kernels"] if s["launches"]}
+    assert all(np.array_equal(x, y) for x, y in zip(rc[:3], r1[:3]))
     n1 = {s["name"]: s for s in r1[3]["kernels"] if s["launches"]}
     assert "upper_bound" not in n1 and "symbolic_wave<1024>" in n1, sorted(n1)
     assert n1["symbolic_wave<1024>"]["rows"] == m and n1["symbolic_wave<1024>"]["products"] == r1[3]["nnzCt"]
-    r0 = _check(oracle, m, m, m, A, A, options={"wave_first": 0})
+    r0 = _check(oracle, m, m, m, A, A, options={"wave_first": 0, "compress_b": 0})
     assert "upper_bound" in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
     assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
     # A rows of up to 100 entries (chunk loop), B rows of <= 20: bound 2000 -> the 4096-slot table
     mm, kk, nn = 300, 400, 3000
     A2 = random_csr(mm, kk, 0.2, rng, empty_rows=(0, 17, 299), max_row=100)
     B2 = random_csr(kk, nn, 0.005, rng, empty_rows=(3,), max_row=20)
-    a1 = _check(oracle, mm, kk, nn, A2, B2)
-    a0 = _check(oracle, mm, kk, nn, A2, B2, options={"wave_first": 0})
+    a1 = _check(oracle, mm, kk, nn, A2, B2, options={"compress_b": 0})
+    a0 = _check(oracle, mm, kk, nn, A2, B2, options={"wave_first": 0, "compress_b": 0})
     assert "upper_bound" not in {s["name"] for s in a1[3]["kernels"] if s["launches"]}
     assert all(np.array_equal(x, y) for x, y in zip(a0[:3], a1[:3]))
     # one long row of A breaks the bound: plain pipeline
@@ -423,9 +428,15 @@ def test_compression_is_automatic_for_heavy_clustered_rows(oracle):
     r0 = _check(oracle, m, m, m, A, A, options={"compress_b": 0})
     assert "compress_b" not in {s["name"] for s in r0[3]["kernels"] if s["launches"]}
     assert all(np.array_equal(x, y) for x, y in zip(r0[:3], r1[:3]))
-    mm, rp, col, val = poisson_case("poisson27pt", 7, 7, 7)
+    # (a grid line of 40 nodes: the nine runs of 3 columns of a row sit in nine different blocks of 32 -- a third as many
+    # pairs as entries, above the 25 % from which the pass is chosen for rows of fewer than 1536 products.  On a 7 x 7 x 7
+    # grid a whole plane's nine columns share a block, and the compressed pass does take it.)
+    mm, rp, col, val = poisson_case("poisson27pt", 40, 5, 5)
     r2 = _check(oracle, mm, mm, mm, (rp, col, val), (rp, col, val))
     assert "compress_b" not in {s["name"] for s in r2[3]["kernels"] if s["launches"]}
+    mm, rp, col, val = poisson_case("poisson27pt", 7, 7, 7)
+    r3 = _check(oracle, mm, mm, mm, (rp, col, val), (rp, col, val))
+    assert "compress_b" in {s["name"] for s in r3[3]["kernels"] if s["launches"]}
 
 
 def test_sort_key_width_paths(oracle):
