@@ -14,6 +14,12 @@
 // rowPtrC (bhsparse_cuda.h:280, 289, 2787-2808).
 #include "../../include/bhsparse_hip.h"
 #include "bhs_kernels.hip.h"
+#include "bhs_row_wg.hip.h"
+#include "bhs_row_wave.hip.h"
+#include "bhs_row_quad.hip.h"
+#include "bhs_compress.hip.h"
+#include "bhs_row_lane.hip.h"
+#include "bhs_sort.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
 #include "bhs_class_wg.hip.h"

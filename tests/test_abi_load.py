@@ -3,6 +3,7 @@ symbol include/bhsparse_hip.h declares.  No compute calls (no GPU here)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -86,3 +87,29 @@ def test_dist_library_exports_every_declared_symbol(hiplib):
     out = (C.c_int * 3)()
     assert raw.bhs_dist_partition_rows(-1, None, None, None, 2, out) == _lib.BHS_ERR_INVALID_ARG
     assert raw.bhs_dist_partition_rows(0, None, None, None, 2, out) == 0 and list(out) == [0, 0, 0]
+
+
+def test_measurement_tools_still_build(tmp_path):
+    """tools/ holds stand-alone probes (.hip) and measurement scripts (.py) that nothing else imports: every probe must
+    still cross-compile for gfx950 and every script must still parse, or they rot silently."""
+    import glob
+    import py_compile
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    probes = sorted(glob.glob(os.path.join(tools, "*.hip")))
+    assert probes
+
+    def build(src):
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        p = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-result", "-I", os.path.join(os.path.dirname(tools), "benchmark_spgemm_using_csr_amd", "csrc"), "-c", "-o", obj, src],
+                           capture_output=True, text=True, timeout=600)
+        return src, p.returncode, p.stderr[-800:]
+    with ThreadPoolExecutor(4) as ex:
+        for src, rc, err in ex.map(build, probes):
+            assert rc == 0, (src, err)
+    for f in sorted(glob.glob(os.path.join(tools, "*.py"))):
+        py_compile.compile(f, cfile=str(tmp_path / (os.path.basename(f) + "c")), doraise=True)
