@@ -325,6 +325,26 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     state_after = gpu_state() if rank == 0 else None
+    # ... and once UNDER LOAD (outside the timed region): rocm-smi is asked while this rank keeps multiplying for about a
+    # second -- boxes of the pool differ by up to 15 % on the same build, and the clocks an idle GPU reports say nothing
+    state_load = None
+    if rank == 0 and world == 1 and not args.no_general:
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(s=gpu_state()))
+        t_l = time.perf_counter()
+        n_l = 0
+        while time.perf_counter() - t_l < 0.4:            # (clocks ramp up first)
+            assert bh.spgemm() == 0
+            n_l += 1
+        th.start()
+        while th.is_alive() and time.perf_counter() - t_l < 20.0:
+            assert bh.spgemm() == 0
+            n_l += 1
+        th.join()
+        state_load = box.get("s")
+        if isinstance(state_load, dict):
+            state_load["multiplies_meanwhile"] = n_l
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -584,7 +604,7 @@ def main():
                    "library_options": lib_opts or None},
         "ms_min": round(float(np.min(step_ms)), 4), "ms_median": round(float(np.median(step_ms)), 4),
         "setup_ms": round(setup_ms, 4), "setup_ms_warm": round(setup_ms_warm, 4),
-        "ms_per_step_incl_setup": incl_setup, "fresh_handles": fresh, "gpu_state": {"before": state_before, "after": state_after},
+        "ms_per_step_incl_setup": incl_setup, "fresh_handles": fresh, "gpu_state": {"before": state_before, "after": state_after, "under_load": state_load},
         "general_path": general,
         "nnzC_per_s": round(nnzC_total / (ms_per_step * 1e-3), 1),
         "device_ms_per_step": round(float(np.sum(stage)) / args.steps, 4),
