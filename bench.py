@@ -65,6 +65,33 @@ def gpu_state():
         return {"error": str(e)[-120:]}
 
 
+def stream_copy_GBs(dev, gib=2, reps=8):
+    """Bytes read + written per second by a plain device-to-device copy of `gib` GiB (torch's copy kernel): what THIS box's
+    memory system streams.  The boxes of the pool run the memory-bound class kernels of one build in 1.45 to 1.69 ms while
+    the VALU-bound general pipeline takes the same time on all of them (profiles/r04_box_probe.txt); this figure goes
+    beside the headline so that a slow line can be told from a slow build."""
+    import torch
+    try:
+        n = gib << 27                                      # float64 elements
+        a = torch.empty(n, dtype=torch.float64, device=dev)
+        b = torch.empty_like(a)
+        a.fill_(1.0)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        torch.cuda.empty_cache()
+        return round(2.0 * n * 8 / (ms * 1e-3) / 1e9, 1)
+    except Exception as e:                                 # a diagnostic must not take the bench line down
+        return {"error": str(e)[-120:]}
+
+
 def device_digest(bh, m, dev):
     """The sums of oracle/make_ref_golden.digest_of over the library's C, evaluated on the device."""
     import torch
@@ -345,6 +372,7 @@ def main():
         state_load = box.get("s")
         if isinstance(state_load, dict):
             state_load["multiplies_meanwhile"] = n_l
+            state_load["stream_copy_GBs"] = stream_copy_GBs(dev)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -148,6 +148,8 @@ struct bhs_handle {
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
+    int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
+    unsigned scanEpoch = 0;              // tag of this multiply's tile words
     int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
     int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
@@ -250,7 +252,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_SYM_SUMS = 104 /* kMaxBins x 3 u64: products, nnz(C rows), nnz(A rows) */,
        S_NUM_SUMS = 104 + 96,
        S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
-       S_ZERO_END = 104 + 194,   /* everything below is zeroed at the start of every spgemm */
+       S_SCAN_TICKET = 104 + 194 /* tile numbers of k_scan_onepass */,
+       S_ZERO_END = 104 + 195,   /* everything below is zeroed at the start of every spgemm */
        S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* (free) */,
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
@@ -1310,6 +1313,21 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches += 1;
     } else {
+    if (h->scanOnePass) {
+        // one pass with look-back over the tiles before (k_scan_onepass); the tile words carry this multiply's epoch
+        const int nTiles = (m + kScan1Tile - 1) / kScan1Tile;
+        h->scanEpoch = (h->scanEpoch + 1) & 0x3FFFFu;
+        if (h->scanEpoch == 0) {                                    // (every 2^18 multiplies the words of 2^18 multiplies ago could match)
+            BHS_HIP(hipMemsetAsync(h->blockSum.p, 0, sizeof(unsigned long long) * (size_t)std::max(nTiles, 1), h->stream));
+            h->scanEpoch = 1;
+        }
+        hipLaunchKernelGGL(k_scan_onepass, dim3((unsigned)nTiles), dim3(kScan1Block), 0, h->stream, m, (int*)h->Cp.p, h->dAp,
+                           (unsigned long long*)h->blockSum.p, h->scanEpoch, small + S_SCAN_TICKET, (long long*)(small + S_TOTAL_C),
+                           small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches += 1;
+    } else {
     hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
                        (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
@@ -1319,6 +1337,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches += 3;
+    }
     }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
@@ -2159,6 +2178,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "scan_one_pass")) { h->scanOnePass = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "ub_lanes")) {      // (tuning hook) lanes per row of A in k_upper_bound, a power of two; rows beyond 32 passes go to its long list
         int g = 1;
         while (g < value && g < 64) g <<= 1;
