@@ -322,11 +322,13 @@ __global__ __launch_bounds__(256) void k_class_reset(int* __restrict__ small, in
     for (int i = i0; i < nScan; i += step) scanState[i] = 0ull;
 }
 
+constexpr int kLineWindow = 4096, kLineMax = 512;                  // rows compared for the grid-line hint, the longest line it finds
 // The period hint: eight rows spread over the matrix, each compared with the rows 1 .. 8 before it; the smallest
 // distance at which a sample repeats, by majority (1 when there is none).  One wave, at hand-over time.
 __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out,
-                                                   int* __restrict__ local = nullptr, int ncols = 0)
+                                                   int* __restrict__ local = nullptr, int ncols = 0, int* __restrict__ line = nullptr)
 {
+    __shared__ unsigned char changed[kLineWindow + kLineMax];
     const int lane = threadIdx.x, smp = lane >> 3, d = (lane & 7) + 1;
     const long long row = (long long)(smp + 1) * nrows / 9;
     bool same = row - d >= 0 && row < nrows;
@@ -360,6 +362,38 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { dist += __shfl_xor(dist, o, 64); cnt += __shfl_xor(cnt, o, 64); }
         if (lane == 0) *local = (cnt == 0 || ncols <= 4096 || dist * 16 < (long long)cnt * ncols) ? 1 : 0;   // (a small B sits in the caches anyway)
+    }
+    // Third hint (round 4), for the ring kernel: the length of a grid line.  Where a grid's line of unknowns ends the row
+    // lengths change (the neighbour beyond the end is missing), so the places where a row's length differs from the row
+    // before it repeat with the line's length -- also in the grid's first and last lines, whose rows are shorter but change
+    // at the same places.  A window of kLineWindow rows from the middle of the matrix.
+    if (line != nullptr) {
+        const long long first = (long long)nrows / 2;
+        int found = 0;
+        if (first >= 1 && first + kLineWindow + kLineMax < nrows) {
+            int changes = 0;
+            for (int i = lane; i < kLineWindow + kLineMax; i += 64) {
+                const int a = Rp[first + i - 1], b = Rp[first + i], c = Rp[first + i + 1];
+                changed[i] = (unsigned char)(c - b != b - a);
+                changes += i < kLineWindow && c - b != b - a;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) changes += __shfl_xor(changes, o, 64);
+            __syncthreads();
+            // lane l tries the lengths 16 + l, 16 + 64 + l, ...: the smallest that fits all but an eighth of the changes (a
+            // wrong length misses nearly all of them; the right one a few where the window crosses from plane to plane)
+            const int allowed = changes / 8;
+            found = 0x7fffffff;
+            for (int P = 16 + lane; changes > 0 && P <= kLineMax; P += 64) {
+                int miss = 0;
+                for (int i = 0; miss <= allowed && i < kLineWindow; ++i) miss += changed[i] != changed[i + P];
+                if (miss <= allowed) { found = P; break; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) found = min(found, __shfl_xor(found, o, 64));
+            if (found == 0x7fffffff) found = 0;
+        }
+        if (lane == 0) *line = found;
     }
 }
 

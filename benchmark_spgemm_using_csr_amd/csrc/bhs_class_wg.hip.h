@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     long long nnzA, const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classMap, const int* __restrict__ classRel,
     const int* __restrict__ classLane, const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx,
-    int accStride, int stageCap, int ringCap, int rowBase)     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
+    int accStride, int stageCap, int ringCap, int rowBase, int superRows)     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     const int lane = threadIdx.x;
@@ -67,10 +67,13 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     acc_t* sAx = acc + accStride;                                // A values of the run at hand
     value_t* ring = reinterpret_cast<value_t*>(sAx + stageCap);
 
-    // super-runs: XCD x takes [x * perX, (x + 1) * perX); block b runs on XCD b % 8
-    constexpr int RPS = kClassSuper / kClassRun;                 // runs per super-run
-    const int nRuns = (m + kClassRun - 1) / kClassRun;
-    const int nSuper = (nRuns + RPS - 1) / RPS;
+    // super-runs of superRows consecutive rows (a grid line of A where it has such lines -- the waves of an XCD then walk
+    // neighbouring lines side by side and meet in the same rows of B -- else kClassSuper), cut into runs of kClassRun rows,
+    // the last one of a super-run shorter if it must be: XCD x takes the super-runs [x * perX, (x + 1) * perX); block b
+    // runs on XCD b % 8
+    const int RPS = (superRows + kClassRun - 1) / kClassRun;     // runs per super-run
+    const int nSuper = (m + superRows - 1) / superRows;
+    const int nRuns = nSuper * RPS;
     const int xcd = blockIdx.x & 7, perX = (nSuper + 7) / 8;
     const int wavesPerX = gridDim.x >> 3, wIdx = blockIdx.x >> 3;
     // the i-th run this wave works on: run (i % RPS) of its (i / RPS)-th super-run
@@ -79,6 +82,11 @@ __global__ __launch_bounds__(64) void k_class_numeric(
         if (sr >= perX) return nRuns;
         const long long run = ((long long)xcd * perX + sr) * RPS + i % RPS;
         return (int)min((long long)nRuns, run);
+    };
+    auto first_row = [&](int run) { return (run / RPS) * superRows + (run % RPS) * kClassRun; };
+    auto rows_of = [&](int run) {
+        if (run >= nRuns) return 0;
+        return max(0, min(min(kClassRun, superRows - (run % RPS) * kClassRun), m - first_row(run)));
     };
 
     // A run's metadata travels through a three-deep register pipeline so that no load is waited for where it is
@@ -89,14 +97,14 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     struct RunPtrs { int ap, cp, cls; };
     auto load_ptrs = [&](int run) {
         RunPtrs r{0, 0, -1};
-        if (run < nRuns) {
-            const int row0 = run * kClassRun, nr = min(kClassRun, m - row0);
+        const int nr = rows_of(run);
+        if (nr > 0) {
+            const int row0 = first_row(run);
             if (lane <= nr) { r.ap = Ap[row0 + lane]; r.cp = Cp[row0 + lane]; }
             if (lane < nr) r.cls = classC[row0 + lane];
         }
         return r;
     };
-    auto rows_of = [&](int run) { return run < nRuns ? min(kClassRun, m - run * kClassRun) : 0; };
     auto entries_of = [&](const RunPtrs& r, int nr) { return min(__builtin_amdgcn_readlane(r.ap, nr) - __builtin_amdgcn_readlane(r.ap, 0), stageCap); };
 
     // class at hand (registers) ...
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(64) void k_class_numeric(
     for (int it = 0;; ++it) {
         const int run = run_of(it);
         if (run >= nRuns) break;
-        const int row0 = run * kClassRun, nr = rows_of(run);
+        const int row0 = first_row(run), nr = rows_of(run);
         const int base = __builtin_amdgcn_readlane(p0.ap, 0);
         // requests for the runs behind this one (consumed behind this run's first vmcnt(0))
         const RunPtrs p3 = load_ptrs(run_of(it + 3));

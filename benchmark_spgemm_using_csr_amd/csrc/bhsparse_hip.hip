@@ -205,6 +205,8 @@ struct bhs_handle {
     int forcePath = 0;
     int noPack32 = 0;                    // test hook: force 64-bit sort keys
     int wgPerCU = 0;                     // tuning hook: persistent workgroups per CU (0 = occupancy API)
+    int classSuperRows = 0;              // tuning hook: consecutive rows a wave of the ring kernel takes (0 = a grid line of A, or kClassSuper)
+    int lineA = 0;                       // rows per grid line of A if it has such lines, starting at row 0 (k_row_period), else 0
     int symLoadPct = 75, numLoadPct = 75; // max table load factor (percent) that decides a row's bin
     int maxTableLog2 = 15;
     // timing
@@ -258,7 +260,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal */,
+       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
+                       the length of A's grid lines */,
        S_SMALL_INTS = 454 };
 
 template <int V> struct template_int { static constexpr int value = V; };
@@ -537,14 +540,15 @@ int launch_class_numeric_impl(bhs_handle* h, int r0, int r1)
     perCU = std::max(1, std::min(perCU, 32));
     const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
     const int mR = r1 - r0;
-    const long long nSuper = ((long long)mR + kClassSuper - 1) / kClassSuper;
+    const int superRows = std::max(4 * kClassRun, h->classSuperRows > 0 ? h->classSuperRows : (h->lineA > 0 ? h->lineA : kClassSuper));
+    const long long nSuper = ((long long)mR + superRows - 1) / superRows;
     long long grid = std::min<long long>(nSuper, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     if (h->verbose > 1) printf("  [class numeric (ring): %d waves per CU by the occupancy API, %d used, %zu bytes of LDS each, grid %lld]\n", perCU, useCU, smem, grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        (long long)h->nnzA, h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
                        (const unsigned*)h->classMap.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
-                       out_cx(h), accStride, stageCap, ringCap, r0);
+                       out_cx(h), accStride, stageCap, ringCap, r0, superRows);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -1671,12 +1675,12 @@ int finish_set_data(bhs_handle* h)
     // the scans of the data set (longest rows, the period hint, sortedness of B's rows) are queued together and read
     // back with ONE synchronisation
     int* small0 = (int*)h->small.p;
-    BHS_HIP(hipMemsetAsync(small0 + S_SCAN, 0, sizeof(int) * 5, h->stream));
+    BHS_HIP(hipMemsetAsync(small0 + S_SCAN, 0, sizeof(int) * (S_SMALL_INTS - S_SCAN), h->stream));
     h->periodA = h->periodB = 1;
     if (h->m > 0) {
         const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 2);
         hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_SCAN);
-        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1, small0 + S_SCAN + 4, h->k);
+        hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1, small0 + S_SCAN + 4, h->k, small0 + S_SCAN + 5);
         BHS_HIP(hipGetLastError());
     }
     if (h->k > 0) {
@@ -1716,14 +1720,25 @@ int finish_set_data(bhs_handle* h)
         BHS_TRY(check_sorted());
     }
     int* hscan = (int*)h->hostSmall;                                // (pinned)
-    BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 5, hipMemcpyDeviceToHost, h->stream));
-    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 5, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 6, hipMemcpyDeviceToHost, h->stream));
+    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     const int maxRowA = hscan[0];
     h->maxRowA = maxRowA;
     h->maxRowB = hscan[2];
     if (h->m > 0) h->periodA = hscan[1];
     h->localA = h->m > 0 ? hscan[4] : 1;
+    // a wave of the ring kernel takes whole grid lines when A has them (rows whose lengths repeat with that period,
+    // the matrix a whole number of them) -- a stretch of rows ends where a line ends anyway
+    h->lineA = 0;
+    if (h->m > 0 && hscan[5] >= 16 && h->m % hscan[5] == 0) {
+        // (measured on poisson27pt n^3 against 64 rows: n = 96 -8 %, 110 -6 %, 160 -4 %, 200 -4 %, 128 -1 %; n = 100, whose
+        // line ends in half a run, +1 %; n = 72, 1.7 lines per wave, +3 %)
+        int line = hscan[5];
+        while (line < 48) line *= 2;
+        const int whole = (line + kClassRun - 1) / kClassRun * kClassRun;
+        if (line <= 256 && (whole - line) * 50 <= line && h->m / line >= 32LL * h->numCU) h->lineA = line;
+    }
     if (h->k > 0) h->periodB = hscan[3];
     // lanes per row of A in k_upper_bound: the average row for regular inputs, widened for skewed ones so
     // that the longest row is walked in <= 32 passes
@@ -1739,7 +1754,7 @@ int finish_set_data(bhs_handle* h)
     }
     if (checkB) {
         int* small = small0;
-        int flag = hscan[5];
+        int flag = hscan[6];
         h->bSorted = flag ? 0 : 1;
         if (!h->bSorted && h->sortB) {
             // Unsorted rows of B: sort them once here (the reference's driver does this on the host before
@@ -2163,6 +2178,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_super_rows")) { h->classSuperRows = (int)std::max<long long>(0, std::min<long long>(value, 1 << 15)); return BHS_SUCCESS; }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "wave_first")) { h->waveFirst = value != 0; return BHS_SUCCESS; }
@@ -2214,6 +2230,7 @@ int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
     if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
     if (!strcmp(key, "local_a")) { *value_out = h->localA; return BHS_SUCCESS; }
+    if (!strcmp(key, "line_a")) { *value_out = h->lineA; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b_used")) { *value_out = h->cmpState > 0 ? 1 : 0; return BHS_SUCCESS; }
     return BHS_ERR_INVALID_ARG;
 }
