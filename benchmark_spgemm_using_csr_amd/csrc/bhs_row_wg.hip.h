@@ -443,9 +443,12 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
     const int* __restrict__ Aj, const value_t* __restrict__ Ax,
     const int* __restrict__ Bp, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ cntOut, int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket,
-    int reverse)                                               // 1: queue taken from its end (longest rows there)
+    int reverse,                                               // 1: queue taken from its end (longest rows there)
+    const int* __restrict__ qnDev = nullptr)                  // the queue's length is this word on the device (k_row_wave_window's spill list)
 {
     constexpr int BLOCK = kLdsBitmapBlock, CH = kLdsBitmapChunk, U = 4, NW = BLOCK / 64;
+    if (qnDev != nullptr) qn = *qnDev;
+    if (qn <= 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     unsigned* bm = reinterpret_cast<unsigned*>(smemRaw);
     int* rank8 = reinterpret_cast<int*>(bm + nWords);

@@ -1,0 +1,368 @@
+// bhs_row_window.hip.h -- rows of a few thousand entries of C, one WAVE per row, column window by column window: the
+// bitmap accumulator of bhs_row_wg.hip.h with a bitmap of one window, the window's piece of the row put together in LDS.
+#pragma once
+
+namespace bhs {
+
+// ===========================================================================
+// The reference sends rows of more than 512 entries through EM_mergepath / EM_mergepath_global (bhsparse_cuda.h:1043-
+// 1489): a merge of the row's B rows in shared memory, out to HBM when the row outgrows it, one workgroup per row.
+// k_row_bitmap_lds (bhs_row_wg.hip.h) keeps one occupancy bit per COLUMN OF B in LDS instead -- 128 KB for 2^20 columns,
+// one row per CU at a time -- and every phase of a row is a handful of dependent round trips to L2 with nothing to hide
+// them behind.  That is fine for a row of 10^5 products and poor for the rows a graph has most of: an R-MAT graph of
+// 2^20 rows has 38 k rows of 2 k .. 8 k entries of C (12 entries of A times B rows of 250, typically), and that kernel
+// spent 54 us on each.  What such rows cost is (a) the round trips and (b) requests: one 4-byte store per column from the
+// ordered sweep, one 8-byte store or fp64 atomic per product, each its own 64-byte request to L2 (measured on this
+// kernel's first form, 125 M products: 3.0 ms as a whole, 2.1 with plain stores for the atomics, 1.4 without the
+// products' stores, 0.66 without any store).
+//
+// Here:
+//   * the columns are cut into WINDOWS of at most 2^16 columns (an 8 KB bitmap) and a wave walks its row window by
+//     window: no barrier anywhere, ten rows in flight per CU;
+//   * the windows hold about equal shares of B's entries, not equal shares of the columns (k_window_hist /
+//     k_window_pick: a graph's columns are anything but uniform -- with equal widths the first window of an R-MAT row
+//     held a third of it);
+//   * an index of B built at the start of the multiply (k_b_windows16) says where each window begins in every row of B
+//     (rows of B ascend, so a window's entries are one contiguous piece of the row): a window's products are a flat space
+//     over the pieces, every product is loaded once per pass, and a lane reads its B row's window starts one window ahead;
+//   * pass 1 sets bits; ONE wave scan of the lanes' totals ranks everything (a lane owns 32 consecutive bitmap words,
+//     stored group-swizzled so that the lanes' 16-byte reads spread over the banks); pass 2 adds every product to its
+//     entry's value IN LDS (ds_add_f64) and writes the entry's column beside it -- no sweep over the bitmap -- and both
+//     arrays leave 64 lanes wide.  A window with more entries than the staging arrays hold is done in rounds by rank;
+//   * a window of at most 512 products (nearly all of them) keeps columns and products of pass 1 in registers: pass 2
+//     neither searches nor loads.
+// ===========================================================================
+constexpr int kWwLog2 = 16;                                        // most columns per window
+constexpr int kWwWords = 1 << (kWwLog2 - 5);                       // 2048 bitmap words
+constexpr int kWwBucketLog2 = 12;                                  // window boundaries are multiples of 4096 columns
+constexpr int kWwBuckets = 256;                                    // ... so at most 2^20 columns
+constexpr int kWwMax = 32;                                         // most windows: 15 cuts by share of B's entries + 16 by width
+constexpr int kWwU = 8;                                            // products per lane and batch
+constexpr int kWwCap = 384;                                        // entries of C staged per round
+constexpr int kWwSpillA = 128;                                     // longest row of A this kernel keeps
+constexpr int kWwSpillWin = 2048;                                  // most products of one window it keeps
+constexpr int kWwStride = kWwMax + 2;                              // 16-bit offsets per row of B in the index (even: a row starts on a 4-byte boundary)
+constexpr int kWwTabInts = kWwMax + 2;                             // device table: the number of windows, their first columns, n
+#ifndef BHS_WW_LAB
+#define BHS_WW_LAB 0                                               // measurement switches: 2 no pass 2, 4 no write-out
+#endif
+
+#if BHS_PHASES_SPA
+#define BHS_TICK_WW(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); phw[i] += t__ - tWw; tWw = t__; } while (0)
+#else
+#define BHS_TICK_WW(i) do { } while (0)
+#endif
+
+// entries of B per bucket of 4096 columns
+__global__ __launch_bounds__(256) void k_window_hist(long long nnzB, const int* __restrict__ Bj, unsigned* __restrict__ hist)
+{
+    __shared__ unsigned h[kWwBuckets];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nnzB; i += (long long)gridDim.x * 256)
+        atomicAdd(&h[min(Bj[i] >> kWwBucketLog2, kWwBuckets - 1)], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// the windows: a new one begins when the one at hand holds a fifteenth of B's entries or is 2^16 columns wide (at most
+// 15 + 16 such places in 256 buckets: 32 windows)
+// tab[0] = number of windows, tab[1 + w] = first column of window w, tab[1 + nWin] = n
+__global__ __launch_bounds__(64) void k_window_pick(int n, long long nnzB, const unsigned* __restrict__ hist, int* __restrict__ tab)
+{
+    if (threadIdx.x != 0) return;
+    const int nb = (n + (1 << kWwBucketLog2) - 1) >> kWwBucketLog2;
+    const long long target = (nnzB + 14) / 15;
+    int nWin = 0, width = 0;
+    long long acc = 0;
+    tab[1] = 0;
+    for (int b = 0; b < nb; ++b) {
+        acc += hist[b];
+        ++width;
+        if (b + 1 < nb && (acc >= target || width == (1 << (kWwLog2 - kWwBucketLog2))) && nWin + 1 < kWwMax) {
+            ++nWin;
+            tab[1 + nWin] = (b + 1) << kWwBucketLog2;
+            acc = 0;
+            width = 0;
+        }
+    }
+    ++nWin;
+    tab[1 + nWin] = n;
+    tab[0] = nWin;
+}
+
+// where the windows begin in every row of B, as 16-bit offsets from the row's start (rows of B are shorter than 2^16):
+// win[r * kWwStride + w] = entries of row r with a column before window w (w = 0 .. kWwMax, the tail repeats the row's length)
+__global__ __launch_bounds__(256) void k_b_windows16(int k, const int* __restrict__ tab, const int* __restrict__ Bp, const int* __restrict__ Bj,
+                                                     unsigned short* __restrict__ win)
+{
+    // (a row's offsets are staged in LDS and leave as one contiguous piece per block)
+    __shared__ unsigned short stage[256 * kWwStride + 2];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int nWin = tab[0];
+    if (r < k) {
+        const int s = Bp[r], e = Bp[r + 1];
+        unsigned short* out = stage + threadIdx.x * kWwStride;
+        int pos = s;
+        out[0] = 0;
+        for (int w = 1; w < nWin; ++w) {
+            const int lim = tab[1 + w];
+            if (e - pos <= 8) {
+                while (pos < e && Bj[pos] < lim) ++pos;
+            } else {
+                int lo = pos, hi = e;                              // first entry in [pos, e) with column >= lim
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (Bj[mid] < lim) lo = mid + 1; else hi = mid; }
+                pos = lo;
+            }
+            out[w] = (unsigned short)(pos - s);
+        }
+        for (int w = nWin; w < kWwStride; ++w) out[w] = (unsigned short)(e - s);
+    }
+    __syncthreads();
+    const int rows = min(256, k - blockIdx.x * 256);
+    const unsigned* src = reinterpret_cast<const unsigned*>(stage);
+    unsigned* dst = reinterpret_cast<unsigned*>(win + (size_t)blockIdx.x * 256 * kWwStride);
+    const int n32 = rows * kWwStride / 2;
+    for (int i = threadIdx.x; i < n32; i += 256) dst[i] = src[i];
+}
+
+// bitmap, rank of every 8-word group + the eight words' offsets from it (one byte each), chunk arrays, staged columns and values
+constexpr size_t wave_window_smem() { return (size_t)kWwWords * 4 + (size_t)(kWwWords / 8) * 12 + 2 * 64 * sizeof(int) + (size_t)kWwCap * (sizeof(int) + sizeof(acc_t)); }
+
+// word x of a wave's bitmap lives at: its lane's block (x >> 5), the 8-word group rotated by the block number, the word
+__device__ __forceinline__ int ww_phys(int x) { return (x & ~31) | ((((x >> 3) ^ (x >> 5)) & 3) << 3) | (x & 7); }
+
+__global__ __launch_bounds__(64) void k_row_wave_window(
+    const int4* __restrict__ desc, int qn, const int* __restrict__ tab, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const unsigned short* __restrict__ Bwin, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket, int reverse,
+    int4* __restrict__ spill)                                  // spill[0].x: rows handed on, spill[1 ..]: their descriptors
+{
+    constexpr int U = kWwU, CAP = kWwCap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    acc_t* vals = reinterpret_cast<acc_t*>(smemRaw);               // (first: 8-byte aligned whatever follows)
+    unsigned* bm = reinterpret_cast<unsigned*>(vals + CAP);
+    int* rank8 = reinterpret_cast<int*>(bm + kWwWords);
+    uint2* sub8 = reinterpret_cast<uint2*>(rank8 + kWwWords / 8);      // entries before each word of a group, from the group's first (<= 224: a byte)
+    int* sIncl = reinterpret_cast<int*>(sub8 + kWwWords / 8);
+    int* sBase = sIncl + 64;
+    int* cols = sBase + 64;
+    const int lane = threadIdx.x;
+    const int nWin = __builtin_amdgcn_readfirstlane(tab[0]);
+    for (int i = lane; i < kWwWords / 4; i += 64) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    wave_sync();
+#if BHS_PHASES_SPA
+    unsigned long long phw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tWw = __builtin_readcyclecounter();
+#endif
+
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(ticket, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= qn) break;
+        const int4 d = desc[reverse ? qn - 1 - q : q];
+        const int a0 = d.y, a1 = d.z;
+        // A row of A with hundreds of entries and short B rows (a hub of a web graph) is the wrong shape for windows --
+        // entries x windows pieces to look up, nearly all of them empty: it goes on to k_row_bitmap_lds, which walks
+        // whole B rows, through the spill list.
+        if (a1 - a0 > kWwSpillA) {
+            if (lane == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
+            continue;
+        }
+        // ... and so does a row whose products crowd into one window (a web graph's rows: neighbouring pages): thousands
+        // of products of one window want the 1024 lanes of that kernel, not rounds of 384 entries by one wave.  The
+        // windows' product counts come from the index alone: 17 loads per entry of A, 32 wave sums.
+        {
+            unsigned pk[kWwStride / 2];
+            int len[kWwMax];
+#pragma unroll
+            for (int w = 0; w < kWwMax; ++w) len[w] = 0;
+            for (int ca = a0; ca < a1; ca += 64) {
+                if (ca + lane < a1) {
+                    const unsigned* src = reinterpret_cast<const unsigned*>(Bwin + (size_t)Aj[ca + lane] * kWwStride);
+#pragma unroll
+                    for (int i = 0; i < kWwStride / 2; ++i) pk[i] = src[i];
+#pragma unroll
+                    for (int w = 0; w < kWwMax; ++w) {
+                        const unsigned lo = w & 1 ? pk[w / 2] >> 16 : pk[w / 2] & 0xFFFFu;
+                        const unsigned hi = (w + 1) & 1 ? pk[(w + 1) / 2] >> 16 : pk[(w + 1) / 2] & 0xFFFFu;
+                        len[w] += (int)(hi - lo);
+                    }
+                }
+            }
+            int most = 0;
+#pragma unroll
+            for (int w = 0; w < kWwMax; ++w) most = max(most, wave_sum_dpp(len[w]));
+            if (most > kWwSpillWin) {
+                if (lane == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
+                continue;
+            }
+        }
+        long long base = (long long)d.w;                           // where the window at hand begins in the row of C
+        // a row of A of at most 64 entries (nearly all of them) is read once: a lane keeps its entry's value and walks the
+        // window starts of its B row one load ahead of the window at hand -- no round trip per window but the products'
+        const bool single = a1 - a0 <= 64;
+        acc_t av = 0.0;                                            // this lane's A value of the chunk at hand
+        const unsigned short* wptr = Bwin;
+        int rowB = 0, cur = 0, nxt = 0;
+        if (single && a0 + lane < a1) {
+            const int c = Aj[a0 + lane];
+            wptr = Bwin + (size_t)c * kWwStride;
+            rowB = Bp[c];
+            av = (acc_t)Ax[a0 + lane];
+            nxt = wptr[1];
+        }
+        BHS_TICK_WW(0);
+        for (int w = 0; w < nWin; ++w) {
+            const int colBase = tab[1 + w], words = (tab[2 + w] - colBase + 31) >> 5;   // (wave-uniform: scalar loads)
+            int total = 0, rowTotal = 0;
+            // products of the last batch, kept for pass 2 when the window has one chunk and one batch
+            int kc[U], ke[U];
+            acc_t kv[U];
+            const int sb0 = rowB + cur, slen = nxt - cur;          // (single) this lane's piece of the window
+            cur = nxt;
+            if (single && a0 + lane < a1 && w + 2 <= nWin) nxt = wptr[w + 2];
+            // the window's pieces of 64 B rows -> a flat product space (sIncl / sBase); returns its size
+            auto stage_chunk = [&](int ca) {
+                int b0 = sb0, len = slen;
+                if (!single) {
+                    b0 = len = 0;
+                    av = 0.0;
+                    if (ca + lane < a1) {
+                        const int c = Aj[ca + lane];
+                        const unsigned short* src = Bwin + (size_t)c * kWwStride + w;
+                        b0 = Bp[c] + src[0];
+                        len = (int)src[1] - (int)src[0];
+                        av = (acc_t)Ax[ca + lane];
+                    }
+                }
+                const int incl = wave_incl_scan_dpp(len);
+                sIncl[lane] = incl;
+                sBase[lane] = b0 - (incl - len);
+                wave_sync();
+                return __builtin_amdgcn_readlane(incl, 63);
+            };
+            auto find = [&](int p) {                               // first entry j with sIncl[j] > p
+                int l = 0, r = 63;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
+                return l;
+            };
+            // one batch of the chunk's products: column within the window (-1: none), A entry within the chunk, A value x B value
+            auto load_batch = [&](int p0, bool values) {
+                long long idx[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * 64 + lane;
+                    ke[u] = p < total ? find(p) : 0;
+                    idx[u] = (long long)sBase[ke[u]] + p;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool on = p0 + u * 64 + lane < total;
+                    kc[u] = on ? Bj[idx[u]] - colBase : -1;
+                    kv[u] = on && values ? (acc_t)Bx[idx[u]] : (acc_t)0;
+                }
+                if (values) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kv[u] *= __shfl(av, ke[u], 64);   // (product formed in acc_t)
+                }
+            };
+            // ---- pass 1: occupancy bits
+            for (int ca = a0; ca < a1; ca += 64) {
+                total = stage_chunk(ca);
+                rowTotal += total;
+                for (int p0 = 0; p0 < total; p0 += 64 * U) {
+                    load_batch(p0, single && total <= 64 * U);     // (values only if they stay in registers for pass 2)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (kc[u] >= 0) atomicOr(&bm[ww_phys(kc[u] >> 5)], 1u << (kc[u] & 31));
+                }
+                wave_sync();                                       // (the next chunk overwrites sIncl / sBase)
+            }
+            BHS_TICK_WW(1);
+            if (rowTotal == 0) continue;
+            const bool kept = single && rowTotal <= 64 * U;
+            // ---- the lanes' totals, their ranks, the rank of every 8-word group and of every word within it
+            const int blk = lane * 32, rot = lane & 3;
+            int cnt4[4] = {0, 0, 0, 0}, mine = 0;
+            if (blk < words) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint4 lo = *reinterpret_cast<const uint4*>(&bm[blk + ((j ^ rot) << 3)]);
+                    const uint4 hi = *reinterpret_cast<const uint4*>(&bm[blk + ((j ^ rot) << 3) + 4]);
+                    const int c0 = __popc(lo.x), c1 = c0 + __popc(lo.y), c2 = c1 + __popc(lo.z), c3 = c2 + __popc(lo.w);
+                    const int c4 = c3 + __popc(hi.x), c5 = c4 + __popc(hi.y), c6 = c5 + __popc(hi.z);
+                    cnt4[j] = c6 + __popc(hi.w);
+                    sub8[lane * 4 + j] = make_uint2((unsigned)(c0 << 8 | c1 << 16 | c2 << 24), (unsigned)(c3 | c4 << 8 | c5 << 16 | c6 << 24));
+                    mine += cnt4[j];
+                }
+            }
+            const int incl = wave_incl_scan_dpp(mine);
+            const int winCount = __builtin_amdgcn_readlane(incl, 63);
+            const int first = incl - mine;                         // rank of this lane's first column
+            *reinterpret_cast<int4*>(&rank8[lane * 4]) = make_int4(first, first + cnt4[0], first + cnt4[0] + cnt4[1], first + cnt4[0] + cnt4[1] + cnt4[2]);
+            BHS_TICK_WW(2);
+            // rank of column c of the window (its bit is set): its group's, its word's offset in the group, the bits below it
+            auto rank_of = [&](int c) {
+                const int wd = c >> 5, grp = wd >> 3, k = wd & 7;
+                const uint2 sb = sub8[grp];
+                const unsigned word = bm[ww_phys(wd)];
+                const unsigned off = ((k & 4 ? sb.y : sb.x) >> ((k & 3) * 8)) & 255u;
+                return rank8[grp] + (int)off + __popc(word & ((1u << (c & 31)) - 1u));
+            };
+            wave_sync();
+            // ---- rounds of CAP entries: zeroed values in LDS, every product added to its entry, out in full-width stores
+            for (int r0 = 0; r0 < winCount; r0 += CAP) {
+                const int nr = min(CAP, winCount - r0);
+                for (int i = lane; i < nr; i += 64) vals[i] = 0.0;
+                wave_sync();
+                BHS_TICK_WW(3);
+                auto add = [&](int c, acc_t v) {
+                    const int pos = rank_of(c) - r0;
+                    if ((unsigned)pos < (unsigned)CAP) {
+                        cols[pos] = colBase + c;                   // (every product of the entry writes the same column: no sweep over the bitmap)
+                        unsafeAtomicAdd(&vals[pos], v);
+                    }
+                };
+                if (BHS_WW_LAB & 2) {
+                } else if (kept) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (kc[u] >= 0) add(kc[u], kv[u]);
+                } else {
+                    for (int ca = a0; ca < a1; ca += 64) {
+                        total = stage_chunk(ca);
+                        for (int p0 = 0; p0 < total; p0 += 64 * U) {
+                            load_batch(p0, true);
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+                                if (kc[u] >= 0) add(kc[u], kv[u]);
+                        }
+                        wave_sync();
+                    }
+                }
+                wave_sync();
+                BHS_TICK_WW(4);
+                if (!(BHS_WW_LAB & 4)) {
+                    for (int i = lane; i < nr; i += 64) {
+                        Cj[base + r0 + i] = cols[i];
+                        Cx[base + r0 + i] = (value_t)vals[i];
+                    }
+                }
+                wave_sync();
+                BHS_TICK_WW(5);
+            }
+            base += winCount;
+            // ---- leave the bitmap clean
+            for (int i = lane; i * 4 < ((words + 31) & ~31); i += 64) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);   // (whole blocks: the words are swizzled within them)
+            wave_sync();
+            BHS_TICK_WW(6);
+        }
+    }
+#if BHS_PHASES_SPA
+    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_phase_cycles[i], phw[i]);
+#endif
+}
+
+}  // namespace bhs

@@ -16,6 +16,7 @@
 #include "bhs_kernels.hip.h"
 #include "bhs_row_wg.hip.h"
 #include "bhs_row_wave.hip.h"
+#include "bhs_row_window.hip.h"
 #include "bhs_row_quad.hip.h"
 #include "bhs_compress.hip.h"
 #include "bhs_row_lane.hip.h"
@@ -146,6 +147,9 @@ struct bhs_handle {
     // hub rows (bhs_hub.hip.h): rows with at least hubMin products are cut into items of hubItemProducts products
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
+    DevBuf bWinSpill;                    // k_row_wave_window's spill lists
+    DevBuf bWin, bWinTab;                // where the column windows begin in every row of B, the windows themselves (k_b_windows16, k_window_pick): rebuilt by the multiplies that need them
+    int useWindowBitmap = 1;             // rows of 2 k .. 8 k entries one wave each, window by window (k_row_wave_window): 0 never, 1 if there are many, 2 always
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
     int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
@@ -236,6 +240,8 @@ struct bhs_handle {
         unsigned long long symSums[kMaxBins * 3];
         bool numDirectFull = false;
         int rangesRun = 0;
+        bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
+        long long midRows = 0;           // rows of the numeric bins between the hash tables and the long rows
     } ps;
     // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
     int* extCj = nullptr;
@@ -414,7 +420,7 @@ int launch_row_spa(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 
 // Long rows of matrices with <= 2^20 columns: bitmap accumulator in LDS, one 1024-lane workgroup per CU.
 template <bool NUM>
-int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, int reverse = 0)
+int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, int reverse = 0, const int* qnDev = nullptr)
 {
     auto kern = k_row_bitmap_lds<NUM>;
     int perCUunused = 1;     // (one workgroup per CU by design; the call raises the dynamic-LDS limit for this device)
@@ -426,7 +432,7 @@ int launch_row_bitmap_lds(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt
     BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLdsBitmapBlock), lds_bitmap_smem<NUM>(nWords), h->ls, queue,
                        qn, nWords, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h),
-                       small + h->ticketSlot, reverse);
+                       small + h->ticketSlot, reverse, qnDev);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }
@@ -525,6 +531,51 @@ RingLds class_ring_lds(bhs_handle* h)
     l.ringCap = (int)(((long long)h->ps.classMaxRing + 3) & ~3ll);
     l.bytes = (size_t)(l.accStride + l.stageCap) * sizeof(acc_t) + (size_t)l.ringCap * sizeof(value_t);
     return l;
+}
+
+// rows of a few thousand entries window by window, a wave each (bhs_row_window.hip.h): the windows and the index of B
+// (on h->stream, before the bins fork: every bin's stream waits for it)
+int ensure_b_windows(bhs_handle* h)
+{
+    if (h->ps.bWinBuilt) return BHS_SUCCESS;
+    BHS_TRY(ensure(h, h->bWinTab, (kWwBuckets + kWwTabInts) * sizeof(int)));
+    BHS_TRY(ensure(h, h->bWin, (size_t)std::max(h->k, 1) * (size_t)kWwStride * sizeof(unsigned short)));
+    unsigned* hist = (unsigned*)h->bWinTab.p;
+    int* tab = (int*)h->bWinTab.p + kWwBuckets;
+    EventPair* ep = nullptr;
+    BHS_TRY(timed_begin(h, "b_windows", &ep));
+    BHS_HIP(hipMemsetAsync(hist, 0, kWwBuckets * sizeof(unsigned), h->stream));
+    const long long gh = std::max<long long>(1, std::min<long long>(((long long)h->nnzB + 4095) / 4096, (long long)h->numCU * 4));
+    hipLaunchKernelGGL(k_window_hist, dim3((unsigned)gh), dim3(256), 0, h->stream, (long long)h->nnzB, h->dBj, hist);
+    hipLaunchKernelGGL(k_window_pick, dim3(1), dim3(64), 0, h->stream, h->n, (long long)h->nnzB, (const unsigned*)hist, tab);
+    hipLaunchKernelGGL(k_b_windows16, dim3((unsigned)((h->k + 255) / 256)), dim3(256), 0, h->stream, h->k, (const int*)tab, h->dBp, h->dBj,
+                       (unsigned short*)h->bWin.p);
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches++;
+    h->ps.bWinBuilt = true;
+    return BHS_SUCCESS;
+}
+
+// one wave per row, windows of 2^16 columns: the numeric bins between the hash tables and the long rows
+int launch_row_wave_window(bhs_handle* h, const int4* queue, int qn, int* Cp, int reverse = 0)
+{
+    auto kern = k_row_wave_window;
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, wave_window_smem(), &perCU));
+    perCU = std::max(1, std::min(perCU, 32));
+    const long long grid = std::max<long long>(1, std::min<long long>(qn, (long long)h->numCU * perCU));
+    int* small = (int*)h->small.p;
+    // the rows it hands on (long rows of A): a list of its own per launch -- the bins run side by side -- then
+    // k_row_bitmap_lds on that list, its length read on the device
+    BHS_TRY(ensure(h, h->bWinSpill, ((size_t)std::max(h->m, 1) + 2 * kMaxBins + 2) * sizeof(int4)));
+    int4* spill = (int4*)h->bWinSpill.p + (queue - (const int4*)h->queue.p) + 2 * (h->ticketSlot - S_TICKETS + 1);
+    BHS_HIP(hipMemsetAsync(spill, 0, sizeof(int4), h->ls));
+    BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), wave_window_smem(), h->ls, queue, qn, (const int*)h->bWinTab.p + kWwBuckets, h->dAj, h->dAx,
+                       h->dBp, (const unsigned short*)h->bWin.p, h->dBj, h->dBx, out_cj(h), out_cx(h), small + h->ticketSlot, reverse, spill);
+    BHS_HIP(hipGetLastError());
+    return launch_row_bitmap_lds<true>(h, spill + 1, h->numCU, Cp, 0, (const int*)spill);
 }
 
 // Numeric pass by row classes on the rows [r0, r1): the ring kernel (bhs_class_wg.hip.h)
@@ -784,10 +835,21 @@ bool bin_takes_lds_bitmap(const bhs_handle* h, const KernelCfg& c)
     return NUM && c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->forcePath == 0;
 }
 
+// (only when the multiply has enough such rows to fill the device's wave slots several times over -- h->ps.midRows, set
+// before the numeric bins fork: the index of B costs 0.12 ms to build, and a few thousand rows are not worth it.  Measured:
+// R-MAT 2^20 rows, 38 k such rows, 18.4 -> 15.1 ms; the two web-graph stand-ins, 1.2 k / 5 k such rows, 1.8 -> 2.1 / 3.1 -> 3.2 ms.)
+template <bool NUM>
+bool bin_takes_wave_window(const bhs_handle* h, const KernelCfg& c)
+{
+    return NUM && !c.win && bin_takes_lds_bitmap<NUM>(h, c) && h->useWindowBitmap && h->bSorted && h->maxRowB < 65536 &&
+           (long long)h->n <= ((long long)kWwBuckets << kWwBucketLog2) && (h->useWindowBitmap >= 2 || h->ps.midRows >= 32LL * h->numCU);
+}
+
 template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt, int reverse = 0)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
+    if (queue != nullptr && bin_takes_wave_window<NUM>(h, c)) return launch_row_wave_window(h, queue, qn, CpOrCnt, reverse);
     if (bin_takes_lds_bitmap<NUM>(h, c)) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt, reverse);
     if (c.win && h->useSpa && h->maxTableLog2 >= 15 && h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
@@ -1520,6 +1582,11 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (full) h->ps.numDirectFull = numDirect;
     h->ps.rangesRun++;
     const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
+    h->ps.midRows = 0;
+    for (int b = 2; b < kNumNumBins; ++b)
+        if (!kNumCfg[b].win && bin_takes_lds_bitmap<true>(h, kNumCfg[b])) h->ps.midRows += numCount[b];
+    for (int b = 2; b < kNumNumBins; ++b)
+        if (numCount[b] && numQueue && bin_takes_wave_window<true>(h, kNumCfg[b])) BHS_TRY(ensure_b_windows(h));
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
     if (numCount[kHubBin]) {
         bin_stream(h, kHubBin);
@@ -1546,8 +1613,9 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // only take CUs from each other, and the shorter bins' launch would trail behind) go as ONE queue, taken
         // from its end so that the longest rows start first.
         int lo = b, rows = numCount[b];
-        if (numQueue && h->mergeBitmapBins && bin_takes_lds_bitmap<true>(h, kNumCfg[b]))
-            while (lo - 1 >= 2 && bin_takes_lds_bitmap<true>(h, kNumCfg[lo - 1])) { --lo; rows += numCount[lo]; }
+        auto kernel_of = [&](int bb) { return !bin_takes_lds_bitmap<true>(h, kNumCfg[bb]) ? 0 : bin_takes_wave_window<true>(h, kNumCfg[bb]) ? 2 : 1; };
+        if (numQueue && h->mergeBitmapBins && kernel_of(b))
+            while (lo - 1 >= 2 && kernel_of(lo - 1) == kernel_of(b)) { --lo; rows += numCount[lo]; }
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kNumNames[b], &ep));
         BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[lo] : nullptr, rows, (int*)h->Cp.p, lo < b));
@@ -1913,6 +1981,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
     release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
     release(h->classBigIdx); release(h->classBigMap);
+    release(h->bWin); release(h->bWinTab); release(h->bWinSpill);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
     if (h->hostSmall) (void)hipHostFree(h->hostSmall);
@@ -2190,6 +2259,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "window_bitmap")) { h->useWindowBitmap = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }

@@ -732,9 +732,53 @@ def test_long_rows_bitmap_accumulators(oracle, n):
     Cp, Cj, Cx, info = _check(oracle, len(rowsA), k, n, A, B)
     assert np.diff(Cp).max() > 6144
     assert "numeric_long_rows" in [kk["name"] for kk in info["kernels"]]
-    for opts in ({"lds_bitmap": 0}, {"spa": 0}, {"lds_bitmap_min_log2": 99}):
+    for opts in ({"lds_bitmap": 0}, {"spa": 0}, {"lds_bitmap_min_log2": 99}, {"window_bitmap": 2}):
         Cp2, Cj2, Cx2, _ = _check(oracle, len(rowsA), k, n, A, B, options=opts)
         assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
+
+
+@pytest.mark.parametrize("n", [2 ** 20, 300000, 70000])
+def test_wave_per_row_column_windows(oracle, n):
+    """Rows of a few thousand entries of C, one wave each, column window by column window (bhs_row_window.hip.h; it
+    takes the place of the reference's EM_mergepath rounds, bhsparse_cuda.h:1043-1489, for graphs).  B's columns are
+    skewed like an R-MAT graph's -- the windows are cut by B's entries, not by columns -- and the rows of A cover: up to
+    64 entries (everything in registers), 65 .. 128 (two chunks), more (handed on to k_row_bitmap_lds), a window of
+    more than 512 products (pass 2 loads again, several rounds of 384 entries), products crowded into one window
+    (handed on), columns hit many times, an empty row of B, the first and the last column."""
+    rng = np.random.default_rng(n % 977)
+    k = 3000
+
+    def skewed(count):
+        c = (n * rng.random(count) ** 3).astype(np.int64)           # a third of the entries in the first 1/27 of the columns
+        return np.unique(np.minimum(c, n - 1))
+
+    rowsB = [skewed(int(rng.integers(150, 500))) for _ in range(k)]
+    rowsB[5] = np.empty(0, np.int64)
+    rowsB[6] = np.array([0, n - 1])
+    for j in range(10, 40):                                          # thirty rows of B inside one stretch of 20 000 columns
+        rowsB[j] = np.unique(n // 2 + rng.integers(0, 20000, 1500))
+    Bp = np.zeros(k + 1, np.int32); Bp[1:] = np.cumsum([len(r) for r in rowsB])
+    Bj = np.concatenate(rowsB).astype(np.int32)
+    Bx = rng.integers(1, 10, len(Bj)).astype(np.float64)
+    free = np.setdiff1d(np.arange(40, k), [5, 6])
+    rowsA = [np.sort(rng.choice(free, int(rng.integers(8, 30)), replace=False)) for _ in range(300)]
+    rowsA += [np.sort(rng.choice(free, 64, replace=False)), np.sort(rng.choice(free, 65, replace=False)),
+              np.sort(rng.choice(free, 128, replace=False)), np.sort(rng.choice(free, 129, replace=False)),
+              np.sort(rng.choice(free, 400, replace=False)), np.array([5, 6, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59]),
+              np.arange(10, 40), np.array([5]), np.empty(0, np.int64)]
+    Ap = np.zeros(len(rowsA) + 1, np.int32); Ap[1:] = np.cumsum([len(r) for r in rowsA])
+    Aj = np.concatenate(rowsA).astype(np.int32)
+    Ax = rng.integers(1, 10, len(Aj)).astype(np.float64)
+    A, B = (Ap, Aj, Ax), (Bp, Bj, Bx)
+    Cp, Cj, Cx, info = _check(oracle, len(rowsA), k, n, A, B, options={"window_bitmap": 2, "class_path": 0})
+    names = [kk["name"] for kk in info["kernels"]]
+    assert "b_windows" in names and np.diff(Cp).max() > 8192
+    Cp0, Cj0, Cx0, info0 = _check(oracle, len(rowsA), k, n, A, B, options={"window_bitmap": 0, "class_path": 0})
+    assert "b_windows" not in [kk["name"] for kk in info0["kernels"]]
+    assert np.array_equal(Cj, Cj0) and np.array_equal(Cx, Cx0)
+    # (by default a multiply with so few such rows leaves them with k_row_bitmap_lds)
+    _, _, _, info1 = _check(oracle, len(rowsA), k, n, A, B, options={"class_path": 0})
+    assert "b_windows" not in [kk["name"] for kk in info1["kernels"]]
 
 
 def test_huge_column_space():

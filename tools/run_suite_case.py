@@ -21,10 +21,13 @@ for kv in os.environ.get('BHS_OPTS', '').split(','):
     if kv: k_, v_ = kv.split('='); assert bh.set_option(k_, int(v_)) == 0
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
 for _ in range(2): assert bh.spgemm() == 0
-acc = {}; st = np.zeros(4); n = 5
+acc = {}; info = {}; st = np.zeros(4); n = 5
 for _ in range(n):
     assert bh.spgemm() == 0
     st += np.array(bh.stage_ms) / n
-    for s in bh.kernel_stats(): acc[s["name"]] = acc.get(s["name"], 0) + s["ms"] / n
+    for s in bh.kernel_stats():
+        acc[s["name"]] = acc.get(s["name"], 0) + s["ms"] / n
+        info[s["name"]] = (s["rows"], s["products"], s["nnz_out"])
 print(name, os.environ.get('BHS_OPTS', ''), "stages", np.round(st, 3), "total %.3f ms  %.1f GFLOPs" % (st.sum(), 2 * bh.nnzCt / st.sum() / 1e6))
 print("   ", {k: round(v, 3) for k, v in acc.items() if v > 0.01})
+print("    rows / products / nnz of the kernels over 0.2 ms:", {k: v for k, v in info.items() if acc[k] > 0.2})
