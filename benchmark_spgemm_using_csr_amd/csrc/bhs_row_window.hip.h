@@ -365,4 +365,250 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
 #endif
 }
 
+// ===========================================================================
+// The long rows (more than 8 k entries of C) the same way, 256 lanes per row: where a multiply has thousands of them (the
+// R-MAT graph: 14 k rows, 232 M products) four rows per CU in flight beat k_row_bitmap_lds's one.  A lane owns ONE
+// 8-word group of the window's bitmap (no swizzle needed: the lanes' 32-byte pieces are consecutive), the ranks come
+// from a block scan, the staging arrays hold 2048 entries, a window of up to 2048 products stays in registers.  Rows of A
+// beyond 512 entries and rows with more than 16 k products in one window go on to k_row_bitmap_lds.
+// ===========================================================================
+constexpr int kWgLanes = 256, kWgCap = 2048, kWgSpillA = 512, kWgSpillWin = 16384;
+
+constexpr size_t wg_window_smem()
+{
+    return (size_t)kWwWords * 4 + (size_t)(kWwWords / 8) * 12 + 2 * kWgLanes * sizeof(int) + kWgLanes * sizeof(acc_t) + (size_t)kWgCap * (sizeof(int) + sizeof(acc_t)) +
+           (8 + 4 * kWwMax) * sizeof(int);
+}
+
+__global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: three workgroups per CU; held to 128 it spills and gains nothing)
+
+    const int4* __restrict__ desc, int qn, const int* __restrict__ tab, const int* __restrict__ Aj, const value_t* __restrict__ Ax,
+    const int* __restrict__ Bp, const unsigned short* __restrict__ Bwin, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
+    int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket, int reverse, int4* __restrict__ spill)
+{
+    constexpr int L = kWgLanes, NW = L / 64, U = kWwU, CAP = kWgCap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    acc_t* vals = reinterpret_cast<acc_t*>(smemRaw);
+    acc_t* sAv = vals + CAP;                                       // A values of the chunk at hand
+    unsigned* bm = reinterpret_cast<unsigned*>(sAv + L);
+    int* rank8 = reinterpret_cast<int*>(bm + kWwWords);
+    uint2* sub8 = reinterpret_cast<uint2*>(rank8 + kWwWords / 8);
+    int* sIncl = reinterpret_cast<int*>(sub8 + kWwWords / 8);
+    int* sBase = sIncl + L;
+    int* cols = sBase + L;
+    int* misc = cols + CAP;                                        // [0] ticket, [1 .. NW] wave totals, then NW x kWwMax window sums
+    int* winSum = misc + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nWin = tab[0];
+    for (int i = tid; i < kWwWords / 4; i += L) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // inclusive scan over the workgroup; total = the sum
+    auto block_scan = [&](int v, int& total) {
+        int incl = wave_incl_scan_dpp(v);
+        if (lane == 63) misc[1 + wv] = incl;
+        __syncthreads();
+        int off = 0;
+        total = 0;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            const int x = misc[1 + t];
+            if (t < wv) off += x;
+            total += x;
+        }
+        __syncthreads();
+        return incl + off;
+    };
+
+    for (;;) {
+        if (tid == 0) misc[0] = atomicAdd(ticket, 1);
+        __syncthreads();
+        const int q = misc[0];
+        __syncthreads();
+        if (q >= qn) break;
+        const int4 d = desc[reverse ? qn - 1 - q : q];
+        const int a0 = d.y, a1 = d.z;
+        // products per window from the index (as in k_row_wave_window); rows of the wrong shape go on
+        int most = 0x7fffffff;
+        if (a1 - a0 <= kWgSpillA) {
+            unsigned pk[kWwStride / 2];
+            int len[kWwMax];
+#pragma unroll
+            for (int w = 0; w < kWwMax; ++w) len[w] = 0;
+            for (int ca = a0; ca < a1; ca += L) {
+                if (ca + tid < a1) {
+                    const unsigned* src = reinterpret_cast<const unsigned*>(Bwin + (size_t)Aj[ca + tid] * kWwStride);
+#pragma unroll
+                    for (int i = 0; i < kWwStride / 2; ++i) pk[i] = src[i];
+#pragma unroll
+                    for (int w = 0; w < kWwMax; ++w) {
+                        const unsigned lo = w & 1 ? pk[w / 2] >> 16 : pk[w / 2] & 0xFFFFu;
+                        const unsigned hi = (w + 1) & 1 ? pk[(w + 1) / 2] >> 16 : pk[(w + 1) / 2] & 0xFFFFu;
+                        len[w] += (int)(hi - lo);
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < kWwMax; ++w) {
+                const int sum = wave_sum_dpp(len[w]);
+                if (lane == 0) winSum[wv * kWwMax + w] = sum;
+            }
+            __syncthreads();
+            most = 0;
+            for (int w = 0; w < kWwMax; ++w) {
+                int sum = 0;
+#pragma unroll
+                for (int t = 0; t < NW; ++t) sum += winSum[t * kWwMax + w];
+                most = max(most, sum);
+            }
+        }
+        if (most > kWgSpillWin) {
+            if (tid == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
+            __syncthreads();                                       // (lane-0 work never next to the loop's back edge: see bhs_row_wg.hip.h)
+            continue;
+        }
+        long long base = (long long)d.w;
+        const bool single = a1 - a0 <= L;
+        const unsigned short* wptr = Bwin;
+        int rowB = 0, cur = 0, nxt = 0;
+        if (single) {
+            sAv[tid] = 0.0;
+            if (a0 + tid < a1) {
+                const int c = Aj[a0 + tid];
+                wptr = Bwin + (size_t)c * kWwStride;
+                rowB = Bp[c];
+                sAv[tid] = (acc_t)Ax[a0 + tid];
+                nxt = wptr[1];
+            }
+        }
+        for (int w = 0; w < nWin; ++w) {
+            const int colBase = tab[1 + w];
+            int total = 0, rowTotal = 0;
+            int kc[U], ke[U];
+            acc_t kv[U];
+            const int sb0 = rowB + cur, slen = nxt - cur;
+            cur = nxt;
+            if (single && a0 + tid < a1 && w + 2 <= nWin) nxt = wptr[w + 2];
+            auto stage_chunk = [&](int ca) {
+                int b0 = sb0, len = slen;
+                if (!single) {
+                    b0 = len = 0;
+                    acc_t a = 0.0;
+                    if (ca + tid < a1) {
+                        const int c = Aj[ca + tid];
+                        const unsigned short* src = Bwin + (size_t)c * kWwStride + w;
+                        b0 = Bp[c] + src[0];
+                        len = (int)src[1] - (int)src[0];
+                        a = (acc_t)Ax[ca + tid];
+                    }
+                    sAv[tid] = a;
+                }
+                int tot;
+                const int incl = block_scan(len, tot);
+                sIncl[tid] = incl;
+                sBase[tid] = b0 - (incl - len);
+                __syncthreads();
+                return tot;
+            };
+            auto find = [&](int p) {                               // first entry j with sIncl[j] > p
+                int l = 0, r = L - 1;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
+                return l;
+            };
+            auto load_batch = [&](int p0, bool values) {
+                long long idx[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * L + tid;
+                    ke[u] = p < total ? find(p) : 0;
+                    idx[u] = (long long)sBase[ke[u]] + p;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool on = p0 + u * L + tid < total;
+                    kc[u] = on ? Bj[idx[u]] - colBase : -1;
+                    kv[u] = on && values ? (acc_t)Bx[idx[u]] : (acc_t)0;
+                }
+                if (values) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kv[u] *= sAv[ke[u]];
+                }
+            };
+            // ---- pass 1: occupancy bits
+            for (int ca = a0; ca < a1; ca += L) {
+                total = stage_chunk(ca);
+                rowTotal += total;
+                for (int p0 = 0; p0 < total; p0 += L * U) {
+                    load_batch(p0, single && total <= L * U);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (kc[u] >= 0) atomicOr(&bm[kc[u] >> 5], 1u << (kc[u] & 31));
+                }
+                __syncthreads();
+            }
+            if (rowTotal == 0) continue;                           // (uniform: every lane has the same totals)
+            const bool kept = single && rowTotal <= L * U;
+            // ---- a lane's group: its words' offsets, its total; ranks by a block scan
+            int mine;
+            {
+                const uint4 lo = *reinterpret_cast<const uint4*>(&bm[tid * 8]);
+                const uint4 hi = *reinterpret_cast<const uint4*>(&bm[tid * 8 + 4]);
+                const int c0 = __popc(lo.x), c1 = c0 + __popc(lo.y), c2 = c1 + __popc(lo.z), c3 = c2 + __popc(lo.w);
+                const int c4 = c3 + __popc(hi.x), c5 = c4 + __popc(hi.y), c6 = c5 + __popc(hi.z);
+                mine = c6 + __popc(hi.w);
+                sub8[tid] = make_uint2((unsigned)(c0 << 8 | c1 << 16 | c2 << 24), (unsigned)(c3 | c4 << 8 | c5 << 16 | c6 << 24));
+            }
+            int winCount;
+            const int incl = block_scan(mine, winCount);
+            rank8[tid] = incl - mine;
+            __syncthreads();
+            auto rank_of = [&](int c) {
+                const int wd = c >> 5, grp = wd >> 3, k = wd & 7;
+                const uint2 sb = sub8[grp];
+                const unsigned word = bm[wd];
+                const unsigned off = ((k & 4 ? sb.y : sb.x) >> ((k & 3) * 8)) & 255u;
+                return rank8[grp] + (int)off + __popc(word & ((1u << (c & 31)) - 1u));
+            };
+            for (int r0 = 0; r0 < winCount; r0 += CAP) {
+                const int nr = min(CAP, winCount - r0);
+                for (int i = tid; i < nr; i += L) vals[i] = 0.0;
+                __syncthreads();
+                auto add = [&](int c, acc_t v) {
+                    const int pos = rank_of(c) - r0;
+                    if ((unsigned)pos < (unsigned)CAP) {
+                        cols[pos] = colBase + c;
+                        unsafeAtomicAdd(&vals[pos], v);
+                    }
+                };
+                if (kept) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (kc[u] >= 0) add(kc[u], kv[u]);
+                } else {
+                    for (int ca = a0; ca < a1; ca += L) {
+                        total = stage_chunk(ca);
+                        for (int p0 = 0; p0 < total; p0 += L * U) {
+                            load_batch(p0, true);
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+                                if (kc[u] >= 0) add(kc[u], kv[u]);
+                        }
+                        __syncthreads();
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < nr; i += L) {
+                    Cj[base + r0 + i] = cols[i];
+                    Cx[base + r0 + i] = (value_t)vals[i];
+                }
+                __syncthreads();
+            }
+            base += winCount;
+            for (int i = tid; i < kWwWords / 4; i += L) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace bhs

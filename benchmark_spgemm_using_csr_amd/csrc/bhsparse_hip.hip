@@ -241,7 +241,7 @@ struct bhs_handle {
         bool numDirectFull = false;
         int rangesRun = 0;
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
-        long long midRows = 0;           // rows of the numeric bins between the hash tables and the long rows
+        long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
     } ps;
     // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
     int* extCj = nullptr;
@@ -558,21 +558,24 @@ int ensure_b_windows(bhs_handle* h)
 }
 
 // one wave per row, windows of 2^16 columns: the numeric bins between the hash tables and the long rows
-int launch_row_wave_window(bhs_handle* h, const int4* queue, int qn, int* Cp, int reverse = 0)
+template <bool WG>   // false: one wave per row (k_row_wave_window); true: 256 lanes per row (k_row_wg_window, the long rows)
+int launch_row_window(bhs_handle* h, const int4* queue, int qn, int* Cp, int reverse = 0)
 {
-    auto kern = k_row_wave_window;
+    auto kern = WG ? k_row_wg_window : k_row_wave_window;
+    const int block = WG ? kWgLanes : 64;
+    const size_t smem = WG ? wg_window_smem() : wave_window_smem();
     int perCU = 1;
-    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, wave_window_smem(), &perCU));
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), block, smem, &perCU));
     perCU = std::max(1, std::min(perCU, 32));
     const long long grid = std::max<long long>(1, std::min<long long>(qn, (long long)h->numCU * perCU));
     int* small = (int*)h->small.p;
-    // the rows it hands on (long rows of A): a list of its own per launch -- the bins run side by side -- then
-    // k_row_bitmap_lds on that list, its length read on the device
+    // the rows it hands on (long rows of A, rows crowded into one window): a list of its own per launch -- the bins run
+    // side by side -- then k_row_bitmap_lds on that list, its length read on the device
     BHS_TRY(ensure(h, h->bWinSpill, ((size_t)std::max(h->m, 1) + 2 * kMaxBins + 2) * sizeof(int4)));
     int4* spill = (int4*)h->bWinSpill.p + (queue - (const int4*)h->queue.p) + 2 * (h->ticketSlot - S_TICKETS + 1);
     BHS_HIP(hipMemsetAsync(spill, 0, sizeof(int4), h->ls));
     BHS_HIP(hipMemsetAsync(small + h->ticketSlot, 0, sizeof(int), h->ls));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), wave_window_smem(), h->ls, queue, qn, (const int*)h->bWinTab.p + kWwBuckets, h->dAj, h->dAx,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), smem, h->ls, queue, qn, (const int*)h->bWinTab.p + kWwBuckets, h->dAj, h->dAx,
                        h->dBp, (const unsigned short*)h->bWin.p, h->dBj, h->dBx, out_cj(h), out_cx(h), small + h->ticketSlot, reverse, spill);
     BHS_HIP(hipGetLastError());
     return launch_row_bitmap_lds<true>(h, spill + 1, h->numCU, Cp, 0, (const int*)spill);
@@ -841,15 +844,18 @@ bool bin_takes_lds_bitmap(const bhs_handle* h, const KernelCfg& c)
 template <bool NUM>
 bool bin_takes_wave_window(const bhs_handle* h, const KernelCfg& c)
 {
-    return NUM && !c.win && bin_takes_lds_bitmap<NUM>(h, c) && h->useWindowBitmap && h->bSorted && h->maxRowB < 65536 &&
-           (long long)h->n <= ((long long)kWwBuckets << kWwBucketLog2) && (h->useWindowBitmap >= 2 || h->ps.midRows >= 32LL * h->numCU);
+    if (!(NUM && bin_takes_lds_bitmap<NUM>(h, c) && h->useWindowBitmap && h->bSorted && h->maxRowB < 65536 &&
+          (long long)h->n <= ((long long)kWwBuckets << kWwBucketLog2)))
+        return false;
+    if (c.win) return h->useWindowBitmap >= 2 || h->ps.longRows >= 16LL * h->numCU;   // (256 lanes per row: k_row_wg_window)
+    return h->useWindowBitmap >= 2 || h->ps.midRows >= 32LL * h->numCU;
 }
 
 template <bool NUM>
 int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, int* CpOrCnt, int reverse = 0)
 {
     if (c.block == 16) return launch_row_quad<NUM>(h, queue, qn, CpOrCnt);
-    if (queue != nullptr && bin_takes_wave_window<NUM>(h, c)) return launch_row_wave_window(h, queue, qn, CpOrCnt, reverse);
+    if (queue != nullptr && bin_takes_wave_window<NUM>(h, c)) return c.win ? launch_row_window<true>(h, queue, qn, CpOrCnt, reverse) : launch_row_window<false>(h, queue, qn, CpOrCnt, reverse);
     if (bin_takes_lds_bitmap<NUM>(h, c)) return launch_row_bitmap_lds<NUM>(h, queue, qn, CpOrCnt, reverse);
     if (c.win && h->useSpa && h->maxTableLog2 >= 15 && h->spaSlots > 0) return launch_row_spa<NUM>(h, queue, qn, CpOrCnt);
     const int lg = std::min(c.log2ts, h->maxTableLog2);
@@ -1582,9 +1588,9 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     if (full) h->ps.numDirectFull = numDirect;
     h->ps.rangesRun++;
     const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
-    h->ps.midRows = 0;
+    h->ps.midRows = h->ps.longRows = 0;
     for (int b = 2; b < kNumNumBins; ++b)
-        if (!kNumCfg[b].win && bin_takes_lds_bitmap<true>(h, kNumCfg[b])) h->ps.midRows += numCount[b];
+        if (bin_takes_lds_bitmap<true>(h, kNumCfg[b])) (kNumCfg[b].win ? h->ps.longRows : h->ps.midRows) += numCount[b];
     for (int b = 2; b < kNumNumBins; ++b)
         if (numCount[b] && numQueue && bin_takes_wave_window<true>(h, kNumCfg[b])) BHS_TRY(ensure_b_windows(h));
     BHS_TRY(fork_bins(h, numCount, kNumNumBins));
@@ -1613,7 +1619,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // only take CUs from each other, and the shorter bins' launch would trail behind) go as ONE queue, taken
         // from its end so that the longest rows start first.
         int lo = b, rows = numCount[b];
-        auto kernel_of = [&](int bb) { return !bin_takes_lds_bitmap<true>(h, kNumCfg[bb]) ? 0 : bin_takes_wave_window<true>(h, kNumCfg[bb]) ? 2 : 1; };
+        auto kernel_of = [&](int bb) { return !bin_takes_lds_bitmap<true>(h, kNumCfg[bb]) ? 0 : bin_takes_wave_window<true>(h, kNumCfg[bb]) ? (kNumCfg[bb].win ? 3 : 2) : 1; };
         if (numQueue && h->mergeBitmapBins && kernel_of(b))
             while (lo - 1 >= 2 && kernel_of(lo - 1) == kernel_of(b)) { --lo; rows += numCount[lo]; }
         bin_stream(h, b);
