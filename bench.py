@@ -584,8 +584,12 @@ def main():
         bh.free_mem()
         del Ap, Aj, Ax, Bp, Bj, Bx
         torch.cuda.empty_cache()
-        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40", "weblike_1m"):
-            if wname == "weblike_1m":   # stand-in for configs[3] (SuiteSparse webbase-1M is not in the image): same size, compression 1.35
+        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40", "weblike_1m", "rmat_s20"):
+            if wname == "rmat_s20":     # a social-network graph (R-MAT, 2^20 rows): rows of C of thousands of entries by the ten thousand (bhs_row_window.hip.h)
+                st2, d2 = "R-MAT graph (gallery.rmat_csr)", (1 << 20,)
+                rpw, colw = gallery.rmat_csr()
+                bp2, bj2 = torch.from_numpy(np.asarray(rpw)).to(dev), torch.from_numpy(np.asarray(colw)).to(dev)
+            elif wname == "weblike_1m":   # stand-in for configs[3] (SuiteSparse webbase-1M is not in the image): same size, compression 1.35
                 st2, d2 = "web-like power-law (gallery.weblike_csr)", (1000005,)
                 rpw, colw = gallery.weblike_csr()
                 bp2, bj2 = torch.from_numpy(rpw).to(dev), torch.from_numpy(colw).to(dev)

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: th
         }
         if (most > kWgSpillWin) {
             if (tid == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
-            __syncthreads();                                       // (lane-0 work never next to the loop's back edge: see bhs_row_wg.hip.h)
+            __syncthreads();                                       // (lane-0 work never next to the loop's back edge: see the end of the loop)
             continue;
         }
         long long base = (long long)d.w;
@@ -607,6 +607,10 @@ __global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: th
             for (int i = tid; i < kWwWords / 4; i += L) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
         }
+        // (A barrier between whatever lane 0 does alone at the end of a row and its ticket draw at the top of the next:
+        // without one hipcc folds the two into ONE divergent region around the loop's back edge -- lane 0 in an outer
+        // loop, everyone else in an inner one that meets the ticket's barriers again before lane 0 has drawn, and the
+        // workgroup takes its row forever.  Seen in this kernel's first form; `llvm-objdump` shows the two loop nests.)
         __syncthreads();
     }
 }

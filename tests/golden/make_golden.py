@@ -113,13 +113,16 @@ def full_size():
     sums = json.load(open(path))
     for tag, name, dims in (("p5_1024", "poisson5pt", (1024, 1024, 1)), ("p27_128", "poisson27pt", (128, 128, 128)),
                             ("powerlaw_1m", "powerlaw", (1000005, 3105536, 4700)),
-                            ("weblike_1m", "weblike", (1000005,)), ("fem3_40", "fem3", (40, 40, 40))):
+                            ("weblike_1m", "weblike", (1000005,)), ("fem3_40", "fem3", (40, 40, 40)),
+                            ("rmat_s20", "rmat", (1 << 20,))):
         if tag in sums and "--force" not in sys.argv:
             continue
         if name == "powerlaw":        # stand-in for configs[3] (webbase-1M: the SuiteSparse file is not in the image)
             rp, col = gallery.powerlaw_csr(dims[0], dims[0], dims[1], dims[2])
         elif name == "weblike":       # the stand-in with webbase-1M's compression (nnzCt / nnzC = 1.35; published 1.36)
             rp, col = gallery.weblike_csr(dims[0])
+        elif name == "rmat":          # R-MAT graph, 2^20 rows: the rows the column-window kernels are for
+            rp, col = gallery.rmat_csr()
         elif name == "fem3":          # poisson27pt (x) ones(3, 3): 3 unknowns per node
             rp, col = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", *dims), 3)
         else:

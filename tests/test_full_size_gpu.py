@@ -24,7 +24,8 @@ pytestmark = pytest.mark.gpu
 CASES = {"p5_1024": ("poisson5pt", (1024, 1024, 1)), "p27_128": ("poisson27pt", (128, 128, 128)),
          "powerlaw_1m": ("powerlaw", (1000005, 3105536, 4700)),   # round 1-3 stand-in for configs[3]: hub-heavy, compression 1.007
          "weblike_1m": ("weblike", (1000005,)),                   # stand-in for configs[3] (webbase-1M, file absent) with its compression: 1.35
-         "fem3_40": ("fem3", (40, 40, 40))}                       # poisson27pt (x) ones(3, 3): the big-class kernels
+         "fem3_40": ("fem3", (40, 40, 40)),                       # poisson27pt (x) ones(3, 3): the big-class kernels
+         "rmat_s20": ("rmat", (1 << 20,))}                        # R-MAT graph: 52 k rows of 2 k .. 150 k entries -- the column-window kernels (bhs_row_window.hip.h)
 
 
 def _spmv(rp, col, val, x):
@@ -41,7 +42,7 @@ def _spmv(rp, col, val, x):
 REF_AT_FULL_SIZE = ("p5_1024", "p27_128", "weblike_1m", "fem3_40")
 
 
-@pytest.mark.parametrize("tag", ["p5_1024", "p27_128", "powerlaw_1m", "weblike_1m", "fem3_40"])
+@pytest.mark.parametrize("tag", ["p5_1024", "p27_128", "powerlaw_1m", "weblike_1m", "fem3_40", "rmat_s20"])
 def test_full_size_digests_and_properties(hiplib, tag):
     import torch
     from benchmark_spgemm_using_csr_amd import gallery, facade
@@ -60,6 +61,9 @@ def test_full_size_digests_and_properties(hiplib, tag):
     elif stencil == "fem3":
         rp, col = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", *dims), 3)
         Bp, Bj = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    elif stencil == "rmat":
+        rp, col = gallery.rmat_csr()
+        Bp, Bj = torch.from_numpy(np.asarray(rp)).to(dev), torch.from_numpy(np.asarray(col)).to(dev)
     else:
         Bp, Bj = gallery.poisson_csr_torch(stencil, *dims, device=dev)
     Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
@@ -72,6 +76,8 @@ def test_full_size_digests_and_properties(hiplib, tag):
     assert bh.initPlatform(plats) == 0
     assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
     assert bh.spgemm() == 0
+    if stencil == "rmat":                                    # (the multiply has enough such rows for the window kernels to be chosen)
+        assert "b_windows" in [s["name"] for s in bh.kernel_stats()]
     nnzC = bh.get_nnzC()
     N = dims[0]
     closed = {"poisson27pt": (5 * N - 6) ** 3, "poisson5pt": 13 * N * N - 20 * N + 4}.get(stencil, ref["nnzC"])
