@@ -328,7 +328,7 @@ constexpr int kLineWindow = 4096, kLineMax = 512;                  // rows compa
 __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj, int* __restrict__ out,
                                                    int* __restrict__ local = nullptr, int ncols = 0, int* __restrict__ line = nullptr)
 {
-    __shared__ unsigned char changed[kLineWindow + kLineMax];
+    __shared__ unsigned changed[(kLineWindow + kLineMax) / 32 + 2];
     const int lane = threadIdx.x, smp = lane >> 3, d = (lane & 7) + 1;
     const long long row = (long long)(smp + 1) * nrows / 9;
     bool same = row - d >= 0 && row < nrows;
@@ -371,22 +371,38 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
         const long long first = (long long)nrows / 2;
         int found = 0;
         if (first >= 1 && first + kLineWindow + kLineMax < nrows) {
+            // one bit per row of the window: its length differs from the row before it
             int changes = 0;
-            for (int i = lane; i < kLineWindow + kLineMax; i += 64) {
-                const int a = Rp[first + i - 1], b = Rp[first + i], c = Rp[first + i + 1];
-                changed[i] = (unsigned char)(c - b != b - a);
-                changes += i < kLineWindow && c - b != b - a;
-            }
+            for (int i0 = 0; i0 < kLineWindow + kLineMax; i0 += 64 * 8) {     // (eight steps' loads in flight at once)
+                int a[8], b[8], c[8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) changes += __shfl_xor(changes, o, 64);
+                for (int u = 0; u < 8; ++u) {
+                    const long long i = first + i0 + u * 64 + lane;
+                    a[u] = Rp[i - 1]; b[u] = Rp[i]; c[u] = Rp[i + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j0 = i0 + u * 64;
+                    const unsigned long long m = __ballot(c[u] - b[u] != b[u] - a[u]);
+                    if (lane == 0) { changed[j0 >> 5] = (unsigned)m; changed[(j0 >> 5) + 1] = (unsigned)(m >> 32); }
+                    if (j0 < kLineWindow) changes += __popcll(m);
+                }
+            }
+            if (lane == 0) changed[(kLineWindow + kLineMax) >> 5] = 0u;
             __syncthreads();
             // lane l tries the lengths 16 + l, 16 + 64 + l, ...: the smallest that fits all but an eighth of the changes (a
-            // wrong length misses nearly all of them; the right one a few where the window crosses from plane to plane)
+            // wrong length misses nearly all of them; the right one a few where the window crosses from plane to plane).
+            // 32 rows per step: the window's bits against the same bits P rows on.
             const int allowed = changes / 8;
             found = 0x7fffffff;
             for (int P = 16 + lane; changes > 0 && P <= kLineMax; P += 64) {
+                const int ws = P >> 5, sh = P & 31;
                 int miss = 0;
-                for (int i = 0; miss <= allowed && i < kLineWindow; ++i) miss += changed[i] != changed[i + P];
+                for (int w = 0; w < kLineWindow / 32 && miss <= allowed; ++w) {
+                    const unsigned lo = changed[w + ws], hi = changed[w + ws + 1];
+                    const unsigned there = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                    miss += __popc(changed[w] ^ there);
+                }
                 if (miss <= allowed) { found = P; break; }
             }
 #pragma unroll
