@@ -779,6 +779,31 @@ def test_wave_per_row_column_windows(oracle, n):
     # (by default a multiply with so few such rows leaves them with k_row_bitmap_lds)
     _, _, _, info1 = _check(oracle, len(rowsA), k, n, A, B, options={"class_path": 0})
     assert "b_windows" not in [kk["name"] for kk in info1["kernels"]]
+    # the numeric half in row ranges (what the multi-GPU layer does): the index of B is built once per multiply, every
+    # range has its own spill lists
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dA, dB = (t(Ap), t(Aj), t(Ax)), (t(Bp), t(Bj), t(Bx))
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.set_option("class_path", 0) == 0 and bh.set_option("window_bitmap", 2) == 0
+    m = len(rowsA)
+    assert bh.initData_device(m, k, n, len(Aj), dA[2], dA[0], dA[1], len(Bj), dB[2], dB[0], dB[1]) == 0
+    L, h = bh._lib, bh._h
+    ct, cc = C.c_int64(0), C.c_int(0)
+    assert L.bhs_spgemm_symbolic(h, C.byref(ct), C.byref(cc)) == 0 and cc.value == Cp[-1]
+    cuts = [0, m // 3, m // 3 + 7, m]
+    for s3 in (2, 0, 1):
+        assert L.bhs_spgemm_numeric(h, cuts[s3], cuts[s3 + 1]) == 0
+    assert L.bhs_spgemm_finish(h, None) == 0
+    Cj3 = np.empty(cc.value, np.int32); Cx3 = np.empty(cc.value, np.float64)
+    assert bh.get_C(Cj3, Cx3) == 0
+    assert np.array_equal(Cj3, Cj) and np.array_equal(Cx3, Cx)
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
 def test_huge_column_space():
