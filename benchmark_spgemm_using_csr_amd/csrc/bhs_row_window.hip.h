@@ -37,7 +37,8 @@ constexpr int kWwWords = 1 << (kWwLog2 - 5);                       // 2048 bitma
 constexpr int kWwBucketLog2 = 12;                                  // window boundaries are multiples of 4096 columns
 constexpr int kWwBuckets = 256;                                    // ... so at most 2^20 columns
 constexpr int kWwMax = 32;                                         // most windows: 15 cuts by share of B's entries + 16 by width
-constexpr int kWwU = 8;                                            // products per lane and batch
+constexpr int kWwU = 4;                                            // products per lane and batch (one wave per row)
+constexpr int kWgU = 8;                                            // ... (256 lanes per row)
 constexpr int kWwCap = 384;                                        // entries of C staged per round
 constexpr int kWwSpillA = 128;                                     // longest row of A this kernel keeps
 constexpr int kWwSpillWin = 2048;                                  // most products of one window it keeps
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
         // whole B rows, through the spill list.
         if (a1 - a0 > kWwSpillA) {
             if (lane == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
+            wave_sync();                                           // (lane-0 work never next to the loop's back edge: see the end of the loop)
             continue;
         }
         // ... and so does a row whose products crowd into one window (a web graph's rows: neighbouring pages): thousands
@@ -195,12 +197,13 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
             for (int w = 0; w < kWwMax; ++w) most = max(most, wave_sum_dpp(len[w]));
             if (most > kWwSpillWin) {
                 if (lane == 0) spill[1 + atomicAdd(&spill[0].x, 1)] = d;
+                wave_sync();
                 continue;
             }
         }
         long long base = (long long)d.w;                           // where the window at hand begins in the row of C
         // a row of A of at most 64 entries (nearly all of them) is read once: a lane keeps its entry's value and walks the
-        // window starts of its B row one load ahead of the window at hand -- no round trip per window but the products'
+        // window starts of its B row one load ahead of the window at hand
         const bool single = a1 - a0 <= 64;
         acc_t av = 0.0;                                            // this lane's A value of the chunk at hand
         const unsigned short* wptr = Bwin;
@@ -213,42 +216,73 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
             nxt = wptr[1];
         }
         BHS_TICK_WW(0);
-        for (int w = 0; w < nWin; ++w) {
+        // the window's pieces of 64 B rows -> a flat product space (sIncl / sBase); returns its size
+        auto stage_chunk = [&](int w, int ca, int sb0, int slen) {
+            int b0 = sb0, len = slen;
+            if (!single) {
+                b0 = len = 0;
+                av = 0.0;
+                if (ca + lane < a1) {
+                    const int c = Aj[ca + lane];
+                    const unsigned short* src = Bwin + (size_t)c * kWwStride + w;
+                    b0 = Bp[c] + src[0];
+                    len = (int)src[1] - (int)src[0];
+                    av = (acc_t)Ax[ca + lane];
+                }
+            }
+            const int incl = wave_incl_scan_dpp(len);
+            sIncl[lane] = incl;
+            sBase[lane] = b0 - (incl - len);
+            wave_sync();
+            return __builtin_amdgcn_readlane(incl, 63);
+        };
+        auto find = [&](int p) {                                   // first entry j with sIncl[j] > p
+            int l = 0, r = 63;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
+            return l;
+        };
+        // A window of a single-chunk row with at most 64 * UP products is worked on in two halves, and the second half of
+        // window w runs AFTER the first half of window w + 1: `issue` finds the products and requests their columns and B
+        // values -- no branch around the loads, so that the wait for this set's data is a count, not a drain -- and `finish`,
+        // one window later, finds them arrived.  (Phase timers of the form without this: 65 % of the kernel between the
+        // request and the data.)
+        constexpr int UP = 4;
+        struct WinSet { int w, sb0, slen, total; int kc[UP], ke[UP]; acc_t kv[UP]; };
+        auto issue = [&](WinSet& S, int w) {                       // (w >= nWin: an empty window -- the loop below never branches around an issue)
+            S.w = w;
+            S.sb0 = rowB + cur;
+            S.slen = w < nWin ? nxt - cur : 0;
+            cur = nxt;
+            {
+                const int t = wptr[min(w + 2, kWwMax + 1)];        // (the index repeats the row's length to its end)
+                if (a0 + lane < a1) nxt = t;
+            }
+            S.total = stage_chunk(w, a0, S.sb0, S.slen);
+            long long idx[UP];
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int p = u * 64 + lane;
+                S.ke[u] = p < S.total ? find(p) : 0;
+                idx[u] = p < S.total ? (long long)sBase[S.ke[u]] + p : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int c = Bj[idx[u]];
+                S.kv[u] = (acc_t)Bx[idx[u]];
+                S.kc[u] = u * 64 + lane < S.total ? c : -1;
+            }
+            wave_sync();
+        };
+        auto finish = [&](WinSet& S) {
+            const int w = S.w;
+            if (w >= nWin) return;
             const int colBase = tab[1 + w], words = (tab[2 + w] - colBase + 31) >> 5;   // (wave-uniform: scalar loads)
-            int total = 0, rowTotal = 0;
-            // products of the last batch, kept for pass 2 when the window has one chunk and one batch
+            const bool kept = single && S.total <= 64 * UP;
             int kc[U], ke[U];
             acc_t kv[U];
-            const int sb0 = rowB + cur, slen = nxt - cur;          // (single) this lane's piece of the window
-            cur = nxt;
-            if (single && a0 + lane < a1 && w + 2 <= nWin) nxt = wptr[w + 2];
-            // the window's pieces of 64 B rows -> a flat product space (sIncl / sBase); returns its size
-            auto stage_chunk = [&](int ca) {
-                int b0 = sb0, len = slen;
-                if (!single) {
-                    b0 = len = 0;
-                    av = 0.0;
-                    if (ca + lane < a1) {
-                        const int c = Aj[ca + lane];
-                        const unsigned short* src = Bwin + (size_t)c * kWwStride + w;
-                        b0 = Bp[c] + src[0];
-                        len = (int)src[1] - (int)src[0];
-                        av = (acc_t)Ax[ca + lane];
-                    }
-                }
-                const int incl = wave_incl_scan_dpp(len);
-                sIncl[lane] = incl;
-                sBase[lane] = b0 - (incl - len);
-                wave_sync();
-                return __builtin_amdgcn_readlane(incl, 63);
-            };
-            auto find = [&](int p) {                               // first entry j with sIncl[j] > p
-                int l = 0, r = 63;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { const int mid = (l + r) >> 1; if (sIncl[mid] > p) r = mid; else l = mid + 1; }
-                return l;
-            };
-            // one batch of the chunk's products: column within the window (-1: none), A entry within the chunk, A value x B value
+            int total = 0, rowTotal = 0;
+            // one batch of a chunk's products (the windows that are not kept): column within the window (-1: none), A value x B value
             auto load_batch = [&](int p0, bool values) {
                 long long idx[U];
 #pragma unroll
@@ -269,20 +303,32 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
                 }
             };
             // ---- pass 1: occupancy bits
-            for (int ca = a0; ca < a1; ca += 64) {
-                total = stage_chunk(ca);
-                rowTotal += total;
-                for (int p0 = 0; p0 < total; p0 += 64 * U) {
-                    load_batch(p0, single && total <= 64 * U);     // (values only if they stay in registers for pass 2)
+            if (kept) {
+                rowTotal = S.total;
+                if (rowTotal == 0) return;
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (kc[u] >= 0) atomicOr(&bm[ww_phys(kc[u] >> 5)], 1u << (kc[u] & 31));
+                for (int u = 0; u < UP; ++u) {
+                    S.kv[u] *= __shfl(av, S.ke[u], 64);
+                    if (S.kc[u] >= 0) {
+                        S.kc[u] -= colBase;
+                        atomicOr(&bm[ww_phys(S.kc[u] >> 5)], 1u << (S.kc[u] & 31));
+                    }
                 }
-                wave_sync();                                       // (the next chunk overwrites sIncl / sBase)
+            } else {
+                for (int ca = a0; ca < a1; ca += 64) {
+                    total = stage_chunk(w, ca, S.sb0, S.slen);
+                    rowTotal += total;
+                    for (int p0 = 0; p0 < total; p0 += 64 * U) {
+                        load_batch(p0, false);
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (kc[u] >= 0) atomicOr(&bm[ww_phys(kc[u] >> 5)], 1u << (kc[u] & 31));
+                    }
+                    wave_sync();                                   // (the next chunk overwrites sIncl / sBase)
+                }
+                if (rowTotal == 0) return;
             }
             BHS_TICK_WW(1);
-            if (rowTotal == 0) continue;
-            const bool kept = single && rowTotal <= 64 * U;
             // ---- the lanes' totals, their ranks, the rank of every 8-word group and of every word within it
             const int blk = lane * 32, rot = lane & 3;
             int cnt4[4] = {0, 0, 0, 0}, mine = 0;
@@ -328,11 +374,11 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
                 if (BHS_WW_LAB & 2) {
                 } else if (kept) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (kc[u] >= 0) add(kc[u], kv[u]);
+                    for (int u = 0; u < UP; ++u)
+                        if (S.kc[u] >= 0) add(S.kc[u], S.kv[u]);
                 } else {
                     for (int ca = a0; ca < a1; ca += 64) {
-                        total = stage_chunk(ca);
+                        total = stage_chunk(w, ca, S.sb0, S.slen);
                         for (int p0 = 0; p0 < total; p0 += 64 * U) {
                             load_batch(p0, true);
 #pragma unroll
@@ -358,7 +404,27 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
             for (int i = lane; i * 4 < ((words + 31) & ~31); i += 64) reinterpret_cast<uint4*>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);   // (whole blocks: the words are swizzled within them)
             wave_sync();
             BHS_TICK_WW(6);
+        };
+        WinSet A, B;
+        if (single) {
+            issue(A, 0);
+            for (int w = 0; w < nWin; w += 2) {
+                issue(B, w + 1);
+                finish(A);
+                issue(A, w + 2);
+                finish(B);
+            }
+        } else {
+            for (int w = 0; w < nWin; ++w) {
+                A.w = w; A.sb0 = 0; A.slen = 0; A.total = 0x7fffffff;
+                finish(A);
+            }
         }
+        // (A convergent operation between whatever lane 0 does alone at the end of a row -- the hand-over above -- and its
+        // ticket draw at the top of the next: without one hipcc folds the two into ONE divergent region around the loop's
+        // back edge, lane 0 in an outer loop and the other 63 in an inner one where readfirstlane finds the ticket of a
+        // lane that never drew: the wave takes row 0 forever.  Seen twice in this file; the ISA shows the two loop nests.)
+        wave_sync();
     }
 #if BHS_PHASES_SPA
     if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_phase_cycles[i], phw[i]);
@@ -386,7 +452,7 @@ __global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: th
     const int* __restrict__ Bp, const unsigned short* __restrict__ Bwin, const int* __restrict__ Bj, const value_t* __restrict__ Bx,
     int* __restrict__ Cj, value_t* __restrict__ Cx, int* __restrict__ ticket, int reverse, int4* __restrict__ spill)
 {
-    constexpr int L = kWgLanes, NW = L / 64, U = kWwU, CAP = kWgCap;
+    constexpr int L = kWgLanes, NW = L / 64, U = kWgU, CAP = kWgCap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     acc_t* vals = reinterpret_cast<acc_t*>(smemRaw);
     acc_t* sAv = vals + CAP;                                       // A values of the chunk at hand
