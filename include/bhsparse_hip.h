@@ -188,6 +188,12 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *   "lds_bitmap"      0: keep the long-row bitmap in HBM even when the matrix has <= 2^20 columns
  *   "lds_bitmap_min_log2"  numeric workgroup bins with tables of at least 2^v slots go to the LDS bitmap
  *                     kernel when n <= 2^20 (default 12; 99: only rows beyond every table)
+ *   "window_bitmap"   rows of thousands of entries of C column window by column window, a wave (2 k .. 8 k entries) or 256
+ *                     lanes (beyond) per row, several rows per CU (bhs_row_window.hip.h): 1 (default) when the multiply has
+ *                     >= 32 resp. >= 16 such rows per CU, 2 always, 0 never; needs ascending rows of B shorter than 2^16
+ *                     and n <= 2^20
+ *   "class_super_rows"  consecutive rows a wave of the class numeric kernel takes (0, default: a grid line of A where
+ *                     "line_a" found one, else 64)
  *   "small_b"         0: always 64-bit address arithmetic for colIndB / valB (default: 32-bit byte offsets when
  *                     nnz(B) < 2^29)
  *   "lane_first"      1 (default): when every row of A has <= 12 entries and every row of B <= 64 (stencils), the
@@ -248,6 +254,8 @@ BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
  *   "max_row_a", "max_row_b"   longest row of A / B
  *   "local_a"    1 when sampled rows of A keep their entries near the diagonal (mean |column - row| < columns / 16): the
  *                lane-per-row kernels are only chosen then
+ *   "line_a"     rows per grid line of A when the places where a row's length changes repeat with a fixed period and the
+ *                matrix is a whole number of such lines (a wave of the class numeric kernel then takes whole lines), else 0
  *   "compress_b_used"  1 when the symbolic pass of the general pipeline runs on B's pattern compressed to (column block,
  *                mask) pairs for this data set
  * Returns BHS_ERR_INVALID_ARG for unknown keys, BHS_ERR_NOT_READY without data.  */
