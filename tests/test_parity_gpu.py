@@ -804,6 +804,11 @@ def test_wave_per_row_column_windows(oracle, n):
     assert bh.get_C(Cj3, Cx3) == 0
     assert np.array_equal(Cj3, Cj) and np.array_equal(Cx3, Cx)
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
+    # the value_type float build (sums of small integers: exact in float too)
+    Cpf, Cjf, Cxf, infof = spgemm_csr(m, k, n, Ap, Aj, Ax.astype(np.float32), Bp, Bj, Bx.astype(np.float32),
+                                      options={"window_bitmap": 2, "class_path": 0}, value_dtype=np.float32)
+    assert "b_windows" in [kk["name"] for kk in infof["kernels"]]
+    assert np.array_equal(Cpf, Cp) and np.array_equal(Cjf, Cj) and np.array_equal(Cxf.astype(np.float64), Cx)
 
 
 def test_huge_column_space():
