@@ -149,7 +149,10 @@ struct bhs_handle {
     DevBuf hubBits, hubRank, hubItems, hubSeg, hubCtl;
     DevBuf bWinSpill;                    // k_row_wave_window's spill lists
     DevBuf bWin, bWinTab;                // where the column windows begin in every row of B, the windows themselves (k_b_windows16, k_window_pick): rebuilt by the multiplies that need them
-    int useWindowBitmap = 1;             // rows of 2 k .. 8 k entries one wave each, window by window (k_row_wave_window): 0 never, 1 if there are many, 2 always
+#ifndef BHS_WINDOW_DEFAULT
+#define BHS_WINDOW_DEFAULT 1                  // (a measurement build may force the window kernels on every multiply: 2)
+#endif
+    int useWindowBitmap = BHS_WINDOW_DEFAULT;             // rows of 2 k .. 8 k entries one wave each, window by window (k_row_wave_window): 0 never, 1 if there are many, 2 always
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
     int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
     int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
