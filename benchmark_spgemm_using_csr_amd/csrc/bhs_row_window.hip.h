@@ -39,7 +39,10 @@ constexpr int kWwBuckets = 256;                                    // ... so at 
 constexpr int kWwMax = 32;                                         // most windows: 15 cuts by share of B's entries + 16 by width
 constexpr int kWwU = 4;                                            // products per lane and batch (one wave per row)
 constexpr int kWgU = 8;                                            // ... (256 lanes per row)
-constexpr int kWwCap = 384;                                        // entries of C staged per round
+#ifndef BHS_WW_CAP
+#define BHS_WW_CAP 512                                             // (R-MAT, rows of 2 k .. 8 k entries: 256 1.61 ms, 384 1.58, 512 1.54, 640 1.68)
+#endif
+constexpr int kWwCap = BHS_WW_CAP;                                 // entries of C staged per round
 constexpr int kWwSpillA = 128;                                     // longest row of A this kernel keeps
 constexpr int kWwSpillWin = 2048;                                  // most products of one window it keeps
 constexpr int kWwStride = kWwMax + 2;                              // 16-bit offsets per row of B in the index (even: a row starts on a 4-byte boundary)
@@ -438,12 +441,17 @@ __global__ __launch_bounds__(64) void k_row_wave_window(
 // from a block scan, the staging arrays hold 2048 entries, a window of up to 2048 products stays in registers.  Rows of A
 // beyond 512 entries and rows with more than 16 k products in one window go on to k_row_bitmap_lds.
 // ===========================================================================
-constexpr int kWgLanes = 256, kWgCap = 2048, kWgSpillA = 512, kWgSpillWin = 16384;
+#ifndef BHS_WG_LANES
+#define BHS_WG_LANES 256
+#define BHS_WG_CAP 3072                                            // (2048: R-MAT's long rows 3.79 ms, 3072: 3.56, 1024: 4.33; 128 lanes: 4.8-5.3; 3 workgroups per CU either way)
+#endif
+constexpr int kWgLanes = BHS_WG_LANES, kWgCap = BHS_WG_CAP, kWgSpillA = 2 * BHS_WG_LANES, kWgSpillWin = 64 * BHS_WG_LANES;
 
+static_assert((kWwWords / 8) % kWgLanes == 0, "whole groups per lane");
 constexpr size_t wg_window_smem()
 {
     return (size_t)kWwWords * 4 + (size_t)(kWwWords / 8) * 12 + 2 * kWgLanes * sizeof(int) + kWgLanes * sizeof(acc_t) + (size_t)kWgCap * (sizeof(int) + sizeof(acc_t)) +
-           (8 + 4 * kWwMax) * sizeof(int);
+           (8 + (kWgLanes / 64) * kWwMax) * sizeof(int);
 }
 
 __global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: three workgroups per CU; held to 128 it spills and gains nothing)
@@ -614,19 +622,27 @@ __global__ __launch_bounds__(kWgLanes) void k_row_wg_window(   // (133 VGPRs: th
             }
             if (rowTotal == 0) continue;                           // (uniform: every lane has the same totals)
             const bool kept = single && rowTotal <= L * U;
-            // ---- a lane's group: its words' offsets, its total; ranks by a block scan
-            int mine;
-            {
-                const uint4 lo = *reinterpret_cast<const uint4*>(&bm[tid * 8]);
-                const uint4 hi = *reinterpret_cast<const uint4*>(&bm[tid * 8 + 4]);
+            // ---- a lane's groups (256 / L of them, consecutive): their words' offsets, the lane's total; ranks by a block scan
+            constexpr int GP = (kWwWords / 8) / L;
+            int mine = 0, cntG[GP];
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const int grp = tid * GP + g;
+                const uint4 lo = *reinterpret_cast<const uint4*>(&bm[grp * 8]);
+                const uint4 hi = *reinterpret_cast<const uint4*>(&bm[grp * 8 + 4]);
                 const int c0 = __popc(lo.x), c1 = c0 + __popc(lo.y), c2 = c1 + __popc(lo.z), c3 = c2 + __popc(lo.w);
                 const int c4 = c3 + __popc(hi.x), c5 = c4 + __popc(hi.y), c6 = c5 + __popc(hi.z);
-                mine = c6 + __popc(hi.w);
-                sub8[tid] = make_uint2((unsigned)(c0 << 8 | c1 << 16 | c2 << 24), (unsigned)(c3 | c4 << 8 | c5 << 16 | c6 << 24));
+                cntG[g] = c6 + __popc(hi.w);
+                sub8[grp] = make_uint2((unsigned)(c0 << 8 | c1 << 16 | c2 << 24), (unsigned)(c3 | c4 << 8 | c5 << 16 | c6 << 24));
+                mine += cntG[g];
             }
             int winCount;
             const int incl = block_scan(mine, winCount);
-            rank8[tid] = incl - mine;
+            {
+                int r = incl - mine;
+#pragma unroll
+                for (int g = 0; g < GP; ++g) { rank8[tid * GP + g] = r; r += cntG[g]; }
+            }
             __syncthreads();
             auto rank_of = [&](int c) {
                 const int wd = c >> 5, grp = wd >> 3, k = wd & 7;
