@@ -38,7 +38,10 @@ constexpr int kWwBucketLog2 = 12;                                  // window bou
 constexpr int kWwBuckets = 256;                                    // ... so at most 2^20 columns
 constexpr int kWwMax = 32;                                         // most windows: 15 cuts by share of B's entries + 16 by width
 constexpr int kWwU = 4;                                            // products per lane and batch (one wave per row)
-constexpr int kWgU = 8;                                            // ... (256 lanes per row)
+#ifndef BHS_WG_U
+#define BHS_WG_U 8
+#endif
+constexpr int kWgU = BHS_WG_U;                                     // ... (256 lanes per row)
 #ifndef BHS_WW_CAP
 #define BHS_WW_CAP 512                                             // (R-MAT, rows of 2 k .. 8 k entries: 256 1.61 ms, 384 1.58, 512 1.54, 640 1.68)
 #endif
