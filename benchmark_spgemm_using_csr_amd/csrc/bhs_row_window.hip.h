@@ -1,5 +1,6 @@
-// bhs_row_window.hip.h -- rows of a few thousand entries of C, one WAVE per row, column window by column window: the
-// bitmap accumulator of bhs_row_wg.hip.h with a bitmap of one window, the window's piece of the row put together in LDS.
+// bhs_row_window.hip.h -- rows of thousands of entries of C, one WAVE (k_row_wave_window) or 256 lanes (k_row_wg_window) per
+// row, column window by column window: the bitmap accumulator of bhs_row_wg.hip.h with a bitmap of one window, the window's
+// piece of the row put together in LDS.
 #pragma once
 
 namespace bhs {
@@ -18,7 +19,7 @@ namespace bhs {
 //
 // Here:
 //   * the columns are cut into WINDOWS of at most 2^16 columns (an 8 KB bitmap) and a wave walks its row window by
-//     window: no barrier anywhere, ten rows in flight per CU;
+//     window: no barrier anywhere, nine rows in flight per CU;
 //   * the windows hold about equal shares of B's entries, not equal shares of the columns (k_window_hist /
 //     k_window_pick: a graph's columns are anything but uniform -- with equal widths the first window of an R-MAT row
 //     held a third of it);
@@ -29,8 +30,9 @@ namespace bhs {
 //     stored group-swizzled so that the lanes' 16-byte reads spread over the banks); pass 2 adds every product to its
 //     entry's value IN LDS (ds_add_f64) and writes the entry's column beside it -- no sweep over the bitmap -- and both
 //     arrays leave 64 lanes wide.  A window with more entries than the staging arrays hold is done in rounds by rank;
-//   * a window of at most 512 products (nearly all of them) keeps columns and products of pass 1 in registers: pass 2
-//     neither searches nor loads.
+//   * a window of at most 256 products (most of them) is worked on in two halves, one window apart: its products are
+//     found and requested while the window before it is finished, and stay in registers -- pass 2 neither searches nor
+//     loads.
 // ===========================================================================
 constexpr int kWwLog2 = 16;                                        // most columns per window
 constexpr int kWwWords = 1 << (kWwLog2 - 5);                       // 2048 bitmap words
