@@ -5,8 +5,9 @@
 namespace bhs {
 
 // ---------------------------------------------------------------------------
-// One wave per workgroup.  A wave takes super-runs of kClassSuper consecutive rows, kClassRun at a time; workgroups are
-// dealt to the XCDs so that each XCD's L2 sees one contiguous band of rows.
+// One wave per workgroup.  A wave takes super-runs of consecutive rows -- a grid line of A where it has such lines (the
+// host's superRows; kClassSuper rows otherwise) -- kClassRun at a time; workgroups are dealt to the XCDs so that each
+// XCD's L2 sees one contiguous band of rows.
 //   per run      the A entries of its rows are one contiguous stretch of colIndA / valA: loaded with coalesced loads,
 //                their rowPtrB gathered, both parked in LDS.  These loads run three runs ahead of the arithmetic in a
 //                register pipeline (row pointers -> A entries -> rowPtrB words);
