@@ -38,7 +38,11 @@ struct Options {
     int gx = 0, gy = 0, gz = 0;
     bool keepvalues = false, check = true, cpu_time = false;
     int gpus = 0, ranges = 4;
+    int rank = -1;                   // (-rank R -idfile F: this process IS rank R of a -gpus run; set by the parent's exec)
+    string idfile;
 };
+static char **g_argv = nullptr;
+static int g_argc = 0;
 
 // ref_spgemm::compData (ref_spgemm.h:65-127) with the CPU oracle in place of cusp::multiply and
 // the north_star tolerance (1e-6 relative) in place of the reference's 10 %.  Same prints.
@@ -199,19 +203,27 @@ static int run_multi(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const
     cout << " row blocks (balanced by products):";
     for (int r = 0; r <= world; ++r) cout << " " << starts[r];
     cout << endl;
+    if (opt.rank >= 0) return rank_main(A, B, platforms, warmups, opt, world, opt.rank, starts, opt.idfile);   // a rank's own process
     char idfile[64];
     snprintf(idfile, sizeof(idfile), "/tmp/bhs_dist_id_%d", (int)getpid());
     remove(idfile);
     cout.flush();
     vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
-        const pid_t pid = fork();                              // nothing in this process has touched a GPU yet
+        // One process per GPU, each a FRESH image of this program (fork + exec of /proc/self/exe with -rank r): a forked
+        // copy of a process that has the HIP / RCCL libraries loaded is not a safe place to start a GPU runtime in -- the
+        // N = 1 test hung once in the forked child (round 4) after passing for three rounds.  This process has not
+        // touched a GPU, so the exec is the ordinary start of a child program.
+        const pid_t pid = fork();
         if (pid < 0) return -22;
         if (pid == 0) {
-            const int rc = rank_main(A, B, platforms, warmups, opt, world, r, starts, idfile);
-            if (rc != BHSPARSE_SUCCESS) cout << "rank " << r << ": Found an err, code = " << rc << endl;
-            cout.flush();
-            _exit(rc == BHSPARSE_SUCCESS ? 0 : 1);
+            vector<char *> av(g_argv, g_argv + g_argc);
+            char rbuf[16];
+            snprintf(rbuf, sizeof(rbuf), "%d", r);
+            static char o1[] = "-rank", o2[] = "-idfile";
+            av.push_back(o1); av.push_back(rbuf); av.push_back(o2); av.push_back(idfile); av.push_back(nullptr);
+            execv("/proc/self/exe", av.data());
+            _exit(127);
         }
         kids.push_back(pid);
     }
@@ -308,7 +320,10 @@ int main(int argc, char **argv)
         else if (o == "-cpu") opt.cpu_time = true;
         else if (o == "-gpus" && argc > argi) opt.gpus = atoi(argv[argi++]);
         else if (o == "-ranges" && argc > argi) opt.ranges = atoi(argv[argi++]);
+        else if (o == "-rank" && argc > argi) opt.rank = atoi(argv[argi++]);
+        else if (o == "-idfile" && argc > argi) opt.idfile = argv[argi++];
     }
+    g_argv = argv; g_argc = argc;
     cout << "------------------------" << endl;
     int err = 0;
     if (strcmp(dataset_name1, "0") == 0) err = test_small_spgemm(platforms, opt);
