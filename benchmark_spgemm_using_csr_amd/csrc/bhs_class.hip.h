@@ -50,7 +50,10 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_BIGCOUNT = 8 + 2 * kClassSumSlots + 2 /* big classes */, CS_BIGMAXP = 8 + 2 * kClassSumSlots + 3 /* words of their longest list */,
        CS_SCANTICKET = 8 + 2 * kClassSumSlots + 4 /* tile numbers of k_class_scan */,
        CS_HEADS = 8 + 2 * kClassSumSlots + 5 /* rows of A that went through the class table (k_class_rows on the heads' lists) */,
-       CS_INTS = 8 + 2 * kClassSumSlots + 6 };
+       CS_RINGFULL = 8 + 2 * kClassSumSlots + 6 /* bhs_class_ring.hip.h: most values of a ring of (longest chain + 1) slabs among the classes whose ring fits kClassRingBudget */,
+       CS_RINGONE = 8 + 2 * kClassSumSlots + 7 /* ... most values of (longest chain) slabs among the others (their rows load what they need, row by row); 0x7fffffff: some class cannot */,
+       CS_INTS = 8 + 2 * kClassSumSlots + 8 };
+constexpr int kClassRingBudget = 8192;     // bytes of LDS a wave of bhs_class_ring.hip.h's kernel gives its ring: with the slots of a row of C and the row's A values, 16 waves per CU
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
 {
@@ -622,10 +625,12 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
                                                         int4* __restrict__ classInfo, unsigned* __restrict__ classMap,
                                                         unsigned* __restrict__ classMapA,
                                                         int* __restrict__ classRel, int* __restrict__ classLane,
+                                                        unsigned* __restrict__ classRing,   // nullptr: not wanted
                                                         int* __restrict__ stats)
 {
     __shared__ int keys[kClassMaxP], srt[kClassMaxP], pk[kClassMaxP];
     __shared__ int sIncl[kClassMaxRow], sB0[kClassMaxRow], scan[256];
+    __shared__ int sEnt[kClassMaxRow], sGeo[1];
     const int tid = threadIdx.x, s = blockIdx.x;
     const unsigned long long v = tableA[s];
     if (v == kClassEmpty) {
@@ -816,6 +821,7 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         for (int o = 32; o > 0; o >>= 1) maxLen = max(maxLen, __shfl_xor(maxLen, o, 64));
         const int myPlace = __shfl(place, tid < nA ? chain : 0, 64);
         classLane[(size_t)s * kClassLaneInts + 64 + tid] = tid < nA ? (myPlace | ((tid - opened) << 16) | (myLen << 24)) : 0;
+        sEnt[tid] = tid < nA ? (myPlace | ((tid - opened) << 16)) : 0;
         classLane[(size_t)s * kClassLaneInts + 128 + tid] = tid < nCh ? (kf | (len << 6) | (lc << 13) | (place << 20)) : 0;
         for (int j = 0; j < kClassMaxLoads; ++j) {                             // this lane's pieces of a slab
             const int x = (j * 64 + tid) * kClassEpl;
@@ -830,11 +836,55 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
             // the ring of the ring kernel: (entries of the longest chain + 1) slabs; 4 x 64 lanes x 16 bytes per slab at most
             atomicMax(&stats[CS_MAXRING], slab <= kClassMaxLoads * 64 * kClassEpl ? (maxLen + 1) * slab : 0x7fffffff);
             atomicMax(&stats[CS_MAXSLAB], slab);
+            // ... and of bhs_class_ring.hip.h's kernel: the same ring where it fits that kernel's budget; a class beyond it keeps
+            // (longest chain) slabs -- what ONE row needs -- and starts every row as a stretch
+            sGeo[0] = slab;
+            if (slab > kClassMaxLoads * 64 * kClassEpl) atomicMax(&stats[CS_RINGONE], 0x7fffffff);
+            else if ((maxLen + 1) * slab * (int)sizeof(value_t) <= kClassRingBudget) atomicMax(&stats[CS_RINGFULL], (maxLen + 1) * slab);
+            else atomicMax(&stats[CS_RINGONE], maxLen * slab);
         }
         int mx = myLen;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
         if (tid == 0) atomicMax(&stats[CS_MAXLB], mx);
+    }
+    // classRing (bhs_class_ring.hip.h): per (step, lane) the product's place in the ring at the first row of a
+    // stretch (byte offset, bits 0-15), its A entry (16-22; nA: a step without a product -- it multiplies by the zero behind
+    // the row's A values -- and reads where the lane's last product reads) and bit 31: an entry of C ends here, in this lane
+    // (its last product of the lane, and the entry does not go on in the next lane).  A lane's products come first, its idle
+    // steps last; the class's U steps are the last of the kClassMaxSteps stored ones.  Behind them a word per lane: the
+    // first entry that ends in it (bits 0-15) and 1 + the entry its last running sum is added to (16-31; 0: none).
+    if (classRing != nullptr) {
+        __syncthreads();
+        const int slabP = sGeo[0];                                   // values per slot of the ring
+        auto place_of = [&](int r) {
+            const unsigned code = (unsigned)pk[srt[r] & 1023];
+            const int e = sEnt[code & 63u];
+            return (unsigned)(((e >> 16) * slabP + (e & 0xFFFF) + (int)(code >> 6)) * (int)sizeof(value_t));
+        };
+        for (int idx = tid; idx < kClassMaxSteps * 64; idx += 256) {
+            const int L = idx & 63, j = (idx >> 6) - (kClassMaxSteps - U);
+            const int first = L * U, last = min(P, first + U) - 1, r = first + j;
+            unsigned w;
+            if (j >= 0 && r <= last) {
+                const int sv = srt[r], l = sv >> 10;
+                const bool lastOfEntry = r == last || (srt[r + 1] >> 10) != l;
+                const bool goesOn = l == (srt[last] >> 10) && last + 1 < P && (srt[last + 1] >> 10) == l;
+                w = place_of(r) | ((unsigned)(pk[sv & 1023] & 63) << 16) | ((lastOfEntry && !goesOn) ? 0x80000000u : 0u);
+            } else {
+                w = (P > 0 ? place_of(first <= last ? last : 0) : 0u) | ((unsigned)nA << 16);
+            }
+            classRing[(size_t)s * (kClassMaxP + 64) + idx] = w;
+        }
+        if (tid < 64) {
+            const int first = tid * U, last = min(P, first + U) - 1;
+            int slot0 = 0, tl = -1;
+            if (first <= last) {
+                slot0 = srt[first] >> 10;
+                if (last + 1 < P && (srt[last + 1] >> 10) == (srt[last] >> 10)) tl = srt[last] >> 10;
+            }
+            classRing[(size_t)s * (kClassMaxP + 64) + kClassMaxP + tid] = (unsigned)slot0 | ((unsigned)(tl + 1) << 16);
+        }
     }
     if (tid == 0) {
         classInfo[s] = make_int4(nA, P, nnz, rep);
@@ -969,22 +1019,33 @@ __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int
 // accumulator copies (3.9 ms), the same with atomics (4.0 ms).
 // ---------------------------------------------------------------------------
 constexpr unsigned kClassIdleA = 1u << 12;     // product triple of a lane without a product
-// Stores of C that do not stay in the XCD's L2 (sc1: write-through, the line is dropped).  The kernel writes 3.3 GB that
-// nobody reads again through a 4 MB L2 per XCD: with plain stores those lines push out the rows of B that the next
-// rows of A need again (measured: 5.2 GB read per launch where 1.2 GB is compulsory).
+// Stores of C that do not stay in the XCD's L2.  The kernel writes 3.3 GB that nobody reads again through a 4 MB L2 per
+// XCD: with plain stores those lines push out the rows of B that the next rows of A need again (measured: 5.2 GB read
+// per launch where 1.2 GB is compulsory).  Rounds 3-4 wrote through (sc1); round 5 measured the policies side by side on
+// one box (poisson27pt 128^3, bhs_class_ring.hip.h's kernel): plain 1.58 ms, sc1 1.63, sc0 sc1 1.63, sc1 nt 1.80,
+// nt 1.46 -- non-temporal stores it is (round 4's kernel: 1.61 -> 1.42).
+#if BHS_CLS_STORE_SC1 == 2
+#define BHS_CLS_STORE_POLICY " nt"
+#elif BHS_CLS_STORE_SC1 == 3
+#define BHS_CLS_STORE_POLICY " sc1 nt"
+#elif BHS_CLS_STORE_SC1 == 4
+#define BHS_CLS_STORE_POLICY " sc0 sc1"
+#else
+#define BHS_CLS_STORE_POLICY " sc1"
+#endif
 __device__ __forceinline__ void class_store_c(double* p, double v)
 {
-    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, off" BHS_CLS_STORE_POLICY ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 __device__ __forceinline__ void class_store_c(float* p, float v)
 {
-    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off" BHS_CLS_STORE_POLICY ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 __device__ __forceinline__ void class_store_c(int* p, int v)
 {
-    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off" BHS_CLS_STORE_POLICY ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 constexpr int kClassRunA = 8;

@@ -100,8 +100,8 @@
 #ifndef BHS_CLS_PARTS      // round 2's class kernel: parts a row's products are dealt in
 #define BHS_CLS_PARTS 1
 #endif
-#ifndef BHS_CLS_STORE_SC1      // class kernels: write-through (sc1) stores of C
-#define BHS_CLS_STORE_SC1 1
+#ifndef BHS_CLS_STORE_SC1      // class kernels, stores of C: 0 plain, 1 write-through (sc1; rounds 3-4), 2 non-temporal (nt; round 5: numeric_class 1.54 -> 1.39 ms), 3 sc1 nt (1.80), 4 sc0 sc1
+#define BHS_CLS_STORE_SC1 2
 #endif
 #ifndef BHS_CLS_RUN      // ring kernel: rows per run (metadata granularity)
 #define BHS_CLS_RUN 8

@@ -24,6 +24,7 @@
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
 #include "bhs_class_wg.hip.h"
+#include "bhs_class_ring.hip.h"
 #include "bhs_class_big.hip.h"
 
 #include <algorithm>
@@ -158,10 +159,10 @@ struct bhs_handle {
     int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
     unsigned scanEpoch = 0;              // tag of this multiply's tile words
     int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
-    int classNumeric = 1;                // numeric kernel of the class path: 1 the ring kernel (bhs_class_wg.hip.h) where its LDS fits, 0 k_class_numeric_atomic (round 2) always
+    int classNumeric = 2;                // numeric kernel of the class path: 2 round 5's ring kernel (bhs_class_ring.hip.h) where its LDS fits, 1 round 4's (bhs_class_wg.hip.h), 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
-    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRel, classLane, classHeads, classHeadCnt, classBigIdx, classBigMap;
+    DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRing, classRel, classLane, classHeads, classHeadCnt, classBigIdx, classBigMap;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
     int hubMin = 1 << 17, hubItemProducts = 8192, hubMaxSlots = 0, hubAggregate = 1;
@@ -234,7 +235,7 @@ struct bhs_handle {
         bool empty = false;               // empty product: nothing to launch
         bool noUpperBound = false, symDirect = false;
         bool useClass = false;            // numeric half: k_class_numeric
-        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0, classMaxSlab = 0;
+        int classMaxP = 0, classMaxNnz = 0, classMaxNA = 0, classMaxLB = 0, classMaxRing = 0, classMaxRing2 = 0, classMaxSlab = 0;
         int classBig = 0, classBigMaxP = 0;   // classes beyond the register kernels' tables (bhs_class_big.hip.h), their longest product list
         int laneK = 0, maxCnt = 0, hubRows = 0;
         BinSpec numSpec;
@@ -635,6 +636,68 @@ int launch_class_numeric(bhs_handle* h, int r0, int r1)
     if (U <= 8 && V <= 4) return launch_class_numeric_uv<8, 4>(h, r0, r1);
     if (U <= 12 && V <= 2) return launch_class_numeric_uv<12, 2>(h, r0, r1);
     return launch_class_numeric_uv<16, 8>(h, r0, r1);
+}
+
+// ... round 5's ring kernel (bhs_class_ring.hip.h): the ring a power of two of bytes at LDS address 0, then the slots of a
+// row of C, then the row's A values with a zero behind them
+struct Ring2Lds { int ringBytes, accStride, afixCap; size_t bytes; };   // (the ring: what the neediest class keeps, bhs_class.hip.h CS_RINGFULL / CS_RINGONE)
+Ring2Lds class_ring2_lds(bhs_handle* h)
+{
+    Ring2Lds l;
+    l.ringBytes = (int)std::min<long long>((((long long)h->ps.classMaxRing2 * (long long)sizeof(value_t)) + 15) & ~15ll, 1 << 30);
+    l.accStride = (h->ps.classMaxNnz + 2) & ~1;
+    l.afixCap = (h->ps.classMaxNA + 2) & ~1;
+    l.bytes = (size_t)l.ringBytes + (size_t)(l.accStride + l.afixCap) * sizeof(acc_t);
+    return l;
+}
+// (false: some class's slab is beyond a slab's load instructions, or the ring beyond the 16 bits of a product's place)
+bool class_ring2_fits(bhs_handle* h)
+{
+    if (h->ps.classMaxRing2 <= 0 || h->ps.classMaxRing2 == 0x7fffffff) return false;
+    const Ring2Lds l = class_ring2_lds(h);
+    return l.ringBytes <= 32 * 1024 && l.bytes <= 40 * 1024;
+}
+
+template <int MAXU, int MAXV, int MAXJ>
+int launch_class_ring_impl(bhs_handle* h, int r0, int r1)
+{
+    auto kern = k_class_ring<MAXU, MAXV, MAXJ>;
+    const Ring2Lds lds = class_ring2_lds(h);
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, lds.bytes, &perCU));
+    perCU = std::max(1, std::min(perCU, 32));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    const int mR = r1 - r0;
+    const int superRows = std::max(32, h->classSuperRows > 0 ? h->classSuperRows : (h->lineA > 0 ? h->lineA : kClassSuper));
+    const long long nSuper = ((long long)mR + superRows - 1) / superRows;
+    long long grid = std::min<long long>(nSuper, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    const int chunkRows = std::max(1, std::min(64, 128 / std::max(1, h->ps.classMaxNA)));   // whole rows, <= 128 entries of A
+    if (h->verbose > 1) printf("  [class numeric (ring, round 5): %d waves per CU by the occupancy API, %d used, %zu bytes of LDS each, grid %lld, %d rows per chunk]\n", perCU, useCU, lds.bytes, grid, chunkRows);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.bytes, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
+                       (long long)h->nnzA, h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
+                       (const unsigned*)h->classRing.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
+                       out_cx(h), lds.ringBytes, lds.accStride, r0, superRows, chunkRows);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+
+template <int MAXU, int MAXV>
+int launch_class_ring_uv(bhs_handle* h, int r0, int r1)
+{
+    const bool smallSlab = h->ps.classMaxSlab <= 2 * 64 * kClassEpl;
+    return smallSlab ? launch_class_ring_impl<MAXU, MAXV, 2>(h, r0, r1) : launch_class_ring_impl<MAXU, MAXV, kClassMaxJ>(h, r0, r1);
+}
+
+int launch_class_ring(bhs_handle* h, int r0, int r1)
+{
+    const int U = (h->ps.classMaxP + 63) / 64, V = (h->ps.classMaxNnz + 63) / 64;
+    if (U <= 1 && V <= 1) return launch_class_ring_uv<1, 1>(h, r0, r1);
+    if (U <= 2 && V <= 1) return launch_class_ring_uv<2, 1>(h, r0, r1);
+    if (U <= 4 && V <= 2) return launch_class_ring_uv<4, 2>(h, r0, r1);
+    if (U <= 8 && V <= 4) return launch_class_ring_uv<8, 4>(h, r0, r1);
+    if (U <= 12 && V <= 2) return launch_class_ring_uv<12, 2>(h, r0, r1);
+    return launch_class_ring_uv<16, 8>(h, r0, r1);
 }
 
 // Hub rows: plan -> mark -> count [-> emit -> place], in batches of as many rows as there are bitmap slots.
@@ -1223,6 +1286,7 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * kClassSlots));
     BHS_TRY(ensure(h, h->classMap, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
     BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
+    BHS_TRY(ensure(h, h->classRing, sizeof(unsigned) * (size_t)kClassSlots * kClassRingStride));
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
     BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
     BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
@@ -1300,7 +1364,8 @@ int symbolic_class(bhs_handle* h)
     BHS_TRY(timed_begin(h, "class_patterns", &ep));
     hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
                        h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
-                       (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p, cstats);
+                       (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p,
+                       (unsigned*)h->classRing.p, cstats);
     if (bigPossible) {
         const size_t smemBig = sizeof(int) * 2 * kClassBigMaxP;
         int unused = 0;
@@ -1443,6 +1508,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxNA = cs[CS_MAXNA];
         h->ps.classMaxLB = cs[CS_MAXLB];
         h->ps.classMaxRing = cs[CS_MAXRING];
+        h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
         h->ps.classMaxSlab = cs[CS_MAXSLAB];
         h->ps.classBig = cs[CS_BIGCOUNT];
         h->ps.classBigMaxP = cs[CS_BIGMAXP];
@@ -1518,6 +1584,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
         if (h->ps.classBig) BHS_TRY(launch_class_numeric_big(h, r0, r1));
+        else if (h->classNumeric >= 2 && class_ring2_fits(h)) BHS_TRY(launch_class_ring(h, r0, r1));
         else BHS_TRY(h->classNumeric && class_ring_fits(h) ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
@@ -1988,7 +2055,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->spaRank);
     release(h->longList); release(h->longPart);
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
-    release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRel); release(h->classLane);
+    release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRing); release(h->classRel); release(h->classLane);
     release(h->classBigIdx); release(h->classBigMap);
     release(h->bWin); release(h->bWinTab); release(h->bWinSpill);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
@@ -2286,7 +2353,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_heads")) { h->classHeadsOn = value ? 1 : 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1)); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_aggregate")) { h->hubAggregate = value != 0; return BHS_SUCCESS; }

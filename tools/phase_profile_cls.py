@@ -24,7 +24,9 @@ raw.bhs_debug_phases(buf)
 rows = buf[7]
 names = ["run: requests for the runs behind", "class data (on a change)", "stretch start: first slabs requested",
          "stretch start: wait for them", "row: arithmetic (LDS only)", "row: slab request + write-out", "row: vmcnt wait"]
-tot = sum(buf[i] for i in range(7))
+names += ["(ring, r5) A values placed + 24 LDS reads incl. latency", "(ring, r5) ring moved on", "(ring, r5) chunk switch", "(ring, r5) slab request"]
+idx = list(range(7)) + [8, 9, 10, 11]
+tot = sum(buf[i] for i in idx)
 print("rows", rows, "wave cycles per row: %.0f" % (tot / rows))
-for i, n in enumerate(names): print("  %-44s %8.0f cycles/row  %5.1f %%" % (n, buf[i] / rows, 100.0 * buf[i] / tot))
+for i, n in zip(idx, names): print("  %-52s %8.0f cycles/row  %5.1f %%" % (n, buf[i] / rows, 100.0 * buf[i] / tot))
 print({s["name"]: round(s["ms"], 3) for s in bh.kernel_stats() if s["ms"] > 0.1})
