@@ -53,6 +53,7 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_RINGFULL = 8 + 2 * kClassSumSlots + 6 /* bhs_class_ring.hip.h: most values of a ring of (longest chain + 1) slabs among the classes whose ring fits kClassRingBudget */,
        CS_RINGONE = 8 + 2 * kClassSumSlots + 7 /* ... most values of (longest chain) slabs among the others (their rows load what they need, row by row); 0x7fffffff: some class cannot */,
        CS_INTS = 8 + 2 * kClassSumSlots + 8 };
+constexpr int kClassRingStride = kClassMaxP + 64 + kClassMaxNnz;   // words per class of classRing: 16 steps x 64 lanes, a word per lane, the relative columns in pairs
 constexpr int kClassRingBudget = 8192;     // bytes of LDS a wave of bhs_class_ring.hip.h's kernel gives its ring: with the slots of a row of C and the row's A values, 16 waves per CU
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
             } else {
                 w = (P > 0 ? place_of(first <= last ? last : 0) : 0u) | ((unsigned)nA << 16);
             }
-            classRing[(size_t)s * (kClassMaxP + 64) + idx] = w;
+            classRing[(size_t)s * kClassRingStride + idx] = w;
         }
         if (tid < 64) {
             const int first = tid * U, last = min(P, first + U) - 1;
@@ -883,7 +884,15 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
                 slot0 = srt[first] >> 10;
                 if (last + 1 < P && (srt[last + 1] >> 10) == (srt[last] >> 10)) tl = srt[last] >> 10;
             }
-            classRing[(size_t)s * (kClassMaxP + 64) + kClassMaxP + tid] = (unsigned)slot0 | ((unsigned)(tl + 1) << 16);
+            classRing[(size_t)s * kClassRingStride + kClassMaxP + tid] = (unsigned)slot0 | ((unsigned)(tl + 1) << 16);
+        }
+        // ... and the relative columns as the kernel's lanes write them: lane L of the w-th pair of store instructions takes
+        // the entries e0, e0 + 1 with e0 = min(2 (64 w + L), nnz - 2) -- an odd row's last lane overlaps its neighbour
+        for (int q = tid; q < kClassMaxNnz / 2; q += 256) {
+            const int e0 = max(0, min(2 * q, nnz - 2));
+            const bool on = 2 * q < nnz;
+            classRing[(size_t)s * kClassRingStride + kClassMaxP + 64 + 2 * q] = on ? (unsigned)ulist[e0] : 0u;
+            classRing[(size_t)s * kClassRingStride + kClassMaxP + 64 + 2 * q + 1] = on && e0 + 1 < nnz ? (unsigned)ulist[e0 + 1] : 0u;
         }
     }
     if (tid == 0) {
@@ -1047,6 +1056,42 @@ __device__ __forceinline__ void class_store_c(int* p, int v)
 {
     if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, off" BHS_CLS_STORE_POLICY ::"v"(p), "v"(v) : "memory");
     else *p = v;
+}
+// ... the same with the address as a wave-uniform base (two SGPRs) and a 32-bit byte offset per lane: half the address
+// words per store instruction, and no 64-bit address arithmetic per lane and row
+__device__ __forceinline__ void class_store_c_at(double* base, unsigned off, double v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v;
+}
+__device__ __forceinline__ void class_store_c_at(float* base, unsigned off, float v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v;
+}
+__device__ __forceinline__ void class_store_c_at(int* base, unsigned off, int v)
+{
+    if (BHS_CLS_STORE_SC1) asm volatile("global_store_dword %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+    else *reinterpret_cast<int*>(reinterpret_cast<char*>(base) + off) = v;
+}
+// ... two neighbouring entries per lane: one instruction where two were
+__device__ __forceinline__ void class_store_c2_at(double* base, unsigned off, double a, double b)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void class_store_c2_at(float* base, unsigned off, float a, float b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void class_store_c2_at(int* base, unsigned off, int a, int b)
+{
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 constexpr int kClassRunA = 8;
 constexpr int kClassWavesA = 4;

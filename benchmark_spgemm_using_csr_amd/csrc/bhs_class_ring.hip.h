@@ -25,8 +25,6 @@
 
 namespace bhs {
 
-constexpr int kClassRingStride = kClassMaxP + 64;                 // words per class of classRing: 16 steps x 64 lanes + a word per lane
-
 #ifndef BHS_RING_WAVES
 #define BHS_RING_WAVES 4
 #endif
@@ -117,7 +115,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     unsigned long long endMask[MAXU];                            // per step: the lanes in which an entry of C ends with this product
     unsigned slot0 = 0;                                          // LDS address of the slot of the first entry that ends in this lane
     int tail = -1;                                               // the entry this lane's last running sum is added to (-1: none)
-    int rel[MAXV];
+    constexpr int MAXW = (MAXV + 1) / 2;                         // pairs of store instructions per row: a lane writes two neighbouring entries
+    int relA[MAXW], relB[MAXW];                                  // their columns, relative to the row
     int dma[MAXJ];                                               // this lane's 16 bytes of each load instruction of a slab (bhs_class.hip.h: classLane[256 ..])
     unsigned src[MAXJ];                                          // ... where its next piece comes from (values of B are counted in int32: nnzB < 2^31)
     unsigned stepB = 0, wrapB = 0;                               // bytes per slab, bytes of this class's ring
@@ -190,7 +189,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) dma[j] = classLane[(size_t)cls * kClassLaneInts + 256 + j * 64 + lane];
 #pragma unroll
-                for (int v = 0; v < MAXV; ++v) rel[v] = classRel[(size_t)cls * kClassMaxNnz + v * 64 + lane];   // (beyond the row: never stored)
+                for (int w2 = 0; w2 < MAXW; ++w2) {                  // (beyond the row: never stored)
+                    const uint2 rp = *reinterpret_cast<const uint2*>(classRing + (size_t)cls * kClassRingStride + kClassMaxP + 64 + 2 * (w2 * 64 + lane));
+                    relA[w2] = (int)rp.x;
+                    relB[w2] = (int)rp.y;
+                }
                 __builtin_amdgcn_s_waitcnt(kWaitVm0);                // (so that no later wait has to cover these loads)
                 nA = __builtin_amdgcn_readfirstlane(ci.x);
                 nnz = __builtin_amdgcn_readfirstlane(ci.z);
@@ -308,16 +311,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
             BHS_TICK_CLS(10);
             if (!oneRow) request_slab();
             BHS_TICK_CLS(11);
-            const int out = __builtin_amdgcn_readlane(pc.cp, t);
-            storesInFlight = (BHS_CLS_LAB & 2) ? 0 : 2 * ((nnz + 63) >> 6);   // (the store instructions below: a pair per 64 entries)
+            const int out = (BHS_CLS_LAB & 512) ? (int)(blockIdx.x * 1024) : __builtin_amdgcn_readlane(pc.cp, t);   // (512: every wave writes its rows to one place)
+            storesInFlight = (BHS_CLS_LAB & 2) ? 0 : 2 * ((nnz + 127) >> 7);   // (the store instructions below: a pair per 128 entries)
             if (!(BHS_CLS_LAB & 2)) {
+                typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
+                int* const cjRow = Cj + (long long)out;
+                value_t* const cxRow = Cx + (long long)out;
+                if (nnz >= 2) {
 #pragma unroll
-                for (int v = 0; v < MAXV; ++v) {
-                    const int s = v * 64 + lane;
-                    if (s < nnz) {
-                        class_store_c(&Cj[(long long)out + s], rel[v] + row + rowBase);
-                        class_store_c(&Cx[(long long)out + s], (value_t)acc[s]);
+                    for (int w2 = 0; w2 < MAXW; ++w2) {
+                        const int q = w2 * 64 + lane;
+                        if (2 * q < nnz) {                           // (an odd row's last lane: its neighbour's second entry once more, and the last)
+                            const int e0 = min(2 * q, nnz - 2);
+                            const unsigned a0 = accBase + (unsigned)e0 * (unsigned)sizeof(acc_t);
+                            const acc_t x0 = *(lds_acc_c)(size_t)a0, x1 = *(lds_acc_c)(size_t)(a0 + (unsigned)sizeof(acc_t));
+                            if (!(BHS_CLS_LAB & 1024)) class_store_c2_at(cjRow, (unsigned)e0 * (unsigned)sizeof(int), relA[w2] + row + rowBase, relB[w2] + row + rowBase);
+                            class_store_c2_at(cxRow, (unsigned)e0 * (unsigned)sizeof(value_t), (value_t)x0, (value_t)x1);
+                        }
                     }
+                } else if (nnz == 1 && lane == 0) {
+                    class_store_c_at(cjRow, 0u, relA[0] + row + rowBase);
+                    class_store_c_at(cxRow, 0u, (value_t)acc[0]);
                 }
             }
             wave_sync();
