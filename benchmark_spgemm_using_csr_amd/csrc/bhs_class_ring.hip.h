@@ -123,6 +123,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     int slots = 1;                                               // slabs of the ring
     bool oneRow = false;                                         // the class's ring is beyond the budget: every row loads its own slabs
     int phase = 0, loadSlot = 0, lastRow = -2, storesInFlight = 0;
+    acc_t bv[MAXU], av[MAXU];                                    // the operands of the row at hand's products (read from LDS a row ahead where the rows carry on)
+    bool preIssued = false;                                      // ... they are the row at hand's already
     bool ringOK = false;
 #if BHS_PHASES_CLS
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tPh = __builtin_readcyclecounter();
@@ -169,6 +171,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
             nxtValid = true;
         }
     }
+    // (Everything the prologue asked for is waited for HERE: left pending into the loops, the compiler's wait for the first
+    // block's pointers lands in the header of the row loop -- an s_waitcnt vmcnt(0) at the top of every row, in front of
+    // which the row before's slab request and stores have just been issued.)
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);
     for (int ib = 0; nr > 0; ++ib) {
         row0N = block_of(ib + 1, nrN);
         pn = load_ptrs(row0N, nrN);                              // (consumed behind this block's first vmcnt(0) at the earliest)
@@ -232,37 +238,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 wave_sync();
                 BHS_TICK_CLS(3);
             }
-            // the row's A values to their fixed place.  (Through an address made of an integer, like every LDS access of the
-            // row's arithmetic: for a store through a pointer derived from the shared array the compiler cannot rule out
-            // that a slab's LDS-direct load writes the same bytes and puts an s_waitcnt vmcnt(0) in front of it -- at the
-            // top of the row, where the row before's slab request and stores have just been issued.)
-            {
+            // The row's operands: A's values to their fixed place, then the LDS reads of both operands of every product, and
+            // the products' places moved on by one slab around the ring.  Where the next row carries on (same class, same
+            // chunk of A's values, same block) this was done a row ago, BEHIND that row's arithmetic and in front of its
+            // write-out: the reads' latency -- 16 waves queue at the LDS pipe -- runs beside the slab request and the stores.
+            // (The stores of A's values go through an address made of an integer, like every LDS access of the arithmetic:
+            // for a store through a pointer derived from the shared array the compiler cannot rule out that a slab's
+            // LDS-direct load writes the same bytes and puts an s_waitcnt vmcnt(0) in front of it.)
+            auto issue_reads = [&](int apRow) {
                 typedef __attribute__((address_space(3))) acc_t* lds_acc;
-                const int k0 = 2 * lane - (apT - curBase);
-                const unsigned a0 = afixBase + (unsigned)k0 * (unsigned)sizeof(acc_t);
-                if (!(BHS_CLS_LAB & 16)) {
-                if ((unsigned)k0 < (unsigned)nA) *(lds_acc)(size_t)a0 = (acc_t)axCur.x;
-                if ((unsigned)(k0 + 1) < (unsigned)nA) *(lds_acc)(size_t)(a0 + (unsigned)sizeof(acc_t)) = (acc_t)axCur.y;
-                }
-            }
-            wave_sync();
-            // the row's arithmetic: LDS only
-            {
                 typedef __attribute__((address_space(3))) const value_t* lds_val;
                 typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
-                acc_t bv[MAXU], av[MAXU];
+                const int k0 = 2 * lane - (apRow - curBase);
+                const unsigned a0 = afixBase + (unsigned)k0 * (unsigned)sizeof(acc_t);
+                if (!(BHS_CLS_LAB & 16)) {
+                    if ((unsigned)k0 < (unsigned)nA) *(lds_acc)(size_t)a0 = (acc_t)axCur.x;
+                    if ((unsigned)(k0 + 1) < (unsigned)nA) *(lds_acc)(size_t)(a0 + (unsigned)sizeof(acc_t)) = (acc_t)axCur.y;
+                }
+                wave_sync();
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) bv[u] = (BHS_CLS_LAB & 64) ? (acc_t)*(lds_val)(size_t)(unsigned)(lane * 8 + u * 512) : (acc_t)*(lds_val)(size_t)at[u];
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) av[u] = (BHS_CLS_LAB & 128) ? (acc_t)(u + 1) : *(lds_acc_c)(size_t)aAddr[u];
-                BHS_TICK_CLS(8);
-                // every product moves on by one slab, around the ring (while the reads are under way)
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {                     // (unsigned: below the ring's end the difference wraps to something huge)
                     const unsigned nx = at[u] + stepB;
                     at[u] = min(nx, nx - wrapB);
                 }
-                BHS_TICK_CLS(9);
+                if (!oneRow) phase = phase + 1 == slots ? 0 : phase + 1;
+            };
+            if (!preIssued) issue_reads(apT);
+            BHS_TICK_CLS(8);
+            // the row's arithmetic
+            {
                 acc_t sum = 0.0;
                 unsigned slotPtr = slot0;
 #pragma unroll
@@ -271,15 +279,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                     if (!(BHS_CLS_LAB & 32)) ring_end_step(endMask[u], slotPtr, sum);
                 }
                 if (tail >= 0) unsafeAtomicAdd(&acc[tail], sum);     // (after every plain store of the row: in order)
-                if (!oneRow) phase = phase + 1 == slots ? 0 : phase + 1;
             }
             wave_sync();
             BHS_TICK_CLS(4);
             // whatever is in flight was requested a row ago: the slab the next row needs first -- and the row before's stores,
             // which nobody here waits for (their acknowledgement takes longer than a row's arithmetic)
-            if (BHS_CLS_LAB & 8) __builtin_amdgcn_s_waitcnt(kWaitVm0);
-            else wait_all_but_stores<MAXV>(storesInFlight);
+            // (A counted wait that leaves the row before's stores in flight -- wait_all_but_stores -- measured the same, and
+            // keeps the compiler from knowing that the chunk of A's values has arrived: it then waits in front of their use.)
+            if (BHS_CLS_LAB & 8) wait_all_but_stores<MAXV>(storesInFlight);
+            else __builtin_amdgcn_s_waitcnt(kWaitVm0);
             BHS_TICK_CLS(6);
+            // this row's sums, out of the slots before the next row's arithmetic writes there
+            const int out = (BHS_CLS_LAB & 512) ? (int)(blockIdx.x * 1024) : __builtin_amdgcn_readlane(pc.cp, t);   // (512: every wave writes its rows to one place)
+            acc_t x0[MAXW], x1[MAXW];
+            {
+                typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
+#pragma unroll
+                for (int w2 = 0; w2 < MAXW; ++w2) {
+                    const int e0 = max(0, min(2 * (w2 * 64 + lane), nnz - 2));
+                    const unsigned a0 = accBase + (unsigned)e0 * (unsigned)sizeof(acc_t);
+                    x0[w2] = *(lds_acc_c)(size_t)a0;
+                    x1[w2] = *(lds_acc_c)(size_t)(a0 + (unsigned)sizeof(acc_t));
+                }
+            }
             // the chunk of A's values: the next one becomes the one at hand behind the last row of this one, and the one
             // after it is requested (whatever was requested a chunk ago has arrived: the wait above)
             if (t + 1 == cEnd) {
@@ -289,7 +311,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                     const int e0 = min(s0 + G, nrB);
                     const int b0 = more ? __builtin_amdgcn_readlane(pc.ap, s0) : __builtin_amdgcn_readlane(pn.ap, 0);
                     if (nxtValid) axCur = axNxt;
-                    else axCur = load_chunk(b0, (more ? __builtin_amdgcn_readlane(pc.ap1, e0 - 1) : __builtin_amdgcn_readlane(pn.ap1, e0 - 1)) - b0);
+                    else {                                           // (a block of one chunk: on demand)
+                        axCur = load_chunk(b0, (more ? __builtin_amdgcn_readlane(pc.ap1, e0 - 1) : __builtin_amdgcn_readlane(pn.ap1, e0 - 1)) - b0);
+                        __builtin_amdgcn_s_waitcnt(kWaitVm0);
+                    }
                     curBase = b0;
                     cEnd = e0;                                       // (rows of the block the chunk is in)
                     // the chunk after it: in the same block as the new one, or -- that block ending with it -- in the block
@@ -309,12 +334,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 }
             }
             BHS_TICK_CLS(10);
+            // the next row's operands, if it carries on from this one (its slabs are here: the wait above) -- behind this row's
+            // sums: no store below has to wait for an LDS read
+            __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+            preIssued = false;
+            if (!(BHS_CLS_LAB & 4096) && !oneRow && t + 1 < nr && __builtin_amdgcn_readlane(pc.cls, min(t + 1, 63)) == cur) {
+                issue_reads(__builtin_amdgcn_readlane(pc.ap, min(t + 1, 63)));
+                preIssued = true;
+            }
+            BHS_TICK_CLS(9);
             if (!oneRow) request_slab();
             BHS_TICK_CLS(11);
-            const int out = (BHS_CLS_LAB & 512) ? (int)(blockIdx.x * 1024) : __builtin_amdgcn_readlane(pc.cp, t);   // (512: every wave writes its rows to one place)
             storesInFlight = (BHS_CLS_LAB & 2) ? 0 : 2 * ((nnz + 127) >> 7);   // (the store instructions below: a pair per 128 entries)
             if (!(BHS_CLS_LAB & 2)) {
-                typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
                 int* const cjRow = Cj + (long long)out;
                 value_t* const cxRow = Cx + (long long)out;
                 if (nnz >= 2) {
@@ -323,15 +355,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                         const int q = w2 * 64 + lane;
                         if (2 * q < nnz) {                           // (an odd row's last lane: its neighbour's second entry once more, and the last)
                             const int e0 = min(2 * q, nnz - 2);
-                            const unsigned a0 = accBase + (unsigned)e0 * (unsigned)sizeof(acc_t);
-                            const acc_t x0 = *(lds_acc_c)(size_t)a0, x1 = *(lds_acc_c)(size_t)(a0 + (unsigned)sizeof(acc_t));
                             if (!(BHS_CLS_LAB & 1024)) class_store_c2_at(cjRow, (unsigned)e0 * (unsigned)sizeof(int), relA[w2] + row + rowBase, relB[w2] + row + rowBase);
-                            class_store_c2_at(cxRow, (unsigned)e0 * (unsigned)sizeof(value_t), (value_t)x0, (value_t)x1);
+                            class_store_c2_at(cxRow, (unsigned)e0 * (unsigned)sizeof(value_t), (value_t)x0[w2], (value_t)x1[w2]);
                         }
                     }
                 } else if (nnz == 1 && lane == 0) {
                     class_store_c_at(cjRow, 0u, relA[0] + row + rowBase);
-                    class_store_c_at(cxRow, 0u, (value_t)acc[0]);
+                    class_store_c_at(cxRow, 0u, (value_t)x0[0]);
                 }
             }
             wave_sync();
