@@ -524,6 +524,7 @@ def main():
     # figures are printed.
     general = None
     if world == 1 and not args.no_general:
+        headline_digest = device_digest(bh, m, dev)
         for key in ("class_path", "wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 0) == 0
         for _ in range(2):
@@ -535,7 +536,10 @@ def main():
             assert bh.spgemm() == 0
             tg.append((time.perf_counter() - tq) * 1e3)
         general = {"options": "class_path=0 wave_first=0 lane_first=0 direct_bins=0", "ms_median": round(float(np.median(tg)), 4),
-                   "ms_min": round(float(np.min(tg)), 4), "gflops_median": round(2.0 * bh.nnzCt / (float(np.median(tg)) * 1e6), 2)}
+                   "ms_min": round(float(np.min(tg)), 4), "gflops_median": round(2.0 * bh.nnzCt / (float(np.median(tg)) * 1e6), 2),
+                   # the general pipeline's C against the headline's (row classes), array by array as digests
+                   "digest_equals_headline": device_digest(bh, m, dev) == headline_digest,
+                   "kernels_ms": {s["name"]: round(s["ms"], 4) for s in bh.kernel_stats() if s["launches"] > 0}}
         for key in ("class_path", "wave_first", "lane_first", "direct_bins"):
             assert bh.set_option(key, 1) == 0
 
@@ -617,6 +621,15 @@ def main():
             extra[wname] = {"workload": "%s %s C=A^2" % (st2, "x".join(map(str, d2))), "ms_per_step": round(msq, 4),
                             "gflops": round(2.0 * bh.nnzCt / (msq * 1e6), 2), "nnzCt": bh.nnzCt, "nnzC": bh.nnzC,
                             "pipeline_frac_of_hbm_peak": round(balg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            # the kernel families of this configuration (hipEvent pairs around each, three more multiplies outside the figure above)
+            assert bh.set_option("kernel_stats", 1) == 0
+            kacc = {}
+            for _ in range(3):
+                assert bh.spgemm() == 0
+                for s_ in bh.kernel_stats():
+                    if s_["launches"] > 0:
+                        kacc[s_["name"]] = kacc.get(s_["name"], 0.0) + s_["ms"] / 3
+            extra[wname]["kernels_ms_per_step"] = {k_: round(v_, 4) for k_, v_ in sorted(kacc.items()) if v_ >= 0.0005}
             bh.free_mem()
             del bp2, bj2, bx2, ap2, aj2, ax2
             torch.cuda.empty_cache()

@@ -276,13 +276,16 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
 
 template <int V> struct template_int { static constexpr int value = V; };
 
-int ensure(bhs_handle* h, DevBuf& b, size_t bytes)
+// zeroed: a NEW allocation is cleared on the handle's stream (the scans' tile words: k_scan_onepass takes a word whose epoch
+// matches for published, and what hipMalloc hands out may hold the words another handle's scan left there at that epoch)
+int ensure(bhs_handle* h, DevBuf& b, size_t bytes, bool zeroed = false)
 {
     if (bytes <= b.cap && b.p) return BHS_SUCCESS;
     if (b.p) { BHS_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     if (bytes == 0) bytes = 16;
     BHS_HIP(hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    if (zeroed) BHS_HIP(hipMemsetAsync(b.p, 0, bytes, h->stream));
     return BHS_SUCCESS;
 }
 
@@ -1296,7 +1299,7 @@ int symbolic_class(bhs_handle* h)
     if (bigPossible) BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
     BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
     const int nScanTiles = (m + kClassScanTile - 1) / kClassScanTile;           // (k_class_scan's tile words live in blockSum)
-    BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nScanTiles, (int)(((long long)m + 1 + kScanTile - 1) / kScanTile))));
+    BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nScanTiles, (int)(((long long)m + 1 + kScanTile - 1) / kScanTile)), true));
     hipLaunchKernelGGL(k_class_reset, dim3(32), dim3(256), 0, h->stream, small, (int)S_ZERO_END, small + S_CT_SLOTS, (int)CS_INTS,
                        (int*)h->classHeadCnt.p, 2 * 16 * kClassHeadSegs, (unsigned long long*)h->classTab.p, 2 * kClassSlots,
                        (int*)h->classBigIdx.p, bigPossible ? kClassSlots : 0, (unsigned long long*)h->blockSum.p, nScanTiles);
@@ -1413,7 +1416,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
     BHS_TRY(ensure(h, h->queue, sizeof(int4) * (size_t)m));
     const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
-    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks));
+    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks, true));
 
     EventPair* ep;
     SymChoices sc;

@@ -42,8 +42,13 @@ def _spmv(rp, col, val, x):
 REF_AT_FULL_SIZE = ("p5_1024", "p27_128", "weblike_1m", "fem3_40")
 
 
-@pytest.mark.parametrize("tag", ["p5_1024", "p27_128", "powerlaw_1m", "weblike_1m", "fem3_40", "rmat_s20"])
-def test_full_size_digests_and_properties(hiplib, tag):
+# (tag, library options): the library's own choice of path for every case, and the GENERAL pipeline (no row classes, no
+# direct launches) for the two grid inputs whose default is the class path -- the reference's digests pin both
+@pytest.mark.parametrize("tag,opts", [("p5_1024", {}), ("p27_128", {}), ("powerlaw_1m", {}), ("weblike_1m", {}), ("fem3_40", {}), ("rmat_s20", {}),
+                                      ("p27_128", {"class_path": 0}), ("fem3_40", {"class_path": 0}),
+                                      ("p27_128", {"class_path": 0, "wave_first": 0, "lane_first": 0, "direct_bins": 0})],
+                         ids=lambda v: v if isinstance(v, str) else ("default" if not v else "-".join("%s%d" % kv for kv in v.items())))
+def test_full_size_digests_and_properties(hiplib, tag, opts):
     import torch
     from benchmark_spgemm_using_csr_amd import gallery, facade
     from benchmark_spgemm_using_csr_amd.dist import device_view
@@ -75,7 +80,11 @@ def test_full_size_digests_and_properties(hiplib, tag):
     bh = facade.bhsparse()
     assert bh.initPlatform(plats) == 0
     assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
+    for k_, v_ in opts.items():
+        assert bh.set_option(k_, v_) == 0
     assert bh.spgemm() == 0
+    if "class_path" in opts:                                 # (the general pipeline is what ran)
+        assert "numeric_class" not in [s["name"] for s in bh.kernel_stats() if s["launches"] > 0]
     if stencil == "rmat":                                    # (the multiply has enough such rows for the window kernels to be chosen)
         assert "b_windows" in [s["name"] for s in bh.kernel_stats()]
     nnzC = bh.get_nnzC()
@@ -261,3 +270,31 @@ def test_webbase_1m_from_file(hiplib, oracle):
     res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
     assert res["ok"], res
     print("webbase-1M: nnzCt=%d nnzC=%d" % (info["nnzCt"], info["nnzC"]))
+
+
+def test_nnz_overflow_is_an_error_code(hiplib):
+    """nnz(C) beyond int32 (the reference's index type, bhsparse.h:367,431): poisson27pt 260^3 squared has (5 * 260 - 6)^3 =
+    2 169 112 376 entries.  The multiply must stop with BHS_ERR_NNZ_OVERFLOW behind its symbolic half -- before any array
+    of C is allocated (the inputs are 11.4 GB; C would be 26 GB)."""
+    import torch
+    from benchmark_spgemm_using_csr_amd import gallery, facade
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 40 GB of free device memory")
+    N = 260
+    Bp, Bj = gallery.poisson_csr_torch("poisson27pt", N, N, N, device=dev)
+    Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
+    m = Bp.numel() - 1
+    assert (5 * N - 6) ** 3 > 2 ** 31 - 1
+    plats = [False] * facade.NUM_PLATFORMS
+    plats[facade.BHSPARSE_HIP] = True
+    for opts in ({}, {"class_path": 0}):
+        bh = facade.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        assert bh.initData_device(m, m, m, Bj.numel(), Bx, Bp, Bj, Bj.numel(), Bx, Bp, Bj) == 0
+        for k_, v_ in opts.items():
+            assert bh.set_option(k_, v_) == 0
+        assert bh.spgemm() == facade._lib.BHS_ERR_NNZ_OVERFLOW
+        assert bh.free_mem() == 0
+        assert bh.freePlatform() == 0

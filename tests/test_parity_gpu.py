@@ -911,6 +911,43 @@ def test_repeated_spgemm_and_data_swap(oracle):
     assert bh.freePlatform() == 0
 
 
+@pytest.mark.gpu
+def test_two_handles_back_to_back_on_the_general_pipeline(oracle):
+    """the one-pass scan of rowPtrC (k_scan_onepass) takes a tile word whose epoch matches for published.  A
+    new handle starts at the same epoch as the one before it and may be handed the very memory that handle's scan left
+    its words in: create, multiply, destroy, create, multiply on DIFFERENT matrices of more than 8192 rows (several scan
+    tiles), general pipeline, and compare rowPtrC / the whole product."""
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    rng = np.random.default_rng(77)
+    cases = []
+    for m, per in ((40000, 6), (52000, 9), (40000, 4)):
+        c = np.sort((np.arange(m)[:, None] + rng.integers(-3000, 3000, (m, per))) % m, axis=1)
+        keep = np.ones(c.shape, bool)
+        keep[:, 1:] = c[:, 1:] != c[:, :-1]
+        rp = np.zeros(m + 1, np.int32)
+        np.cumsum(keep.sum(axis=1), out=rp[1:])
+        col = c[keep].astype(np.int32)
+        val = rng.integers(1, 10, len(col)).astype(np.float64)
+        cases.append((m, rp, col, val))
+    for rep in range(2):
+        for m, rp, col, val in cases:
+            bh = bhmod.bhsparse()
+            assert bh.initPlatform(plats) == 0
+            assert bh.set_option("class_path", 0) == 0
+            Cp = np.zeros(m + 1, np.int32)
+            assert bh.initData(m, m, m, len(col), val, rp, col, len(col), val, rp, col, Cp) == 0
+            assert bh.spgemm() == 0
+            nnzC = bh.get_nnzC()
+            Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+            assert bh.get_C(Cj, Cx) == 0
+            ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+            assert np.array_equal(ref[0], Cp)
+            assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=1e-12)["ok"]
+            assert bh.free_mem() == 0
+            assert bh.freePlatform() == 0
+
+
 def test_errors_are_codes_not_exceptions():
     plats = [False] * bhmod.NUM_PLATFORMS
     plats[bhmod.BHSPARSE_HIP] = True
