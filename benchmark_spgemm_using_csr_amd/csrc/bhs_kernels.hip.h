@@ -69,6 +69,17 @@ __device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA, int qv, i
     return (b == 1) ? 2 : b;        // 0 < v <= upper[2] that did not qualify for the quad bin
 }
 
+// Stores of C in the general pipeline's kernels: written once, read by nobody here.  BHS_GEN_NT 1: non-temporal.
+template <typename T>
+__device__ __forceinline__ void gen_store_c(T* p, T v)
+{
+#if BHS_GEN_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // s_waitcnt immediate (gfx9 encoding): vmcnt(0), expcnt and lgkmcnt left at their maxima (no wait)
 constexpr int kWaitVm0 = 0x0F70;
 

@@ -17,6 +17,7 @@
 #undef BHS_WPB
 #undef BHS_XCD_CHUNK
 #undef BHS_NT_STORES
+#undef BHS_GEN_NT
 #undef BHS_DEFER_MUL
 #undef BHS_UNIFORM
 #undef BHS_WAVE_ATTR
@@ -63,6 +64,9 @@
 #endif
 #ifndef BHS_NT_STORES      // non-temporal stores of C in the wave kernels (measured: no gain)
 #define BHS_NT_STORES 0
+#endif
+#ifndef BHS_GEN_NT      // general pipeline (lane, quad, wave kernels): non-temporal stores of C
+#define BHS_GEN_NT 0
 #endif
 #ifndef BHS_DEFER_MUL      // numeric wave kernel: 1 valB and the A value stay in registers until the batch is inserted; 2 the A entry index instead; 0 multiply behind the load
 #define BHS_DEFER_MUL 1

@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
                 const int r = pass * RPP + lane / S, e = lane % S;
                 if (e < sN[w][r]) {
                     const long long o = (long long)sOut[w][r] + e;
-                    Cj[o] = sCol[w][r * SP + e];
-                    Cx[o] = sVal[w][r * SP + e];
+                    gen_store_c(&Cj[o], sCol[w][r * SP + e]);
+                    gen_store_c(&Cx[o], sVal[w][r * SP + e]);
                 }
             }
             wave_sync();

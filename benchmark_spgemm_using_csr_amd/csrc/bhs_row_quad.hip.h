@@ -220,8 +220,8 @@ __global__ __launch_bounds__(64) void k_row_quad(
                     unsigned slot;
                     if constexpr (PACK32) { c = (int)(x1[0] >> LOG2TS); slot = x1[0] & 63u; }
                     else { c = (int)(x1[0] >> 32); slot = (unsigned)x1[0]; }
-                    Cj[outBase + l16] = c;
-                    Cx[outBase + l16] = (value_t)sm.vals[g][slot];
+                    gen_store_c(&Cj[outBase + l16], c);
+                    gen_store_c(&Cx[outBase + l16], (value_t)sm.vals[g][slot]);
                 }
             } else {
                 packed_t x[4];
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(64) void k_row_quad(
                         unsigned slot;
                         if constexpr (PACK32) { c = (int)(x[e] >> LOG2TS); slot = x[e] & 63u; }
                         else { c = (int)(x[e] >> 32); slot = (unsigned)x[e]; }
-                        Cj[outBase + r] = c;
-                        Cx[outBase + r] = (value_t)sm.vals[g][slot];
+                        gen_store_c(&Cj[outBase + r], c);
+                        gen_store_c(&Cx[outBase + r], (value_t)sm.vals[g][slot]);
                     }
                 }
             }

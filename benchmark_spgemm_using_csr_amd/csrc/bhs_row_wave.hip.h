@@ -219,8 +219,8 @@ __device__ __forceinline__ void block_sort_and_store(int* keys, const acc_t* val
     for (int e = 0; e < E; ++e) {
         const int r = i0 + e;
         if (r < uniq) {
-            Cj[outBase + r] = (int)(x[e] >> 32);
-            Cx[outBase + r] = (value_t)vals[(unsigned)x[e]];
+            gen_store_c(&Cj[outBase + r], (int)(x[e] >> 32));
+            gen_store_c(&Cx[outBase + r], (value_t)vals[(unsigned)x[e]]);
         }
     }
 }
@@ -249,8 +249,8 @@ __device__ __forceinline__ void wave_sort_and_store(const T* packed, const acc_t
             __builtin_nontemporal_store(col, &Cj[outBase + r]);
             __builtin_nontemporal_store((value_t)vals[slot], &Cx[outBase + r]);
 #else
-            Cj[outBase + r] = col;
-            Cx[outBase + r] = (value_t)vals[slot];
+            gen_store_c(&Cj[outBase + r], col);
+            gen_store_c(&Cx[outBase + r], (value_t)vals[slot]);
 #endif
         }
     }
@@ -655,8 +655,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, wave_min_waves(TS, NUM)) void 
                 }
                 for (int r = lane; r < uniq; r += 64) {
                     const packed_t e = sm.packed[r];
-                    Cj[outBase + r] = PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32);
-                    Cx[outBase + r] = (value_t)sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e];
+                    gen_store_c(&Cj[outBase + r], PACK32 ? (int)(e >> LOG2TS) : (int)((unsigned long long)e >> 32));
+                    gen_store_c(&Cx[outBase + r], (value_t)sm.vals[PACK32 ? (unsigned)(e & ((1u << LOG2TS) - 1)) : (unsigned)e]);
                 }
             }
         }

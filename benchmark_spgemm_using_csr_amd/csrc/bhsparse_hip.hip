@@ -25,6 +25,7 @@
 #include "bhs_class.hip.h"
 #include "bhs_class_wg.hip.h"
 #include "bhs_class_ring.hip.h"
+#include "bhs_class_fused.hip.h"
 #include "bhs_class_big.hip.h"
 
 #include <algorithm>
@@ -158,7 +159,7 @@ struct bhs_handle {
     int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
     int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
     unsigned scanEpoch = 0;              // tag of this multiply's tile words
-    int classHeadsOn = 1;                // classify only the rows that differ from the row before them (k_class_heads), hand the classes on
+    int classHeadsOn = 2;                // 2: one pass per matrix (k_class_fused: the wave that finds a row differing from the row before it takes it through the class table itself); 1: rounds 3-4's three launches (k_class_heads, k_class_rows on its lists, k_class_propagate); 0: every row through the table
     int classNumeric = 2;                // numeric kernel of the class path: 2 round 5's ring kernel (bhs_class_ring.hip.h) where its LDS fits, 1 round 4's (bhs_class_wg.hip.h), 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
@@ -1343,7 +1344,10 @@ int symbolic_class(bhs_handle* h)
         constexpr bool IS_A = decltype(isA)::value != 0;
         return class_dispatch(G, class_entries_per_lane(G, maxRow), [&](auto gc, auto ec) {
             constexpr int GG = decltype(gc)::value, E = decltype(ec)::value;
-            if (h->classHeadsOn) {
+            if (h->classHeadsOn >= 2) {
+                hipLaunchKernelGGL((k_class_fused<IS_A, GG, E>), dim3(heads_grid(n, GG)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out,
+                                   tab, cstats, (long long)(IS_A ? h->nnzA : h->nnzB), rng, period);
+            } else if (h->classHeadsOn) {
                 hipLaunchKernelGGL((k_class_heads<IS_A, GG, E>), dim3(heads_grid(n, GG)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out,
                                    headsL, nHeads, heads_cap(n, GG), rng, period);
                 hipLaunchKernelGGL((k_class_rows<IS_A, GG, E>), dim3(rowsGridList, kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb,
@@ -1361,7 +1365,7 @@ int symbolic_class(bhs_handle* h)
     if (rc != BHS_SUCCESS) return rc;
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
-    h->stats[ep->stat].launches += h->classHeadsOn ? 6 : 2;
+    h->stats[ep->stat].launches += h->classHeadsOn == 1 ? 6 : 2;
     h->stats[ep->stat].rows += (int64_t)m + k;
     BHS_HIP(hipEventRecord(h->ev[1], h->stream));
     BHS_TRY(timed_begin(h, "class_patterns", &ep));
@@ -2355,7 +2359,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "class_heads")) { h->classHeadsOn = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_heads")) { h->classHeadsOn = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_min_products")) { h->classMinProducts = (int)std::max<int64_t>(0, value); return BHS_SUCCESS; }
     if (!strcmp(key, "merge_bitmap_bins")) { h->mergeBitmapBins = value != 0; return BHS_SUCCESS; }
