@@ -545,6 +545,8 @@ RingLds class_ring_lds(bhs_handle* h)
 // (on h->stream, before the bins fork: every bin's stream waits for it)
 int ensure_b_windows(bhs_handle* h)
 {
+    // (rebuilt by every multiply that uses it, 0.12 ms: borrowed arrays may change between multiplies -- every other hint kept
+    // from bhs_set_data time is verified on the device where it is used, a stale index of B's windows could not be)
     if (h->ps.bWinBuilt) return BHS_SUCCESS;
     BHS_TRY(ensure(h, h->bWinTab, (kWwBuckets + kWwTabInts) * sizeof(int)));
     BHS_TRY(ensure(h, h->bWin, (size_t)std::max(h->k, 1) * (size_t)kWwStride * sizeof(unsigned short)));
@@ -1886,7 +1888,7 @@ int finish_set_data(bhs_handle* h)
         // (measured on poisson27pt n^3 against 64 rows: n = 96 -8 %, 110 -6 %, 160 -4 %, 200 -4 %, 128 -1 %; n = 100, whose
         // line ends in half a run, +1 %; n = 72, 1.7 lines per wave, +3 %)
         int line = hscan[5];
-        while (line < 48) line *= 2;
+        while (line < 48 && h->m % (2 * line) == 0) line *= 2;      // (short lines: two, four at a time -- still a whole number of them)
         const int whole = (line + kClassRun - 1) / kClassRun * kClassRun;
         if (line <= 256 && (whole - line) * 50 <= line && h->m / line >= 32LL * h->numCU) h->lineA = line;
     }
@@ -2330,7 +2332,10 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     }
     if (!strcmp(key, "no_pack32")) { h->noPack32 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "wg_per_cu")) { h->wgPerCU = (int)value; return BHS_SUCCESS; }
-    if (!strcmp(key, "class_super_rows")) { h->classSuperRows = (int)std::max<long long>(0, std::min<long long>(value, 1 << 15)); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_super_rows")) {                          // (whole runs of round 4's ring kernel)
+        h->classSuperRows = (int)std::max<long long>(0, std::min<long long>(value, 1 << 15)) / kClassRun * kClassRun;
+        return BHS_SUCCESS;
+    }
     if (!strcmp(key, "spa")) { h->useSpa = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "small_b")) { h->allowSmallB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "wave_first")) { h->waveFirst = value != 0; return BHS_SUCCESS; }

@@ -19,6 +19,8 @@
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <cerrno>
+#include <cstring>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -194,16 +196,31 @@ static int rank_main(const CsrHost &A, const CsrHost &B, bool *platforms, int wa
 static int run_multi(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const Options &opt)
 {
     const int world = opt.gpus, m = A.num_rows;
-    cout << " A: ( " << m << " by " << A.num_cols << ", nnz = " << A.num_entries << " ) " << endl;
-    cout << " B: ( " << B.num_rows << " by " << B.num_cols << ", nnz = " << B.num_entries << " ) " << endl;
+    const bool parent = opt.rank < 0;                             // (a rank's own process prints nothing of this again)
+    if (parent) {
+        cout << " A: ( " << m << " by " << A.num_cols << ", nnz = " << A.num_entries << " ) " << endl;
+        cout << " B: ( " << B.num_rows << " by " << B.num_cols << ", nnz = " << B.num_entries << " ) " << endl;
+    }
     vector<int> starts(world + 1);
     int err = bhs_dist_partition_rows(m, A.row_offsets.data(), A.column_indices.data(), B.row_offsets.data(), world,
                                       starts.data());
     if (err != BHSPARSE_SUCCESS) return err;
-    cout << " row blocks (balanced by products):";
-    for (int r = 0; r <= world; ++r) cout << " " << starts[r];
-    cout << endl;
-    if (opt.rank >= 0) return rank_main(A, B, platforms, warmups, opt, world, opt.rank, starts, opt.idfile);   // a rank's own process
+    if (parent) {
+        cout << " row blocks (balanced by products):";
+        for (int r = 0; r <= world; ++r) cout << " " << starts[r];
+        cout << endl;
+    }
+    if (!parent) return rank_main(A, B, platforms, warmups, opt, world, opt.rank, starts, opt.idfile);   // a rank's own process
+    // The ranks are fresh images of this program started with fork + exec.  Under a tool that is preloaded into this process
+    // and initialises the GPU before main (rocprofv3's library does) that exec is one from a process with a live GPU
+    // runtime -- what the pool's boxes refuse: say so instead of reporting a rank failure.
+    for (const char *var : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"}) {
+        const char *v = getenv(var);
+        if (v && *v) {
+            cerr << "-gpus starts one process per GPU by exec; not under a preloaded tool (" << var << " is set). Profile a rank: -gpus N -rank r -idfile f" << endl;
+            return -24;
+        }
+    }
     char idfile[64];
     snprintf(idfile, sizeof(idfile), "/tmp/bhs_dist_id_%d", (int)getpid());
     remove(idfile);
@@ -223,6 +240,7 @@ static int run_multi(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const
             static char o1[] = "-rank", o2[] = "-idfile";
             av.push_back(o1); av.push_back(rbuf); av.push_back(o2); av.push_back(idfile); av.push_back(nullptr);
             execv("/proc/self/exe", av.data());
+            fprintf(stderr, "exec of rank %d failed: %s\n", r, strerror(errno));
             _exit(127);
         }
         kids.push_back(pid);
