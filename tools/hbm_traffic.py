@@ -36,7 +36,7 @@ def stat_name(kk):
     mt = re.search(r"k_row_wave<(\d+), \d+, (true|false)", kk)
     if mt:
         return "%s_wave<%s>" % ("numeric" if mt.group(2) == "true" else "symbolic", mt.group(1))
-    if "k_class_numeric" in kk:
+    if "k_class_numeric" in kk or "k_class_ring" in kk:
         return "numeric_class"
     mt = re.search(r"k_row_lane<(\d+), (true|false)", kk)
     if mt:
@@ -62,11 +62,11 @@ for kk, d in sorted(agg.items()):
     if n and have_r and have_w:
         out[n] = int(e["read_bytes"] + e["write_bytes"])
         out[n + " (read, write)"] = [int(e["read_bytes"]), int(e["write_bytes"])]
-    if have_r and ("k_check_sorted" in kk or "k_class_heads<false" in kk):
+    if have_r and ("k_check_sorted" in kk or "k_class_heads<false" in kk or "k_class_fused<false" in kk):
         check[kk + ": read / (4 nnzB + 4 (k + 1))"] = round(e["read_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
         if e["fetch_size_bytes"]:
             check[kk + ": FETCH_SIZE / same"] = round(e["fetch_size_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
-    if have_w and "k_class_numeric" in kk:
+    if have_w and ("k_class_numeric" in kk or "k_class_ring" in kk):
         check[kk + ": written / (12 nnzC)"] = round(e["write_bytes"] / (12.0 * nnzC), 4)
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 doc = {"_comment": "memory-side bytes per launch (tools/hbm_traffic.py): 128/64/32-byte read requests and 64/32-byte write requests "

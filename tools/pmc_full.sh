@@ -13,4 +13,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SA
   i=$((i+1))
   timeout 90 rocprofv3 --kernel-trace --pmc $set -d $out/pmc$i -o p --output-format csv -- python3 $ROOT/tools/run_case.py p27_128 > /dev/null 2> $out/p$i.err || echo "pass $i ($set) failed"
 done
-cd $ROOT; python3 tools/pmc_summary.py $out | grep -A40 "k_class_numeric" | grep -v "^   _" | head -48
+cd $ROOT; python3 tools/pmc_summary.py $out | grep -A40 "k_class_numeric\|k_class_ring" | grep -v "^   _" | head -48
