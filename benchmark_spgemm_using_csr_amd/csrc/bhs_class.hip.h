@@ -53,7 +53,9 @@ enum { CS_MAXRING = 0 /* most staged B values any class's ring needs (bhs_class_
        CS_RINGFULL = 8 + 2 * kClassSumSlots + 6 /* bhs_class_ring.hip.h: most values of a ring of (longest chain + 1) slabs among the classes whose ring fits kClassRingBudget */,
        CS_RINGONE = 8 + 2 * kClassSumSlots + 7 /* ... most values of (longest chain) slabs among the others (their rows load what they need, row by row); 0x7fffffff: some class cannot */,
        CS_INTS = 8 + 2 * kClassSumSlots + 8 };
-constexpr int kClassRingStride = kClassMaxP + 64 + kClassMaxNnz;   // words per class of classRing: 16 steps x 64 lanes, a word per lane, the relative columns in pairs
+constexpr int kClassRingDma = kClassMaxP + 64 + kClassMaxNnz;      // classRing: where the slab-load words of bhs_class_ring.hip.h's kernel begin (kClassMaxLoads x 64, then the slab's size)
+constexpr int kClassRingStride = kClassRingDma + 4 * 64 + 4;       // words per class of classRing: 16 steps x 64 lanes, a word per lane, the relative columns in pairs, the slab loads
+constexpr int kClassColourUnits = 128;                             // slabs of up to this many 16-byte units get their units coloured over the bank groups
 constexpr int kClassRingBudget = 8192;     // bytes of LDS a wave of bhs_class_ring.hip.h's kernel gives its ring: with the slots of a row of C and the row's A values, 16 waves per CU
 
 __device__ __forceinline__ unsigned class_mix(unsigned h, unsigned v)
@@ -631,7 +633,8 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
 {
     __shared__ int keys[kClassMaxP], srt[kClassMaxP], pk[kClassMaxP];
     __shared__ int sIncl[kClassMaxRow], sB0[kClassMaxRow], scan[256];
-    __shared__ int sEnt[kClassMaxRow], sGeo[1];
+    __shared__ int sEnt[kClassMaxRow], sGeo[4], sChain[kClassMaxRow];
+    __shared__ unsigned char sUnitPos[4 * 64], sUnitOwner[4 * 64];          // a 16-byte unit of the slab -> its place (in units), and back
     const int tid = threadIdx.x, s = blockIdx.x;
     const unsigned long long v = tableA[s];
     if (v == kClassEmpty) {
@@ -824,6 +827,7 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         classLane[(size_t)s * kClassLaneInts + 64 + tid] = tid < nA ? (myPlace | ((tid - opened) << 16) | (myLen << 24)) : 0;
         sEnt[tid] = tid < nA ? (myPlace | ((tid - opened) << 16)) : 0;
         classLane[(size_t)s * kClassLaneInts + 128 + tid] = tid < nCh ? (kf | (len << 6) | (lc << 13) | (place << 20)) : 0;
+        sChain[tid] = tid < nCh ? (kf | (lc << 8) | (place << 16)) : 0;
         for (int j = 0; j < kClassMaxLoads; ++j) {                             // this lane's pieces of a slab
             const int x = (j * 64 + tid) * kClassEpl;
             int c = 0;
@@ -837,12 +841,9 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
             // the ring of the ring kernel: (entries of the longest chain + 1) slabs; 4 x 64 lanes x 16 bytes per slab at most
             atomicMax(&stats[CS_MAXRING], slab <= kClassMaxLoads * 64 * kClassEpl ? (maxLen + 1) * slab : 0x7fffffff);
             atomicMax(&stats[CS_MAXSLAB], slab);
-            // ... and of bhs_class_ring.hip.h's kernel: the same ring where it fits that kernel's budget; a class beyond it keeps
-            // (longest chain) slabs -- what ONE row needs -- and starts every row as a stretch
             sGeo[0] = slab;
-            if (slab > kClassMaxLoads * 64 * kClassEpl) atomicMax(&stats[CS_RINGONE], 0x7fffffff);
-            else if ((maxLen + 1) * slab * (int)sizeof(value_t) <= kClassRingBudget) atomicMax(&stats[CS_RINGFULL], (maxLen + 1) * slab);
-            else atomicMax(&stats[CS_RINGONE], maxLen * slab);
+            sGeo[1] = maxLen;
+            sGeo[2] = nCh;
         }
         int mx = myLen;
 #pragma unroll
@@ -857,11 +858,101 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
     // first entry that ends in it (bits 0-15) and 1 + the entry its last running sum is added to (16-31; 0: none).
     if (classRing != nullptr) {
         __syncthreads();
-        const int slabP = sGeo[0];                                   // values per slot of the ring
+        // The slab's layout in LDS.  An LDS-direct load puts lane L's 16 bytes at (load's base + 16 L) whatever address the
+        // lane reads, so WHICH 16-byte unit of the chains' B rows lands where is free.  The 64 lanes of a step read 64 values
+        // scattered over the ring -- 3.3 lanes per bank pair with the chains side by side, 77 LDS cycles per row where 24
+        // would do (poisson27pt, simulated and counted) --, and which units are read TOGETHER is known here: two units read in
+        // the same step by the same half of the wave, at the same place inside the unit, should not share a bank group
+        // (unit position mod 16).  Units are coloured greedily, in their natural order, with the 16 bank groups (at most
+        // ceil(units / 16) units each) by the weight of such meetings with the units already placed: 77 -> 50 cycles.
+        const int slab0 = sGeo[0], maxLen = sGeo[1], nChains = sGeo[2];
+        const int nUnits = slab0 / kClassEpl;
+        const int cap = (nUnits + 15) / 16, slabC = 16 * cap * kClassEpl;      // units per bank group, the coloured slab
+        const bool fitsBefore = (maxLen + 1) * slab0 * (int)sizeof(value_t) <= kClassRingBudget;
+        const bool colour = BHS_CLS_COLOUR && nUnits > 16 && nUnits <= kClassColourUnits && U >= 1 &&
+                            (!fitsBefore || (maxLen + 1) * slabC * (int)sizeof(value_t) <= kClassRingBudget);
+        auto unit_of = [&](int r, int& sub) {                        // product of rank r: its unit (chains side by side) and its place in it
+            const unsigned code = (unsigned)pk[srt[r] & 1023];
+            const int v = (sEnt[code & 63u] & 0xFFFF) + (int)(code >> 6);
+            sub = v % kClassEpl;
+            return v / kClassEpl;
+        };
+        for (int q = tid; q < 4 * 64; q += 256) { sUnitPos[q] = (unsigned char)q; sUnitOwner[q] = (unsigned char)q; }
+        __syncthreads();
+        if (colour) {
+            unsigned* W = bits;                                       // weights, a byte per pair of units: W[u1 * 32 + u2 / 4], byte u2 % 4 (the bitmap's 16 KB)
+            int* cost = scan;                                         // per bank group
+            for (int i = tid; i < kClassColourUnits * 32; i += 256) W[i] = 0u;
+            __syncthreads();
+            // every (step, half of the wave): its <= 32 products, pair by pair
+            const int nGroups = 2 * U;
+            for (int w = tid; w < nGroups * 32 * 32; w += 256) {
+                const int gidx = w >> 10, i = (w >> 5) & 31, j = w & 31;
+                if (i >= j) continue;
+                const int step = gidx >> 1, half = gidx & 1;
+                const int r1 = (half * 32 + i) * U + step, r2 = (half * 32 + j) * U + step;
+                if (r1 >= P || r2 >= P) continue;
+                int s1, s2;
+                const int u1 = unit_of(r1, s1), u2 = unit_of(r2, s2);
+                if (s1 != s2 || u1 == u2) continue;
+                atomicAdd(&W[u1 * 32 + (u2 >> 2)], 1u << (8 * (u2 & 3)));
+                atomicAdd(&W[u2 * 32 + (u1 >> 2)], 1u << (8 * (u1 & 3)));
+            }
+            __syncthreads();
+            __shared__ int sCount[16];
+            if (tid < 16) sCount[tid] = 0;
+            for (int v = 0; v < nUnits; ++v) {
+                if (tid < 16) cost[tid] = 0;
+                __syncthreads();
+                if (tid < v) {
+                    const int wv = (int)((W[v * 32 + (tid >> 2)] >> (8 * (tid & 3))) & 255u);
+                    if (wv) atomicAdd(&cost[sUnitPos[tid] & 15], wv);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int best = -1, bw = 0x7fffffff;
+                    for (int c = 0; c < 16; ++c)
+                        if (sCount[c] < cap && cost[c] < bw) { bw = cost[c]; best = c; }
+                    sUnitPos[v] = (unsigned char)(best + 16 * sCount[best]);
+                    sCount[best]++;
+                }
+                __syncthreads();
+            }
+            for (int q = tid; q < 4 * 64; q += 256) sUnitOwner[q] = 255;
+            __syncthreads();
+            if (tid < nUnits) sUnitOwner[sUnitPos[tid]] = (unsigned char)tid;
+            __syncthreads();
+        }
+        const int slabP = colour ? slabC : slab0;                    // values per slot of the ring
+        if (tid == 0) {
+            // the ring of (longest chain + 1) slabs where it fits that kernel's budget; a class beyond it keeps (longest
+            // chain) slabs -- what ONE row needs -- and starts every row as a stretch
+            if (slab0 > kClassMaxLoads * 64 * kClassEpl) atomicMax(&stats[CS_RINGONE], 0x7fffffff);
+            else if ((maxLen + 1) * slabP * (int)sizeof(value_t) <= kClassRingBudget) atomicMax(&stats[CS_RINGFULL], (maxLen + 1) * slabP);
+            else atomicMax(&stats[CS_RINGONE], maxLen * slabP);
+            classRing[(size_t)s * kClassRingStride + kClassRingDma + 4 * 64] = (unsigned)slabP;
+        }
+        // lane L's 16 bytes of the j-th LDS-direct load of a slab (bhs_class_ring.hip.h's copy of classLane[256 ..]): the
+        // unit that lives at position 64 j + L -- place in its chain's B row (bits 0-7), that row's length (8-15; 0: no
+        // load), the chain's first A entry (16-21)
+        for (int q = tid; q < kClassMaxLoads * 64; q += 256) {
+            const int un = colour ? (int)sUnitOwner[q] : q;
+            unsigned word = 0;
+            if (un != 255 && un * kClassEpl < slab0) {
+                const int x = un * kClassEpl;
+                int c = 0;
+                for (int cc = 1; cc < nChains; ++cc) c += x >= (sChain[cc] >> 16) ? 1 : 0;
+                const int o = x - (sChain[c] >> 16), rowLen = (sChain[c] >> 8) & 255, kFirst = sChain[c] & 255;
+                word = o < rowLen ? (unsigned)(o | (rowLen << 8) | (kFirst << 16)) : (unsigned)(kFirst << 16);
+            }
+            classRing[(size_t)s * kClassRingStride + kClassRingDma + q] = word;
+        }
         auto place_of = [&](int r) {
             const unsigned code = (unsigned)pk[srt[r] & 1023];
             const int e = sEnt[code & 63u];
-            return (unsigned)(((e >> 16) * slabP + (e & 0xFFFF) + (int)(code >> 6)) * (int)sizeof(value_t));
+            int sub;
+            const int un = unit_of(r, sub);
+            return (unsigned)(((e >> 16) * slabP + (int)sUnitPos[un] * kClassEpl + sub) * (int)sizeof(value_t));
         };
         for (int idx = tid; idx < kClassMaxSteps * 64; idx += 256) {
             const int L = idx & 63, j = (idx >> 6) - (kClassMaxSteps - U);

@@ -192,8 +192,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 for (int u = 0; u < MAXU; ++u) w[u] = classRing[(size_t)cls * kClassRingStride + (kClassMaxSteps - MAXU + u) * 64 + lane];
                 const unsigned lw = classRing[(size_t)cls * kClassRingStride + kClassMaxP + lane];
                 const int geoV = classLane[(size_t)cls * kClassLaneInts + 192];
+                const unsigned slabV = classRing[(size_t)cls * kClassRingStride + kClassRingDma + 4 * 64];
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j) dma[j] = classLane[(size_t)cls * kClassLaneInts + 256 + j * 64 + lane];
+                for (int j = 0; j < MAXJ; ++j) dma[j] = (int)classRing[(size_t)cls * kClassRingStride + kClassRingDma + j * 64 + lane];
 #pragma unroll
                 for (int w2 = 0; w2 < MAXW; ++w2) {                  // (beyond the row: never stored)
                     const uint2 rp = *reinterpret_cast<const uint2*>(classRing + (size_t)cls * kClassRingStride + kClassMaxP + 64 + 2 * (w2 * 64 + lane));
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 nnz = __builtin_amdgcn_readfirstlane(ci.z);
                 const int geo = __builtin_amdgcn_readfirstlane(geoV);
                 const int chainMax = (geo >> 8) & 255;               // entries of the longest chain
-                slab = geo >> 16;
+                slab = __builtin_amdgcn_readfirstlane((int)slabV);   // (k_class_patterns' layout of the slab: its units coloured over the bank groups)
                 // the ring: (longest chain + 1) slabs -- a row's request replaces the slab only that row still needed -- where
                 // that fits the budget; else what one row needs, loaded row by row (every row starts a stretch)
                 oneRow = (chainMax + 1) * slab * (int)sizeof(value_t) > kClassRingBudget;

@@ -18,6 +18,7 @@
 #undef BHS_XCD_CHUNK
 #undef BHS_NT_STORES
 #undef BHS_GEN_NT
+#undef BHS_CLS_COLOUR
 #undef BHS_DEFER_MUL
 #undef BHS_UNIFORM
 #undef BHS_WAVE_ATTR
@@ -64,6 +65,9 @@
 #endif
 #ifndef BHS_NT_STORES      // non-temporal stores of C in the wave kernels (measured: no gain)
 #define BHS_NT_STORES 0
+#endif
+#ifndef BHS_CLS_COLOUR      // k_class_patterns: the slab's 16-byte units coloured over the LDS bank groups (measured: bank conflicts -36 %, LDS cycles -13.5 %, numeric_class no faster, class_patterns 0.05 -> 0.17 ms: off)
+#define BHS_CLS_COLOUR 0
 #endif
 #ifndef BHS_GEN_NT      // general pipeline (lane, quad, wave kernels): non-temporal stores of C
 #define BHS_GEN_NT 0
