@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
         bhs_val2 ax = bhs_val2{(value_t)0, (value_t)0};
         const int e = 2 * lane;
         if (e < nE) {
-            if ((long long)base + e + 1 < nnzA) ax = *reinterpret_cast<const bhs_val2*>(Ax + base + e);
+            // (BHS_CLS_LAB & 8192: A's values, read once by one wave, not kept in the L2)
+            if ((long long)base + e + 1 < nnzA) ax = (BHS_CLS_LAB & 8192) ? __builtin_nontemporal_load(reinterpret_cast<const bhs_val2*>(Ax + base + e)) : *reinterpret_cast<const bhs_val2*>(Ax + base + e);
             else ax.x = Ax[base + e];
         }
         return ax;

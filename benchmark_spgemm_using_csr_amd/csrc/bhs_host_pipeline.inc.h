@@ -1,0 +1,751 @@
+// bhs_host_pipeline.inc.h -- one multiply: the class path and the general pipeline, stage by stage; the multiply in two halves
+// (A part of bhsparse_hip.hip's translation unit: included there, inside its unnamed namespace where that applies.)
+
+int pow2_at_least(double x, int lo, int hi)
+{
+    int v = lo;
+    while (v < hi && (double)v < x) v <<= 1;
+    return v;
+}
+
+// Concurrent bins: fork the side streams from `stream`, give every bin its own stream (round robin) and ticket
+// word, join them back.  Otherwise everything stays on `stream`, one kernel after another.
+int fork_bins(bhs_handle* h, const int* count, int nbins)
+{
+    h->ls = h->stream;
+    int used = 0;
+    for (int b = 1; b < nbins; ++b) used += count[b] > 0;
+    // forking and joining four streams costs ~70 us of event traffic: it pays for power-law matrices whose rows
+    // spread over many small bins, not for a stencil with one dominant bin
+    h->binsForked = h->concurrentBins == 1 || (h->concurrentBins == 2 && used >= 8);
+    if (!h->binsForked) return BHS_SUCCESS;
+    BHS_HIP(hipEventRecord(h->evFork, h->stream));
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i) BHS_HIP(hipStreamWaitEvent(h->binStream[i], h->evFork, 0));
+    return BHS_SUCCESS;
+}
+
+void bin_stream(bhs_handle* h, int bin)
+{
+    h->ticketSlot = S_TICKETS + bin;
+    h->ls = h->binsForked ? h->binStream[bin % bhs_handle::kBinStreams] : h->stream;
+}
+
+int join_bins(bhs_handle* h)
+{
+    h->ls = h->stream;
+    h->ticketSlot = S_TICKET;
+    if (!h->binsForked) return BHS_SUCCESS;
+    h->binsForked = false;
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i) {
+        BHS_HIP(hipEventRecord(h->evJoin[i], h->binStream[i]));
+        BHS_HIP(hipStreamWaitEvent(h->stream, h->evJoin[i], 0));
+    }
+    return BHS_SUCCESS;
+}
+
+// Stages 1 and 2 of the general pipeline: upper bound, symbolic bins and queues, the symbolic kernels.  Leaves the
+// per-row counts in Cp and tells stage 3 which choices it made.
+struct SymChoices {
+    bool noUpperBound = false, symDirect = false;
+    int laneK = 0, hubRows = 0;
+    BinSpec numSpec;
+};
+
+int symbolic_general(bhs_handle* h, SymChoices& out)
+{
+    const int m = h->m;
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    // ------------------------------------------------------------ stage 1
+    // lane bin (k_row_lane): matrices whose A rows are all tiny, B rows strictly ascending
+    int laneK = 0;
+    if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || (h->maxRowA <= kLaneMaxK && h->localA)))
+        laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
+    // hub bin: rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
+    const int hubMin = (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25))
+                           ? h->hubMin : 0;
+    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK, hubMin);
+    BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
+                                (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 8)) ? laneK : 0, hubMin);
+    BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
+    EventPair* ep;
+    h->cmpActive = false;
+    // (the undecided first multiply on a data set only measures the ratio: bins and symbolic pass stay plain)
+    const bool cmpRun = h->compressB && h->bSorted && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+                        (h->compressB == 2 || h->cmpState >= 0);
+    const bool cmpBins = cmpRun && (h->compressB == 2 || h->cmpState > 0);
+    if (cmpRun) {
+        BHS_TRY(ensure(h, h->cExt, sizeof(int2) * (size_t)std::max(h->k, 1)));
+        BHS_TRY(ensure(h, h->cPair, sizeof(int2) * (size_t)std::max(h->nnzB, 1)));
+        BHS_TRY(ensure(h, h->cLen, sizeof(int2) * (size_t)std::max(h->k, 1)));
+        BHS_TRY(ensure(h, h->symKey, sizeof(int) * (size_t)m));
+        BHS_TRY(timed_begin(h, "compress_b", &ep));
+        BHS_TRY(launch_compress_b(h));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += h->k;
+    }
+    const int* symKeys = cmpBins ? (const int*)h->symKey.p : (const int*)h->ub.p;
+    // "Lane-first": every row of A has <= laneK entries and every row of B is short, so every row can go through
+    // the lane-per-row symbolic kernel whatever its product count (the kernel has no table to overflow).  The
+    // upper-bound pass, its host round trip and the symbolic queue all disappear; the lane kernel writes ub[] and
+    // the product total on the side.
+    const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64 &&
+                           !h->specFailed;
+    // "Wave-first": maxRow(A) x maxRow(B) bounds every row's product count; when that bound fits a wave-per-row
+    // table and is not far above the average row (stencils, FEM meshes: poisson27pt 27 x 27 = 729 for every interior
+    // row), every row can run the symbolic wave kernel of that one table size -- again without upper-bound pass,
+    // host round trip or queue; the kernel delivers ub[] and the product total.
+    int wfBin = 0;
+    if (!laneFirst && h->waveFirst && h->directBins && !cmpRun && h->forcePath == 0 && h->maxTableLog2 >= 15 && !h->specFailed) {
+        const long long bound = (long long)h->maxRowA * h->maxRowB;
+        if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
+            for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
+    }
+    const bool noUpperBound = laneFirst || wfBin > 0;
+    if (noUpperBound) numSpec.hubMin = 0;     // (every row is bounded by maxRow(A) x maxRow(B), far below the hub bin)
+    int symCount[kMaxBins], symStart[kMaxBins + 1];
+    if (noUpperBound) {
+        BHS_HIP(hipMemsetAsync(small + S_CT_SLOTS, 0, sizeof(int) * 128, h->stream));
+        for (int b = 0; b < kMaxBins; ++b) { symCount[b] = 0; symStart[b] = 0; }
+        symStart[kMaxBins] = 0;
+        symCount[laneFirst ? kLaneBin : wfBin] = m;
+    }
+    bool symDirect = noUpperBound;
+    if (!noUpperBound) {
+    BHS_TRY(timed_begin(h, "upper_bound", &ep));
+    BHS_TRY(launch_upper_bound(h, symSpec, cmpBins, symSpec.upper[8]));
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches++;
+    h->stats[ep->stat].rows += m;
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    symStart[0] = 0;
+    for (int b = 0; b < kMaxBins; ++b) {
+        symCount[b] = hs[S_SYM_COUNT + b];
+        symStart[b + 1] = symStart[b] + (b == 0 ? 0 : symCount[b]);
+    }
+    unsigned long long tot;
+    memcpy(&tot, hs + S_TOTAL_CT, 8);
+    h->nnzCt = (long long)tot;
+    if (cmpRun) {
+        unsigned long long pairs;
+        memcpy(&pairs, hs + S_PAIRS, 8);
+        if (h->cmpState == 0) {
+            const double avgP = h->avgRowA * h->avgRowB;          // (the rule of bhs_set_data's count)
+            h->cmpState = ((avgP > 1536.0 && (double)pairs <= 0.6 * (double)h->nnzB) || (double)pairs <= 0.25 * (double)h->nnzB) ? 1 : -1;
+        }
+        h->cmpActive = cmpBins;
+        if (h->verbose > 1) printf("  [compress_b] %llu pairs for %d entries: %s\n", pairs, h->nnzB, h->cmpActive ? "used" : "not used");
+    }
+    // "Direct" stages: when EVERY row of the matrix sits in the lane bin or the quad bin (stencils: poisson5pt,
+    // 7pt, 9pt), that bin's queue would list the rows 0..m-1 in order -- the fill pass is skipped and the kernel
+    // derives its descriptors from rowPtrA (and rowPtrC) itself.
+    symDirect = h->directBins && (symCount[kLaneBin] == m || symCount[1] == m);
+    if (!symDirect) {
+    memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
+    BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+    {
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           symKeys, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
+                           small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
+                           (unsigned long long*)(small + S_SYM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+    }
+    }
+    }   // !noUpperBound
+    const int4* symQueue = symDirect ? nullptr : (const int4*)h->queue.p;
+    BHS_HIP(hipEventRecord(h->ev[1], h->stream));
+
+    // ------------------------------------------------------------ stage 2: symbolic
+    int (&symStat)[kMaxBins] = h->ps.symStat;
+    for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
+    BHS_TRY(fork_bins(h, symCount, kNumSymBins));
+    if (symCount[kLaneBin]) {
+        bin_stream(h, kLaneBin);
+        BHS_TRY(timed_begin(h, "symbolic_lane", &ep));
+        BHS_TRY(launch_row_lane<false>(h, laneK, symQueue ? symQueue + symStart[kLaneBin] : nullptr, symCount[kLaneBin], (int*)h->Cp.p,
+                                       laneFirst ? (int*)h->ub.p : nullptr,
+                                       laneFirst ? (unsigned long long*)(small + S_CT_SLOTS) : nullptr));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[kLaneBin];
+        symStat[kLaneBin] = ep->stat;
+    }
+    if (symCount[kHubBin]) {
+        bin_stream(h, kHubBin);
+        BHS_TRY(timed_begin(h, "symbolic_hub_rows", &ep));
+        int rc = launch_hub<false>(h, symQueue + symStart[kHubBin], symCount[kHubBin], (int*)h->Cp.p);
+        if (rc) { h->ls = h->stream; return rc; }
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[kHubBin];
+        symStat[kHubBin] = ep->stat;
+    }
+    for (int i = 1; i < kNumSymBins; ++i) {
+        const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
+        if (!symCount[b]) continue;
+        bin_stream(h, b);
+        BHS_TRY(timed_begin(h, kSymNames[b], &ep));
+        int rc = dispatch_bin<false>(h, kSymCfg[b], symQueue ? symQueue + symStart[b] : nullptr, symCount[b], (int*)h->Cp.p);
+        if (rc) { h->ls = h->stream; return rc; }
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += symCount[b];
+        symStat[b] = ep->stat;
+    }
+    BHS_TRY(join_bins(h));
+    BHS_HIP(hipEventRecord(h->ev[2], h->stream));
+
+    out.noUpperBound = noUpperBound;
+    out.symDirect = symDirect;
+    out.laneK = laneK;
+    out.hubRows = noUpperBound ? 0 : symCount[kHubBin];
+    out.numSpec = numSpec;
+    return BHS_SUCCESS;
+}
+
+// The classifier kernels are instantiated for G lanes per row and E entries per lane: E follows the longest row (a
+// hint from bhs_set_data; a longer row finds no class and sends the multiply to the general pipeline) over the G lanes,
+// as a quarter, a half or all of what the block's class cache holds; rows beyond kClassMaxRow: 64 lanes, 1 / 2 / 4 entries.
+int class_entries_per_lane(int G, int maxRow)
+{
+    if (G >= 64) return maxRow <= kClassMaxRow ? 1 : (maxRow <= 2 * kClassMaxRow ? 2 : 4);
+    const int full = kClassMaxRow / G;
+    if (full >= 4 && maxRow <= kClassMaxRow / 4) return full / 4;
+    if (full >= 2 && maxRow <= kClassMaxRow / 2) return full / 2;
+    return full;
+}
+template <typename F>
+int class_dispatch(int G, int E, F&& f)
+{
+    switch (G * 100 + E) {
+        case 404: return f(template_int<4>{}, template_int<4>{});
+        case 408: return f(template_int<4>{}, template_int<8>{});
+        case 416: return f(template_int<4>{}, template_int<16>{});
+        case 802: return f(template_int<8>{}, template_int<2>{});
+        case 804: return f(template_int<8>{}, template_int<4>{});
+        case 808: return f(template_int<8>{}, template_int<8>{});
+        case 1601: return f(template_int<16>{}, template_int<1>{});
+        case 1602: return f(template_int<16>{}, template_int<2>{});
+        case 1604: return f(template_int<16>{}, template_int<4>{});
+        case 3201: return f(template_int<32>{}, template_int<1>{});
+        case 3202: return f(template_int<32>{}, template_int<2>{});
+        case 6401: return f(template_int<64>{}, template_int<1>{});
+        case 6402: return f(template_int<64>{}, template_int<2>{});
+        case 6404: return f(template_int<64>{}, template_int<4>{});
+    }
+    return BHS_ERR_INTERNAL;
+}
+
+// Stages 1 and 2 by row classes (bhs_class.hip.h): classify the rows of B and A, work out every class's pattern,
+// write the per-row counts.  Everything is launched without a host round trip; stage 3's read-back tells whether every
+// row found a class (otherwise the multiply starts over on the general pipeline).
+int symbolic_class(bhs_handle* h)
+{
+    const int m = h->m, k = h->k;
+    int* small = (int*)h->small.p;
+    EventPair* ep;
+    BHS_TRY(ensure(h, h->classB, sizeof(int) * (size_t)std::max(k, 1)));
+    BHS_TRY(ensure(h, h->classC, sizeof(int) * (size_t)std::max(m, 1)));
+    BHS_TRY(ensure(h, h->classTab, sizeof(unsigned long long) * 2 * kClassSlots));
+    BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * kClassSlots));
+    BHS_TRY(ensure(h, h->classMap, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
+    BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
+    BHS_TRY(ensure(h, h->classRing, sizeof(unsigned) * (size_t)kClassSlots * kClassRingStride));
+    BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
+    BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
+    BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
+    // classes beyond the register kernels' tables are possible: their lists and the big numeric kernel (bhs_class_big.hip.h)
+    const bool bigPossible = h->maxRowA > kClassMaxRow || h->maxRowB > kClassMaxRow || (long long)h->maxRowA * h->maxRowB > kClassMaxP;
+    BHS_TRY(ensure(h, h->classBigIdx, sizeof(int) * kClassSlots));
+    if (bigPossible) BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
+    BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
+    const int nScanTiles = (m + kClassScanTile - 1) / kClassScanTile;           // (k_class_scan's tile words live in blockSum)
+    BHS_TRY(ensure(h, h->blockSum, sizeof(unsigned long long) * (size_t)std::max(nScanTiles, (int)(((long long)m + 1 + kScanTile - 1) / kScanTile)), true));
+    hipLaunchKernelGGL(k_class_reset, dim3(32), dim3(256), 0, h->stream, small, (int)S_ZERO_END, small + S_CT_SLOTS, (int)CS_INTS,
+                       (int*)h->classHeadCnt.p, 2 * 16 * kClassHeadSegs, (unsigned long long*)h->classTab.p, 2 * kClassSlots,
+                       (int*)h->classBigIdx.p, bigPossible ? kClassSlots : 0, (unsigned long long*)h->blockSum.p, nScanTiles);
+    BHS_HIP(hipGetLastError());
+    for (int b = 0; b < kMaxBins; ++b) h->ps.symStat[b] = h->ps.numStat[b] = -1;
+    unsigned long long* tabB = (unsigned long long*)h->classTab.p;
+    unsigned long long* tabA = tabB + kClassSlots;
+    int* cstats = small + S_CT_SLOTS;
+    BHS_TRY(timed_begin(h, "classify_rows", &ep));
+    // lanes per row: the average row, rounded up to a power of two
+    // Three launches per matrix: k_class_heads lists the rows that differ from the row before them (and notes for
+    // every other row which head it follows), k_class_rows classifies the listed rows, k_class_propagate hands the
+    // classes on.  (class_heads = 0: k_class_rows over all rows, round 2's form.)
+    auto rows_grid = [&](int n, int G) {
+        return (unsigned)std::max<long long>(1, std::min<long long>(((long long)n + kClassRowsBlock / G - 1) / (kClassRowsBlock / G), (long long)h->numCU * h->classGridMul));
+    };
+    auto heads_grid = [&](int n, int G) { const long long perBlock = (long long)(kClassHeadsBlock / 64) * class_head_piece(G); return (unsigned)std::max<long long>(1, ((long long)n + perBlock - 1) / perBlock); };
+    auto heads_cap = [&](int n, int G) { return (int)(((long long)heads_grid(n, G) + kClassHeadSegs - 1) / kClassHeadSegs) * (kClassHeadsBlock / 64) * class_head_piece(G); };    // slots per list
+    // A as a row block of a larger product (multi-GPU): only the rows of B that A points at need a class
+    const int* bRange = nullptr;
+    if ((long long)m * 2 <= (long long)k) {
+        int* rg = cstats + CS_RANGE;
+        BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)rg, 0x7fffffff, 1, h->stream));
+        BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)(rg + 1), -1, 1, h->stream));
+        const unsigned gr = (unsigned)std::max<long long>(1, std::min<long long>(((long long)h->nnzA + 255) / 256, (long long)h->numCU * 8));
+        hipLaunchKernelGGL(k_class_col_range, dim3(gr), dim3(256), 0, h->stream, (long long)h->nnzA, h->dAj, rg);
+        bRange = rg;
+    }
+    int* headsL = (int*)h->classHeads.p;                            // (one list area: B's is used up before A's is written)
+    int* nHeadsB = (int*)h->classHeadCnt.p;
+    int* nHeadsA = nHeadsB + 16 * kClassHeadSegs;
+    // (~2 entries per lane in flight; a data set with rows of more than kClassMaxRow entries: 64 lanes, 2 or 4 entries each)
+    const int GB = h->maxRowB > kClassMaxRow ? 64 : pow2_at_least(h->avgRowB / h->classPerLane, 4, 64);
+    const int GA = h->maxRowA > kClassMaxRow ? 64 : pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);
+    const int periodA = std::max(1, std::min(8, h->periodA)), periodB = std::max(1, std::min(8, h->periodB));
+    const unsigned rowsGridList = (unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs));
+    const unsigned propGrid = (unsigned)std::max<long long>(1, std::min<long long>(((long long)std::max(m, k) + 255) / 256, (long long)h->numCU * 8));
+    // one matrix: its heads, their classes, the classes handed on -- or, without heads, every row through the table
+    auto classify = [&](auto isA, int n, const int* Rp, const int* Rj, const int* cb, unsigned long long* tab, int* out,
+                        const int* rng, int* nHeads, int G, int maxRow, int period) {
+        constexpr bool IS_A = decltype(isA)::value != 0;
+        return class_dispatch(G, class_entries_per_lane(G, maxRow), [&](auto gc, auto ec) {
+            constexpr int GG = decltype(gc)::value, E = decltype(ec)::value;
+            if (h->classHeadsOn >= 2) {
+                hipLaunchKernelGGL((k_class_fused<IS_A, GG, E>), dim3(heads_grid(n, GG)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out,
+                                   tab, cstats, (long long)(IS_A ? h->nnzA : h->nnzB), rng, period);
+            } else if (h->classHeadsOn) {
+                hipLaunchKernelGGL((k_class_heads<IS_A, GG, E>), dim3(heads_grid(n, GG)), dim3(kClassHeadsBlock), 0, h->stream, n, Rp, Rj, cb, out,
+                                   headsL, nHeads, heads_cap(n, GG), rng, period);
+                hipLaunchKernelGGL((k_class_rows<IS_A, GG, E>), dim3(rowsGridList, kClassHeadSegs), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb,
+                                   tab, out, cstats, (const int*)nullptr, (const int*)headsL, (const int*)nHeads, heads_cap(n, GG));
+                hipLaunchKernelGGL(k_class_propagate, dim3(propGrid), dim3(256), 0, h->stream, n, out, rng);
+            } else
+                hipLaunchKernelGGL((k_class_rows<IS_A, GG, E>), dim3(rows_grid(n, GG)), dim3(kClassRowsBlock), 0, h->stream, n, Rp, Rj, cb, tab, out,
+                                   cstats, rng, (const int*)nullptr, (const int*)nullptr, 0);
+            return (int)BHS_SUCCESS;
+        });
+    };
+    int rc = classify(template_int<0>{}, k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, nHeadsB, GB, h->maxRowB, periodB);
+    if (rc == BHS_SUCCESS)
+        rc = classify(template_int<1>{}, m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, nHeadsA, GA, h->maxRowA, periodA);
+    if (rc != BHS_SUCCESS) return rc;
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += h->classHeadsOn == 1 ? 6 : 2;
+    h->stats[ep->stat].rows += (int64_t)m + k;
+    BHS_HIP(hipEventRecord(h->ev[1], h->stream));
+    BHS_TRY(timed_begin(h, "class_patterns", &ep));
+    hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
+                       h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
+                       (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p,
+                       (unsigned*)h->classRing.p, cstats);
+    if (bigPossible) {
+        const size_t smemBig = sizeof(int) * 2 * kClassBigMaxP;
+        int unused = 0;
+        BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(k_class_patterns_big), kClassBigPatThreads, smemBig, &unused));   // (raises its LDS limit)
+        hipLaunchKernelGGL(k_class_patterns_big, dim3(kClassSlots), dim3(kClassBigPatThreads), smemBig, h->stream, (const unsigned long long*)tabA,
+                           h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p, (int*)h->classBigIdx.p,
+                           (unsigned*)h->classBigMap.p, (int*)h->classRel.p, cstats);
+    }
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += bigPossible ? 2 : 1;
+    BHS_HIP(hipEventRecord(h->ev[2], h->stream));
+    return BHS_SUCCESS;
+}
+
+// restart: the same multiply starting over on another path (a refuted speculation, rows without a class): the
+// timers and kernel statistics of the abandoned attempt stay in -- it ran inside this multiply.
+int pipeline_symbolic(bhs_handle* h, bool restart = false)
+{
+    h->ls = h->stream;
+    const int m = h->m;
+    if (!restart) {
+        h->evUsed = 0;
+        for (auto& s : h->stats) { s.launches = 0; s.ms = 0; s.rows = s.products = s.nnz_out = s.nnzA_rows = 0; }
+        BHS_HIP(hipEventRecord(h->ev[0], h->stream));
+    }
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    h->nnzC = 0;
+    h->nnzCt = 0;
+    h->hasC = false;
+    h->rowPtrStaged = false;          // (an empty product returns early: the previous multiply's staging must not be read)
+    h->ps = bhs_handle::PipeState();
+
+    BHS_TRY(ensure(h, h->Cp, sizeof(int) * ((size_t)m + 1)));
+    if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
+        BHS_HIP(hipMemsetAsync(h->Cp.p, 0, sizeof(int) * ((size_t)m + 1), h->stream));
+        for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        h->hasC = true;
+        h->ps.open = true;
+        h->ps.empty = true;
+        return BHS_SUCCESS;
+    }
+    BHS_TRY(ensure(h, h->ub, sizeof(int) * (size_t)m));
+    BHS_TRY(ensure(h, h->queue, sizeof(int4) * (size_t)m));
+    const int nScanBlocks = (int)(((long long)m + 1 + kScanTile - 1) / kScanTile);
+    BHS_TRY(ensure(h, h->blockSum, sizeof(long long) * (size_t)nScanBlocks, true));
+
+    EventPair* ep;
+    SymChoices sc;
+    // Row classes first, for data sets whose rows are short on both sides (the hint from bhs_set_data time is
+    // verified on the device row by row)
+    // ... and long enough for the classification passes to pay (round 3's kernels, same box): poisson27pt (729 products
+    // per row) 4.85 -> 2.1 ms on the class kernels, poisson9pt 1024^2 (81) 0.57 -> 0.47 ms, poisson7pt 128^3 (49) 0.73 ->
+    // 0.78 ms, poisson5pt 1024^2 (25) 0.23 -> 0.42 ms: from class_min_products = 64 products per row on
+    const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+                          h->maxRowA <= kClassMaxRowBig && h->maxRowB <= kClassMaxRowBig &&
+                          (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
+                                                 // ... and enough of them: every block of the classifier meets every class once
+                                                 // (poisson27pt 51^3, 90 M products: 0.44 ms general, 0.41 ms by classes;
+                                                 // poisson9pt 512^2, 21 M: 0.20 against 0.25)
+                                                 (double)h->m * h->avgRowA * h->avgRowB >= 6e7));
+    if (useClass) {
+        BHS_TRY(symbolic_class(h));
+        sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)
+        sc.numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, true, 0, 0);
+    } else {
+        BHS_TRY(symbolic_general(h, sc));
+    }
+    const bool noUpperBound = sc.noUpperBound, symDirect = sc.symDirect;
+    const int laneK = sc.laneK;
+    const BinSpec& numSpec = sc.numSpec;
+
+    // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
+    BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
+    if (useClass) {
+        // one pass: every row's count from its class, scanned with look-back over the tiles before (k_class_scan)
+        const int nTiles = (m + kClassScanTile - 1) / kClassScanTile;
+        // (blockSum holds the tile words, cleared by k_class_reset)
+        hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(kClassScanBlock), 0, h->stream, m, (const int*)h->classC.p,
+                           (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
+                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS);
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches += 1;
+    } else {
+    if (h->scanOnePass) {
+        // one pass with look-back over the tiles before (k_scan_onepass); the tile words carry this multiply's epoch
+        const int nTiles = (m + kScan1Tile - 1) / kScan1Tile;
+        h->scanEpoch = (h->scanEpoch + 1) & 0x3FFFFu;
+        if (h->scanEpoch == 0) {                                    // (every 2^18 multiplies the words of 2^18 multiplies ago could match)
+            BHS_HIP(hipMemsetAsync(h->blockSum.p, 0, sizeof(unsigned long long) * (size_t)std::max(nTiles, 1), h->stream));
+            h->scanEpoch = 1;
+        }
+        hipLaunchKernelGGL(k_scan_onepass, dim3((unsigned)nTiles), dim3(kScan1Block), 0, h->stream, m, (int*)h->Cp.p, h->dAp,
+                           (unsigned long long*)h->blockSum.p, h->scanEpoch, small + S_SCAN_TICKET, (long long*)(small + S_TOTAL_C),
+                           small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches += 1;
+    } else {
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
+                       (long long*)h->blockSum.p, small + S_NUM_COUNT, numSpec, small + S_MAXCNT, (const int*)h->ub.p);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, h->stream, nScanBlocks,
+                       (long long*)h->blockSum.p, (long long*)(small + S_TOTAL_C));
+    hipLaunchKernelGGL(k_scan_apply, dim3(nScanBlocks), dim3(256), 0, h->stream, m, (int*)h->Cp.p,
+                       (const long long*)h->blockSum.p);
+    BHS_HIP(hipGetLastError());
+    BHS_TRY(timed_end(h, ep));
+    h->stats[ep->stat].launches += 3;
+    }
+    }
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    if (useClass) {
+        const int* cs = hs + S_CT_SLOTS;
+        if (cs[CS_FLAGS] || cs[CS_CLASSES] == 0) {
+            // a row without a class, or a class beyond the tables: this data set is for the general pipeline
+            h->classState = -1;
+            if (h->verbose > 1) printf("  [row classes: flags %d, %d classes: general pipeline]\n", cs[CS_FLAGS], cs[CS_CLASSES]);
+            return pipeline_symbolic(h, true);
+        }
+        // The class kernels take rows in stretches -- consecutive rows of one class; a matrix whose rows classify but
+        // each for itself (block-diagonal with dense blocks: every row of a block has its own relative pattern) makes
+        // them change class every row: 3.4 ms against 1.9 ms on the general pipeline for 2^20 rows in blocks of 4..32.
+        // More than a quarter of the rows through the table: this data set goes to the general pipeline (class_path = 2
+        // insists on the classes).
+        if (h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && (long long)cs[CS_HEADS] * 4 > (long long)m) {
+            h->classState = -1;
+            if (h->verbose > 1) printf("  [row classes: %d of %d rows start a stretch: general pipeline]\n", cs[CS_HEADS], m);
+            return pipeline_symbolic(h, true);
+        }
+        unsigned long long t = 0, v;
+        for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, cs + CS_SUMS + 2 * i, 8); t += v; }
+        h->nnzCt = (long long)t;
+        h->ps.useClass = true;
+        h->ps.classMaxP = cs[CS_MAXP];
+        h->ps.classMaxNnz = cs[CS_MAXNNZ];
+        h->ps.classMaxNA = cs[CS_MAXNA];
+        h->ps.classMaxLB = cs[CS_MAXLB];
+        h->ps.classMaxRing = cs[CS_MAXRING];
+        h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
+        h->ps.classMaxSlab = cs[CS_MAXSLAB];
+        h->ps.classBig = cs[CS_BIGCOUNT];
+        h->ps.classBigMaxP = cs[CS_BIGMAXP];
+        if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; slabs of <= %d values]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[CS_MAXSLAB]);
+    } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
+        unsigned long long t = 0, v;
+        for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
+        h->nnzCt = (long long)t;
+    }
+    long long nnzC;
+    memcpy(&nnzC, hs + S_TOTAL_C, 8);
+    if (hs[S_ERR] & 2) {
+        // The lane-first / wave-first launch was chosen from the row bounds seen at bhs_set_data time and the
+        // kernels found a row beyond them (borrowed arrays changed since): this multiply starts over on the
+        // general pipeline, which assumes nothing, and the data set stays there.
+        if (!noUpperBound || h->specFailed) return BHS_ERR_INTERNAL;
+        h->specFailed = true;
+        if (h->verbose > 1) printf("  [speculative direct launch refuted on the device: general pipeline]\n");
+        return pipeline_symbolic(h, true);
+    }
+    if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+    if (nnzC > 0x7fffffffLL) return BHS_ERR_NNZ_OVERFLOW;
+    h->nnzC = nnzC;
+    h->ps.noUpperBound = noUpperBound;
+    h->ps.symDirect = symDirect;
+    h->ps.laneK = laneK;
+    h->ps.numSpec = numSpec;
+    h->ps.maxCnt = hs[S_MAXCNT];
+    h->ps.hubRows = sc.hubRows;
+    for (int b = 0; b < kMaxBins; ++b) h->ps.fullCount[b] = hs[S_NUM_COUNT + b];
+    memcpy(h->ps.symSums, hs + S_SYM_SUMS, sizeof(h->ps.symSums));
+    if (h->extCj) {
+        if (nnzC > h->extCap) return BHS_ERR_ALLOC;
+    } else if (!h->lazyOut) {
+        BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
+        BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
+    }
+    BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+    h->rowPtrStaged = false;
+    if (h->wantHostRowPtr) {
+        // rowPtrC is final after the scan: ship it to pinned host memory on a second stream while the
+        // numeric kernels run (the reference does this D2H inside its timed region too, bhsparse_cuda.h:2787)
+        const size_t bytes = sizeof(int) * ((size_t)m + 1);
+        BHS_TRY(ensure_host_rowptr(h, bytes));
+        BHS_HIP(hipEventRecord(h->evScanDone, h->stream));
+        BHS_HIP(hipStreamWaitEvent(h->copyStream, h->evScanDone, 0));
+        BHS_HIP(hipMemcpyAsync(h->hostRowPtr, h->Cp.p, bytes, hipMemcpyDeviceToHost, h->copyStream));
+        BHS_HIP(hipEventRecord(h->evCopyDone, h->copyStream));
+        h->rowPtrStaged = true;
+    }
+    h->ps.open = true;
+    return BHS_SUCCESS;
+}
+
+// Stage 4 on the rows [r0, r1) of A / C.  A row range is the same multiply seen through shifted row pointers (the
+// kernels index rowPtrA / rowPtrC / ub / the pattern array by row), so the handle's views are shifted for the
+// duration of the call; bins and queues are rebuilt for the range.
+int numeric_stage(bhs_handle* h, int r0, int r1)
+{
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    if (h->ps.empty) return BHS_SUCCESS;
+    if (r0 < 0 || r1 > h->m || r0 > r1) return BHS_ERR_INVALID_ARG;
+    if (r0 == r1) return BHS_SUCCESS;
+    const bool full = r0 == 0 && r1 == h->m;
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    EventPair* ep;
+    const BinSpec& numSpec = h->ps.numSpec;
+    const int laneK = h->ps.laneK;
+    int (&numStat)[kMaxBins] = h->ps.numStat;
+    h->ls = h->stream;
+    if (h->ps.useClass) {
+        h->ps.rangesRun++;
+        BHS_TRY(timed_begin(h, "numeric_class", &ep));
+        if (h->ps.classBig) BHS_TRY(launch_class_numeric_big(h, r0, r1));
+        else if (h->classNumeric >= 2 && class_ring2_fits(h)) BHS_TRY(launch_class_ring(h, r0, r1));
+        else BHS_TRY(h->classNumeric && class_ring_fits(h) ? launch_class_numeric(h, r0, r1) : launch_class_numeric_atomic(h, r0, r1));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += r1 - r0;
+        if (full) { h->stats[ep->stat].products += h->nnzCt; h->stats[ep->stat].nnz_out += h->nnzC; h->stats[ep->stat].nnzA_rows += h->nnzA; }
+        return BHS_SUCCESS;
+    }
+    // ---- the range as a view
+    struct View {
+        bhs_handle* h; int m; const int* dAp; void *cp, *ub;
+        View(bhs_handle* h_, int r0_, int mR) : h(h_), m(h_->m), dAp(h_->dAp), cp(h_->Cp.p), ub(h_->ub.p)
+        {
+            h->m = mR;
+            h->dAp = dAp + r0_;
+            h->Cp.p = (int*)cp + r0_;
+            h->ub.p = (int*)ub + r0_;
+        }
+        ~View() { h->m = m; h->dAp = dAp; h->Cp.p = cp; h->ub.p = ub; }
+    } view(h, r0, r1 - r0);
+    const int m = r1 - r0;
+    int numCount[kMaxBins], numStart[kMaxBins + 1];
+    int maxCnt = h->ps.maxCnt;
+    if (full) {
+        for (int b = 0; b < kMaxBins; ++b) numCount[b] = h->ps.fullCount[b];
+    } else {
+        // bins of the range: histogram of its rows (one small round trip per range)
+        int* hr = hs + S_SMALL_INTS + 2 * kMaxBins;
+        BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));     // counts, starts, cursors
+        BHS_HIP(hipMemsetAsync(small + S_NUM_SUMS, 0, sizeof(unsigned long long) * 3 * kMaxBins, h->stream));
+        BHS_HIP(hipMemsetAsync(small + S_MAXCNT, 0, sizeof(int), h->stream));
+        const long long grid = std::min<long long>(((long long)m + 255) / 256, (long long)h->numCU * 4);
+        hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)grid), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
+                           numSpec, small + S_NUM_COUNT, small + S_MAXCNT, (const int*)h->ub.p);
+        BHS_HIP(hipGetLastError());
+        BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(hr + kMaxBins, small + S_MAXCNT, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipStreamSynchronize(h->stream));
+        for (int b = 0; b < kMaxBins; ++b) numCount[b] = hr[b];
+        maxCnt = hr[kMaxBins];
+    }
+    numStart[0] = 0;
+    for (int b = 0; b < kMaxBins; ++b) numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
+    bool numDirect = h->directBins && (numCount[kLaneBin] == m || numCount[1] == m);
+    // "Numeric-first": the longest row of C fits a wave-per-row table that is not oversized for the average row
+    // (poisson27pt: longest 125, average 121): every row runs that one kernel straight from rowPtrA / rowPtrC -- no
+    // queue, and the few short boundary rows no longer pay for kernels of their own.
+    if (!numDirect && h->waveFirst && h->directBins && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+        h->ps.hubRows == 0) {
+        int nb = 0;
+        for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
+        if (nb && maxCnt > 0 && (double)h->nnzC / std::max(view.m, 1) * 4.0 >= (double)numSpec.upper[nb]) {
+            for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
+            numStart[kMaxBins] = 0;
+            numCount[nb] = m;
+            numDirect = true;
+        }
+    }
+    if (!numDirect) {
+        memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
+        BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
+                           small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
+                           (unsigned long long*)(small + S_NUM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+    }
+    if (full) h->ps.numDirectFull = numDirect;
+    h->ps.rangesRun++;
+    const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
+    h->ps.midRows = h->ps.longRows = 0;
+    for (int b = 2; b < kNumNumBins; ++b)
+        if (bin_takes_lds_bitmap<true>(h, kNumCfg[b])) (kNumCfg[b].win ? h->ps.longRows : h->ps.midRows) += numCount[b];
+    for (int b = 2; b < kNumNumBins; ++b)
+        if (numCount[b] && numQueue && bin_takes_wave_window<true>(h, kNumCfg[b])) BHS_TRY(ensure_b_windows(h));
+    BHS_TRY(fork_bins(h, numCount, kNumNumBins));
+    if (numCount[kHubBin]) {
+        bin_stream(h, kHubBin);
+        BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));
+        BHS_TRY(launch_hub<true>(h, numQueue + numStart[kHubBin], numCount[kHubBin], (int*)h->Cp.p));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += numCount[kHubBin];
+        numStat[kHubBin] = ep->stat;
+    }
+    if (numCount[kLaneBin]) {
+        bin_stream(h, kLaneBin);
+        BHS_TRY(timed_begin(h, "numeric_lane", &ep));
+        BHS_TRY(launch_row_lane<true>(h, laneK, numQueue ? numQueue + numStart[kLaneBin] : nullptr, numCount[kLaneBin], (int*)h->Cp.p));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += numCount[kLaneBin];
+        numStat[kLaneBin] = ep->stat;
+    }
+    for (int i = 1; i < kNumNumBins; ++i) {
+        const int b = kNumNumBins - i;
+        if (!numCount[b]) continue;
+        // Neighbouring bins that all run the LDS-bitmap kernel (one workgroup per CU: two such kernels side by side
+        // only take CUs from each other, and the shorter bins' launch would trail behind) go as ONE queue, taken
+        // from its end so that the longest rows start first.
+        int lo = b, rows = numCount[b];
+        auto kernel_of = [&](int bb) { return !bin_takes_lds_bitmap<true>(h, kNumCfg[bb]) ? 0 : bin_takes_wave_window<true>(h, kNumCfg[bb]) ? (kNumCfg[bb].win ? 3 : 2) : 1; };
+        if (numQueue && h->mergeBitmapBins && kernel_of(b))
+            while (lo - 1 >= 2 && kernel_of(lo - 1) == kernel_of(b)) { --lo; rows += numCount[lo]; }
+        bin_stream(h, b);
+        BHS_TRY(timed_begin(h, kNumNames[b], &ep));
+        BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue ? numQueue + numStart[lo] : nullptr, rows, (int*)h->Cp.p, lo < b));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += rows;
+        for (int bb = lo; bb <= b; ++bb) { if (numCount[bb]) numStat[bb] = ep->stat; numCount[bb] = 0; }
+    }
+    BHS_TRY(join_bins(h));
+    return BHS_SUCCESS;
+}
+
+// End of a multiply: everything launched has run, errors raised on the device are collected, timers are read.
+int pipeline_finish(bhs_handle* h)
+{
+    if (!h->ps.open) return BHS_ERR_NOT_READY;
+    h->ps.open = false;
+    if (h->ps.empty) { for (int i = 0; i < 4; ++i) h->stageMs[i] = 0.0; return BHS_SUCCESS; }
+    int* small = (int*)h->small.p;
+    int* hs = h->hostSmall;
+    BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipEventRecord(h->ev[4], h->stream));
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+    const bool oneRange = h->ps.rangesRun == 1;
+    for (int b = 1; b < kMaxBins; ++b) {
+        unsigned long long v[3];
+        if (h->ps.symStat[b] >= 0) {
+            memcpy(v, h->ps.symSums + 3 * b, sizeof(v));
+            if (h->ps.symDirect) { v[0] = (unsigned long long)h->nnzCt; v[2] = (unsigned long long)h->nnzA; }   // no fill pass counted them
+            StatRec& r = h->stats[h->ps.symStat[b]];
+            r.products += (int64_t)v[0]; r.nnzA_rows += (int64_t)v[2];
+        }
+        if (h->ps.numStat[b] >= 0 && oneRange) {             // (per-bin sums of the last range only: reported for whole multiplies)
+            memcpy(v, hs + S_NUM_SUMS + 6 * b, sizeof(v));
+            if (h->ps.numDirectFull) { v[0] = (unsigned long long)h->nnzCt; v[1] = (unsigned long long)h->nnzC; v[2] = (unsigned long long)h->nnzA; }
+            StatRec& r = h->stats[h->ps.numStat[b]];
+            r.products += (int64_t)v[0]; r.nnz_out += (int64_t)v[1]; r.nnzA_rows += (int64_t)v[2];
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0;
+        BHS_HIP(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->stageMs[i] = ms;
+    }
+    for (size_t i = 0; i < h->evUsed; ++i) {
+        float ms = 0;
+        BHS_HIP(hipEventElapsedTime(&ms, h->evPool[i].a, h->evPool[i].b));
+        h->stats[h->evPool[i].stat].ms += ms;
+    }
+    h->hasC = true;
+    h->resCj = out_cj(h);
+    return BHS_SUCCESS;
+}
+
+int run_pipeline_impl(bhs_handle* h)
+{
+    BHS_TRY(pipeline_symbolic(h));
+    BHS_TRY(numeric_stage(h, 0, h->m));
+    return pipeline_finish(h);
+}
+
+// Every exit of the pipeline leaves the handle quiescent: an error taken while the bins of a stage are forked
+// onto the side streams would otherwise leave kernels queued there -- still writing Cp / Cj / the counters while
+// the next bhs_spgemm starts on `stream` -- and stale launch state (ls, ticket slot) behind.
+void quiesce(bhs_handle* h)
+{
+    for (int i = 0; i < bhs_handle::kBinStreams; ++i)
+        if (h->binStream[i]) (void)hipStreamSynchronize(h->binStream[i]);
+    if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    h->ls = h->stream;
+    h->ticketSlot = S_TICKET;
+    h->binsForked = false;
+    h->rowPtrStaged = false;
+}
+
+int run_pipeline(bhs_handle* h)
+{
+    const int rc = run_pipeline_impl(h);
+    if (rc != BHS_SUCCESS) { quiesce(h); h->ps.open = false; }
+    return rc;
+}
