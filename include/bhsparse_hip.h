@@ -234,12 +234,15 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     products / 512 entries per row of C) goes back to the general pipeline for good.
  *                     2: tried whatever the average; 0: never.
  *   "class_numeric"   numeric kernel of the classes whose product list fits a wave's registers (<= 64 entries per row
- *                     of A and B, <= 1024 products): 1 (default) the ring kernel (bhs_class_wg.hip.h: sums in
- *                     registers, B's values through a ring of slabs in LDS) wherever its LDS fits, 0 always the LDS-atomic
- *                     kernel of round 2.  Multiplies with bigger classes (several unknowns per grid node) run
- *                     bhs_class_big.hip.h whatever this says.
- *   "class_heads"     1 (default): only rows that differ from the row `period` rows before them are looked up in
- *                     the class table (period: sampled at bhs_set_data time, the unknowns per node); 0: every row
+ *                     of A and B, <= 1024 products): 2 (default) round 5's ring kernel (bhs_class_ring.hip.h: sums in
+ *                     registers, stored where an entry of C ends; B's values through a ring of slabs in LDS; 16 waves
+ *                     per CU) wherever its LDS fits, 1 round 4's ring kernel (bhs_class_wg.hip.h), 0 always the
+ *                     LDS-atomic kernel of round 2.  Multiplies with bigger classes (several unknowns per grid node)
+ *                     run bhs_class_big.hip.h whatever this says.
+ *   "class_heads"     2 (default): one pass per matrix -- the wave that finds a row differing from the row `period`
+ *                     rows before it takes it through the class table itself (bhs_class_fused.hip.h; period: sampled
+ *                     at bhs_set_data time, the unknowns per node); 1: rounds 3-4's three launches per matrix (list
+ *                     the rows that differ, classify the list, hand the classes on); 0: every row through the table
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),

@@ -737,6 +737,9 @@ def test_long_rows_bitmap_accumulators(oracle, n):
         assert np.array_equal(Cj, Cj2) and np.array_equal(Cx, Cx2)
 
 
+# (watchdog: the window kernels hand a ticket from lane 0 to the wave between two divergent regions; when the compiler once
+# folded the two, the kernel hung instead of failing -- a hang must fail THIS test, not stall the suite)
+@pytest.mark.timeout(120)
 @pytest.mark.parametrize("n", [2 ** 20, 300000, 70000])
 def test_wave_per_row_column_windows(oracle, n):
     """Rows of a few thousand entries of C, one wave each, column window by column window (bhs_row_window.hip.h; it
