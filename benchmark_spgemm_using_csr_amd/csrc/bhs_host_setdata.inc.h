@@ -72,16 +72,26 @@ int finish_set_data(bhs_handle* h)
     int2* longB = nullptr;
     const int logG = std::min(h->logL, 6);                      // lanes per row of B: its average length
     const long long sortGrid = std::max<long long>(1, std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16));
+    // (S_SORTED: positions of colIndB not above their predecessor, S_LONG_B: those of them that are first entries of rows;
+    // equal counts = every row strictly ascending.  h->sortedScan 0: round 2's row-by-row scan, flag in S_SORTED)
     auto check_sorted = [&]() -> int {
         BHS_HIP(hipMemsetAsync(small0 + S_SORTED, 0, sizeof(int), h->stream));
         BHS_HIP(hipMemsetAsync(small0 + S_LONG_B, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)sortGrid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
-                           small0 + S_SORTED, longB, small0 + S_LONG_B);
-        hipLaunchKernelGGL(k_check_sorted_long, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream,
-                           (const int2*)longB, (const int*)(small0 + S_LONG_B), h->dBp, h->dBj, small0 + S_SORTED);
+        if (h->sortedScan) {
+            const long long gf = std::max<long long>(1, std::min<long long>(((long long)h->nnzB + 1023) / 1024, (long long)h->numCU * 16));
+            const long long gs = std::max<long long>(1, std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 16));
+            hipLaunchKernelGGL(k_sorted_flat, dim3((unsigned)gf), dim3(256), 0, h->stream, (long long)h->nnzB, h->dBj, small0 + S_SORTED);
+            hipLaunchKernelGGL(k_sorted_starts, dim3((unsigned)gs), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_LONG_B);
+        } else {
+            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)sortGrid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
+                               small0 + S_SORTED, longB, small0 + S_LONG_B);
+            hipLaunchKernelGGL(k_check_sorted_long, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream,
+                               (const int2*)longB, (const int*)(small0 + S_LONG_B), h->dBp, h->dBj, small0 + S_SORTED);
+        }
         BHS_HIP(hipGetLastError());
         return BHS_SUCCESS;
     };
+    auto unsorted = [&](const int* w) { return h->sortedScan ? w[0] != w[3] : w[0] != 0; };   // w: S_SORTED .. S_LONG_B as read back
     if (checkB) {
         BHS_TRY(ensure(h, h->longList, ((size_t)h->nnzB / 2048 + 2) * sizeof(int2)));
         longB = (int2*)h->longList.p;
@@ -89,7 +99,7 @@ int finish_set_data(bhs_handle* h)
     }
     int* hscan = (int*)h->hostSmall;                                // (pinned)
     BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 6, hipMemcpyDeviceToHost, h->stream));
-    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     const int maxRowA = hscan[0];
     h->maxRowA = maxRowA;
@@ -122,8 +132,7 @@ int finish_set_data(bhs_handle* h)
     }
     if (checkB) {
         int* small = small0;
-        int flag = hscan[6];
-        h->bSorted = flag ? 0 : 1;
+        h->bSorted = unsorted(hscan + 6) ? 0 : 1;
         if (!h->bSorted && h->sortB) {
             // Unsorted rows of B: sort them once here (the reference's driver does this on the host before
             // initData, main.cu:62-64) so that the multiply can take the kernels that want ascending rows.
@@ -138,9 +147,9 @@ int finish_set_data(bhs_handle* h)
             }
             BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
             BHS_TRY(check_sorted());
-            BHS_HIP(hipMemcpyAsync(&flag, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            BHS_HIP(hipMemcpyAsync(hscan + 6, small + S_SORTED, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
             BHS_HIP(hipStreamSynchronize(h->stream));
-            h->bSorted = flag ? 0 : 1;          // (duplicate columns inside a row still count as "not ascending")
+            h->bSorted = unsorted(hscan + 6) ? 0 : 1;          // (duplicate columns inside a row still count as "not ascending")
         }
     }
     // compressed pattern of B: decide now whether it pays (the multiply itself re-runs the compression inside its

@@ -636,6 +636,43 @@ __global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ 
     }
 }
 
+// B-row sortedness check, element-parallel and without a search for row boundaries (round 5): k_sorted_flat counts the
+// positions f >= 1 with Bj[f - 1] >= Bj[f] over the whole index array as one stream (16-byte loads), row boundaries
+// included; k_sorted_starts counts the same test at the first entry of every non-empty row but the first.  The rows are
+// strictly ascending iff the two counts are equal.  (k_check_sorted below walks row by row with a lane group per row:
+// 0.14 ms for poisson27pt 128^3's 223 MB, 1.6 TB/s; these two: one stream of colIndB and one of rowPtrB with a gather.)
+__global__ __launch_bounds__(256) void k_sorted_flat(long long nnz, const int* __restrict__ Bj, int* __restrict__ flat)
+{
+    int bad = 0;
+    const bool aligned = ((size_t)Bj & 15) == 0;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < nnz; i += (long long)gridDim.x * 1024) {
+        int v[4];
+        if (aligned && i + 3 < nnz) {
+            const int4 q = *reinterpret_cast<const int4*>(Bj + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = i + e < nnz ? Bj[i + e] : 0x7fffffff;
+        }
+        const int prev = i > 0 ? Bj[i - 1] : -1;                  // (columns are >= 0)
+        bad += (prev >= v[0] ? 1 : 0) + (i + 1 < nnz && v[0] >= v[1] ? 1 : 0) + (i + 2 < nnz && v[1] >= v[2] ? 1 : 0) +
+               (i + 3 < nnz && v[2] >= v[3] ? 1 : 0);
+    }
+    bad = wave_sum_dpp(bad);
+    if ((threadIdx.x & 63) == 63 && bad) atomicAdd(flat, bad);
+}
+
+__global__ __launch_bounds__(256) void k_sorted_starts(int k, const int* __restrict__ Bp, const int* __restrict__ Bj, int* __restrict__ atStarts)
+{
+    int bad = 0;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < k; r += (long long)gridDim.x * 256) {
+        const int a0 = Bp[r], a1 = Bp[r + 1];
+        if (a1 > a0 && a0 > 0) bad += Bj[a0 - 1] >= Bj[a0] ? 1 : 0;
+    }
+    bad = wave_sum_dpp(bad);
+    if ((threadIdx.x & 63) == 63 && bad) atomicAdd(atStarts, bad);
+}
+
 // B-row sortedness check (reference precondition for EM_mergepath, bhsparse_cuda.h:1902ff; here the lane kernels,
 // the compressed symbolic pass and the column-window path rely on strictly ascending rows).  G = 2^logG lanes per
 // row walk it with coalesced loads; neighbours are compared inside a row only, so no search for row boundaries

@@ -136,6 +136,7 @@ struct bhs_handle {
     const int *dAp = nullptr, *dAj = nullptr, *dBp = nullptr, *dBj = nullptr;
     const value_t *dAx = nullptr, *dBx = nullptr;
     DevBuf ownA[3], ownB[3];
+    int sortedScan = 1;                  // the sortedness scan of B at hand-over: 1 element-parallel (k_sorted_flat + k_sorted_starts), 0 row by row (k_check_sorted)
     int bSorted = 1;
     int logL = 5, ubG = 8, ubLong = kUbLongA;   // k_upper_bound: lanes per row of A, rows beyond ubLong entries go to its long list
     // C

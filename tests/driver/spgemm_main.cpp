@@ -214,10 +214,14 @@ static int run_multi(CsrHost &A, CsrHost &B, bool *platforms, int warmups, const
     // The ranks are fresh images of this program started with fork + exec.  Under a tool that is preloaded into this process
     // and initialises the GPU before main (rocprofv3's library does) that exec is one from a process with a live GPU
     // runtime -- what the pool's boxes refuse: say so instead of reporting a rank failure.
-    for (const char *var : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"}) {
+    // (LD_PRELOAD alone says nothing -- the boxes of the pool preload a library of their own into every process --, a
+    // profiler's library in it does)
+    for (const char *var : {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "LD_PRELOAD"}) {
         const char *v = getenv(var);
-        if (v && *v) {
-            cerr << "-gpus starts one process per GPU by exec; not under a preloaded tool (" << var << " is set). Profile a rank: -gpus N -rank r -idfile f" << endl;
+        const bool tool = v && *v && (strcmp(var, "LD_PRELOAD") != 0 || strstr(v, "rocprof") || strstr(v, "roctracer"));
+        if (tool) {
+            cerr << "-gpus starts one process per GPU by exec; not under a preloaded profiler (" << var << " = " << v
+                 << "). Profile a rank: -gpus N -rank r -idfile f" << endl;
             return -24;
         }
     }
