@@ -663,6 +663,10 @@ def main():
         "native_fallback": native_fallback[0],
         "native_ms_per_step": [round(x / args.steps, 4) for x in gather_ms] if native is not None else None,
         "compute_only_gflops": round(2.0 * nnzCt_total / (t_compute / args.steps * 1e6), 3),
+        # which figure scales with N: `value` is end to end -- every rank ends up with the WHOLE of C, over xGMI links that
+        # move a block slower than a GPU multiplies it (gather_link_floor_ms) --, `compute_only_gflops` is the multiplies alone
+        "scaling_note": ("north_star's >= 6x at 8 GPUs can hold for compute_only_gflops only: value includes the all-gatherv, "
+                         "bounded below by gather_link_floor_ms per step") if world > 1 else None,
         "pipeline_compulsory_bytes": int(bytes_alg_total),
         "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
         "kernels_ms_per_step": {k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items())},

@@ -72,16 +72,18 @@ int finish_set_data(bhs_handle* h)
     int2* longB = nullptr;
     const int logG = std::min(h->logL, 6);                      // lanes per row of B: its average length
     const long long sortGrid = std::max<long long>(1, std::min<long long>(((long long)h->k + (256 >> logG) - 1) / (256 >> logG), (long long)h->numCU * 16));
-    // (S_SORTED: positions of colIndB not above their predecessor, S_LONG_B: those of them that are first entries of rows;
-    // equal counts = every row strictly ascending.  h->sortedScan 0: round 2's row-by-row scan, flag in S_SORTED)
+    // (element-parallel scan: 32 counters of positions of colIndB not above their predecessor at S_CT_SLOTS, 32 of those of
+    // them that are first entries of rows behind them -- free between multiplies --; equal sums = every row strictly
+    // ascending.  h->sortedScan 0: round 2's row-by-row scan, flag in S_SORTED)
     auto check_sorted = [&]() -> int {
         BHS_HIP(hipMemsetAsync(small0 + S_SORTED, 0, sizeof(int), h->stream));
         BHS_HIP(hipMemsetAsync(small0 + S_LONG_B, 0, sizeof(int), h->stream));
         if (h->sortedScan) {
+            BHS_HIP(hipMemsetAsync(small0 + S_CT_SLOTS, 0, sizeof(int) * 64, h->stream));
             const long long gf = std::max<long long>(1, std::min<long long>(((long long)h->nnzB + 1023) / 1024, (long long)h->numCU * 16));
             const long long gs = std::max<long long>(1, std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 16));
-            hipLaunchKernelGGL(k_sorted_flat, dim3((unsigned)gf), dim3(256), 0, h->stream, (long long)h->nnzB, h->dBj, small0 + S_SORTED);
-            hipLaunchKernelGGL(k_sorted_starts, dim3((unsigned)gs), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_LONG_B);
+            hipLaunchKernelGGL(k_sorted_flat, dim3((unsigned)gf), dim3(256), 0, h->stream, (long long)h->nnzB, h->dBj, small0 + S_CT_SLOTS);
+            hipLaunchKernelGGL(k_sorted_starts, dim3((unsigned)gs), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_CT_SLOTS + 32);
         } else {
             hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)sortGrid), dim3(256), 0, h->stream, h->k, logG, h->dBp, h->dBj,
                                small0 + S_SORTED, longB, small0 + S_LONG_B);
@@ -91,7 +93,13 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipGetLastError());
         return BHS_SUCCESS;
     };
-    auto unsorted = [&](const int* w) { return h->sortedScan ? w[0] != w[3] : w[0] != 0; };   // w: S_SORTED .. S_LONG_B as read back
+    // w: S_SORTED as read back, then the 64 counters
+    auto unsorted = [&](const int* w) {
+        if (!h->sortedScan) return w[0] != 0;
+        long long flat = 0, starts = 0;
+        for (int i = 0; i < 32; ++i) { flat += w[1 + i]; starts += w[33 + i]; }
+        return flat != starts;
+    };
     if (checkB) {
         BHS_TRY(ensure(h, h->longList, ((size_t)h->nnzB / 2048 + 2) * sizeof(int2)));
         longB = (int2*)h->longList.p;
@@ -99,7 +107,10 @@ int finish_set_data(bhs_handle* h)
     }
     int* hscan = (int*)h->hostSmall;                                // (pinned)
     BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 6, hipMemcpyDeviceToHost, h->stream));
-    if (checkB) BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    if (checkB) {
+        BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        BHS_HIP(hipMemcpyAsync(hscan + 7, small0 + S_CT_SLOTS, sizeof(int) * 64, hipMemcpyDeviceToHost, h->stream));
+    }
     BHS_HIP(hipStreamSynchronize(h->stream));
     const int maxRowA = hscan[0];
     h->maxRowA = maxRowA;
@@ -147,7 +158,8 @@ int finish_set_data(bhs_handle* h)
             }
             BHS_TRY(sort_rows_device(h, h->k, h->dBp, (int*)h->ownB[1].p, (value_t*)h->ownB[2].p));
             BHS_TRY(check_sorted());
-            BHS_HIP(hipMemcpyAsync(hscan + 6, small + S_SORTED, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+            BHS_HIP(hipMemcpyAsync(hscan + 6, small + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            BHS_HIP(hipMemcpyAsync(hscan + 7, small + S_CT_SLOTS, sizeof(int) * 64, hipMemcpyDeviceToHost, h->stream));
             BHS_HIP(hipStreamSynchronize(h->stream));
             h->bSorted = unsorted(hscan + 6) ? 0 : 1;          // (duplicate columns inside a row still count as "not ascending")
         }

@@ -658,8 +658,13 @@ __global__ __launch_bounds__(256) void k_sorted_flat(long long nnz, const int* _
         bad += (prev >= v[0] ? 1 : 0) + (i + 1 < nnz && v[0] >= v[1] ? 1 : 0) + (i + 2 < nnz && v[1] >= v[2] ? 1 : 0) +
                (i + 3 < nnz && v[2] >= v[3] ? 1 : 0);
     }
+    // (one atomic per block, on one of 32 counters: a matrix with ascending rows has a "violation" at almost every row
+    // start, and thousands of same-address atomics queue for longer than the scan takes)
+    __shared__ int part[4];
     bad = wave_sum_dpp(bad);
-    if ((threadIdx.x & 63) == 63 && bad) atomicAdd(flat, bad);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(&flat[blockIdx.x & 31], part[0] + part[1] + part[2] + part[3]);
 }
 
 __global__ __launch_bounds__(256) void k_sorted_starts(int k, const int* __restrict__ Bp, const int* __restrict__ Bj, int* __restrict__ atStarts)
@@ -669,8 +674,11 @@ __global__ __launch_bounds__(256) void k_sorted_starts(int k, const int* __restr
         const int a0 = Bp[r], a1 = Bp[r + 1];
         if (a1 > a0 && a0 > 0) bad += Bj[a0 - 1] >= Bj[a0] ? 1 : 0;
     }
+    __shared__ int part[4];
     bad = wave_sum_dpp(bad);
-    if ((threadIdx.x & 63) == 63 && bad) atomicAdd(atStarts, bad);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(&atStarts[blockIdx.x & 31], part[0] + part[1] + part[2] + part[3]);
 }
 
 // B-row sortedness check (reference precondition for EM_mergepath, bhsparse_cuda.h:1902ff; here the lane kernels,
