@@ -158,7 +158,7 @@ struct bhs_handle {
 #endif
     int useWindowBitmap = BHS_WINDOW_DEFAULT;             // rows of 2 k .. 8 k entries one wave each, window by window (k_row_wave_window): 0 never, 1 if there are many, 2 always
     // row classes (bhs_class.hip.h): the structure of a row of C worked out once per class of rows
-    int classGridMul = 4, classPerLane = 2, classMinProducts = 64;    // tuning hooks of k_class_rows
+    int classGridMul = 4, classPerLane = 4, classMinProducts = 64;    // tuning hooks of the classifier (entries per lane: 2 until round 5; the one-pass classifier measured 0.295 -> 0.268 ms with 4 on poisson27pt 128^3, 0.537 -> 0.477 on 160^3)
     int scanOnePass = 1;                 // stage 3 of the general pipeline: k_scan_onepass (0: the three scan kernels of rounds 1-3)
     unsigned scanEpoch = 0;              // tag of this multiply's tile words
     int classHeadsOn = 2;                // 2: one pass per matrix (k_class_fused: the wave that finds a row differing from the row before it takes it through the class table itself); 1: rounds 3-4's three launches (k_class_heads, k_class_rows on its lists, k_class_propagate); 0: every row through the table
