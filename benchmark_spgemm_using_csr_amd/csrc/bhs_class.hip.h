@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_row_period(int nrows, const int* __restr
 
 constexpr int kClassHeadSegs = 8;
 constexpr int kClassHeadsBlock = 512;
-constexpr int kClassHeadPiece = 256;                               // most rows per wave (its first is a head by decree)
+constexpr int kClassHeadPiece = BHS_HEAD_PIECE;                    // most rows per wave (its first is a head by decree)
 // ... fewer where a row takes many lanes: a wave walks its piece pass by pass, three dependent round trips each
 constexpr int class_head_piece(int G) { return G >= 64 ? 64 : (G >= 32 ? 128 : kClassHeadPiece); }
 template <bool IS_A, int G, int E>

@@ -23,7 +23,7 @@ namespace bhs {
 template <bool IS_A, int G, int E>
 __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, const int* __restrict__ Rp, const int* __restrict__ Rj,
                                                      const int* __restrict__ classB, int* __restrict__ classOut,
-                                                     unsigned long long* __restrict__ table, int* __restrict__ stats, long long nnzR,
+                                                     unsigned long long* __restrict__ table, int* __restrict__ stats, long long nnzR, int pieceRows,
                                                      const int* __restrict__ range,     // rows [range[0], range[1]] only (nullptr: all)
                                                      int period)                        // a row is compared with the row `period` before it
 {
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, con
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);               // consecutive rows per lane group
     constexpr int RPW = GPW * R;                                   // consecutive rows per wave and pass
     constexpr int WPB = kClassHeadsBlock / 64;
-    constexpr int PIECE = class_head_piece(G);
+    const int PIECE = pieceRows;                                   // consecutive rows a wave walks: its first goes through the class table whatever it looks like
     // the block's cache of the class table (k_class_rows: tag = slot << 20 | 20 bits of the hash, then the pattern)
     constexpr int PW = G * E > kClassMaxRow ? G * E : kClassMaxRow;
     constexpr int NC = PW > 2 * kClassMaxRow ? 16 : 32;

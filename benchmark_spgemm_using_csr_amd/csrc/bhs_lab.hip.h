@@ -19,6 +19,7 @@
 #undef BHS_NT_STORES
 #undef BHS_GEN_NT
 #undef BHS_CLS_COLOUR
+#undef BHS_HEAD_PIECE
 #undef BHS_DEFER_MUL
 #undef BHS_UNIFORM
 #undef BHS_WAVE_ATTR
@@ -68,6 +69,9 @@
 #endif
 #ifndef BHS_CLS_COLOUR      // k_class_patterns: the slab's 16-byte units coloured over the LDS bank groups (measured: bank conflicts -36 %, LDS cycles -13.5 %, numeric_class no faster, class_patterns 0.05 -> 0.17 ms: off)
 #define BHS_CLS_COLOUR 0
+#endif
+#ifndef BHS_HEAD_PIECE      // classifier: consecutive rows a wave walks (its first goes through the class table whatever it looks like)
+#define BHS_HEAD_PIECE 256
 #endif
 #ifndef BHS_GEN_NT      // general pipeline (lane, quad, wave kernels): non-temporal stores of C
 #define BHS_GEN_NT 0
