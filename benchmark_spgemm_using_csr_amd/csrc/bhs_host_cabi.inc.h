@@ -404,6 +404,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "span_path")) { h->spanPath = value ? 1 : 0; h->spanState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sorted_scan")) { h->sortedScan = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_heads")) { h->classHeadsOn = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
@@ -426,6 +427,7 @@ int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
     if (!h || !key || !value_out) return BHS_ERR_INVALID_ARG;
     if (!h->hasData) return BHS_ERR_NOT_READY;
     if (!strcmp(key, "b_sorted")) { *value_out = h->bSorted; return BHS_SUCCESS; }
+    if (!strcmp(key, "span_words")) { *value_out = h->ps.spanWPL; return BHS_SUCCESS; }   // bitmap words per lane of the last multiply's span kernels (0: hash kernels)
     if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
     if (!strcmp(key, "local_a")) { *value_out = h->localA; return BHS_SUCCESS; }

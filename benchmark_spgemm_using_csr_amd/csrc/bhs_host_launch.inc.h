@@ -433,6 +433,50 @@ int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     }
 }
 
+// one wave per row, the row's columns as a bitmap over its span (bhs_row_span.hip.h); VCAP follows the bin's table size
+template <int WPL, int VCAP, bool NUM>
+int launch_row_span_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
+{
+    auto kern = k_row_span<WPL, VCAP, NUM>;
+    const size_t smem = sizeof(SpanSmem<WPL, VCAP, NUM>);
+    int perCU = 1;
+    BHS_TRY(kernel_occupancy(h, reinterpret_cast<const void*>(kern), 64, smem, &perCU));
+    perCU = std::max(1, std::min(perCU, 32));
+    const int useCU = h->wgPerCU > 0 ? h->wgPerCU : perCU;
+    long long grid = std::min<long long>(qn, (long long)h->numCU * useCU);
+    grid = std::max<long long>(8, (grid + 7) / 8 * 8);
+    int chunkLog2 = 0;
+    while ((2 << chunkLog2) <= BHS_XCD_CHUNK && (128LL << chunkLog2) <= (long long)qn) ++chunkLog2;
+    const bool wf = !NUM && queue == nullptr;
+    if (h->verbose > 1) printf("  [%s span: %d words per lane, %d sums, %d waves per CU, smem %zu B]\n", NUM ? "numeric" : "symbolic", WPL, VCAP, perCU, smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), smem, h->ls, queue, qn, chunkLog2, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx,
+                       CpOrCnt, out_cj(h), out_cx(h), h->dAp, wf ? (int*)h->ub.p : (int*)nullptr,
+                       wf ? (unsigned long long*)((int*)h->small.p + S_CT_SLOTS) : (unsigned long long*)nullptr,
+                       (int*)h->small.p + S_ERR, h->reachL, h->reachR);
+    BHS_HIP(hipGetLastError());
+    return BHS_SUCCESS;
+}
+template <bool NUM>
+int launch_row_span(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, int lg)
+{
+    const int wpl = h->ps.spanWPL;
+    if constexpr (!NUM) {
+        if (wpl <= 1) return launch_row_span_impl<1, 1, false>(h, queue, qn, CpOrCnt);
+        if (wpl <= 2) return launch_row_span_impl<2, 1, false>(h, queue, qn, CpOrCnt);
+        return launch_row_span_impl<4, 1, false>(h, queue, qn, CpOrCnt);
+    } else {
+#define BHS_SPAN(W)                                                                                   \
+        if (wpl <= W) {                                                                                \
+            if (lg <= 7) return launch_row_span_impl<W, 128, true>(h, queue, qn, CpOrCnt);            \
+            if (lg <= 9) return launch_row_span_impl<W, 512, true>(h, queue, qn, CpOrCnt);            \
+            return launch_row_span_impl<W, 1024, true>(h, queue, qn, CpOrCnt);                        \
+        }
+        BHS_SPAN(1) BHS_SPAN(2) BHS_SPAN(4)
+#undef BHS_SPAN
+        return BHS_ERR_INTERNAL;
+    }
+}
+
 template <int LOG2TS>
 int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
 {
@@ -575,6 +619,11 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
                 default: break;
             }
         }
+    }
+    // rows accumulated over their column span where the data set's scans say every row fits (checked per row on the device)
+    if (h->ps.spanWPL > 0 && c.block == 64 && !win && lg <= 10 && h->forcePath == 0) return launch_row_span<NUM>(h, queue, qn, CpOrCnt, lg);
+    if constexpr (!NUM) {
+        if (h->ps.spanWPL > 0 && c.block == 64 && !win && h->forcePath == 0) return launch_row_span<NUM>(h, queue, qn, CpOrCnt, lg);
     }
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)

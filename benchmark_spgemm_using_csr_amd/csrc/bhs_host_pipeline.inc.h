@@ -61,6 +61,16 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     int laneK = 0;
     if (h->bSorted && h->forcePath == 0 && h->laneRows && (h->laneRows == 2 || (h->maxRowA <= kLaneMaxK && h->localA)))
         laneK = h->laneRows == 2 ? kLaneMaxK : std::max(4, (h->maxRowA + 1) & ~1);
+    // Rows over their column span (bhs_row_span.hip.h): chosen when the hand-over's scans put every row's span inside the
+    // bitmap (<= 8192 columns: up to four words per lane); no table can overflow, so -- direct launches allowed -- EVERY such
+    // multiply goes without upper-bound pass, round trip and queue.  Not where the lane kernels apply; instead of the
+    // compressed symbolic pass where both do.
+    h->ps.spanWPL = 0;
+    if (h->spanPath && h->spanState >= 0 && h->bSorted && h->forcePath == 0 && laneK == 0 && h->maxRowA <= 64 && !h->specFailed &&
+        h->maxTableLog2 >= 15) {
+        const long long need = (long long)h->widthA + h->reachL + h->reachR + 1;
+        if (need > 0 && need <= 8192) h->ps.spanWPL = need <= 2048 ? 1 : (need <= 4096 ? 2 : 4);
+    }
     // hub bin: rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
     const int hubMin = (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25))
                            ? h->hubMin : 0;
@@ -71,7 +81,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     EventPair* ep;
     h->cmpActive = false;
     // (the undecided first multiply on a data set only measures the ratio: bins and symbolic pass stay plain)
-    const bool cmpRun = h->compressB && h->bSorted && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
+    const bool cmpRun = h->compressB && h->bSorted && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->ps.spanWPL == 0 &&
                         (h->compressB == 2 || h->cmpState >= 0);
     const bool cmpBins = cmpRun && (h->compressB == 2 || h->cmpState > 0);
     if (cmpRun) {
@@ -102,6 +112,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
         if (bound > 0 && bound <= symSpec.upper[8] && (double)bound <= 4.0 * h->avgRowA * h->avgRowB)
             for (int b = 2; b <= 8 && !wfBin; ++b) if (bound <= symSpec.upper[b]) wfBin = b;
     }
+    if (h->ps.spanWPL && !laneFirst && h->waveFirst && h->directBins && !wfBin) wfBin = 2;
     const bool noUpperBound = laneFirst || wfBin > 0;
     if (noUpperBound) numSpec.hubMin = 0;     // (every row is bounded by maxRow(A) x maxRow(B), far below the hub bin)
     int symCount[kMaxBins], symStart[kMaxBins + 1];
@@ -503,6 +514,11 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         // The lane-first / wave-first launch was chosen from the row bounds seen at bhs_set_data time and the
         // kernels found a row beyond them (borrowed arrays changed since): this multiply starts over on the
         // general pipeline, which assumes nothing, and the data set stays there.
+        if (h->ps.spanWPL > 0 && h->spanState >= 0) {             // (a row beyond the span bitmap: the hash kernels from here on)
+            h->spanState = -1;
+            if (h->verbose > 1) printf("  [a row's column span is beyond the bitmap: hash kernels]\n");
+            return pipeline_symbolic(h, true);
+        }
         if (!noUpperBound || h->specFailed) return BHS_ERR_INTERNAL;
         h->specFailed = true;
         if (h->verbose > 1) printf("  [speculative direct launch refuted on the device: general pipeline]\n");
@@ -614,7 +630,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         h->ps.hubRows == 0) {
         int nb = 0;
         for (int b = 2; b <= 6 && !nb; ++b) if (maxCnt <= numSpec.upper[b]) nb = b;
-        if (nb && maxCnt > 0 && (double)h->nnzC / std::max(view.m, 1) * 4.0 >= (double)numSpec.upper[nb]) {
+        if (nb && maxCnt > 0 && ((double)h->nnzC / std::max(view.m, 1) * 4.0 >= (double)numSpec.upper[nb] || h->ps.spanWPL > 0)) {
             for (int b = 0; b < kMaxBins; ++b) { numCount[b] = 0; numStart[b] = 0; }
             numStart[kMaxBins] = 0;
             numCount[nb] = m;

@@ -105,13 +105,28 @@ int finish_set_data(bhs_handle* h)
         longB = (int2*)h->longList.p;
         BHS_TRY(check_sorted());
     }
+    // the scans bhs_row_span.hip.h's kernels are chosen from (rows of B strictly ascending: first / last entry = smallest / largest column)
+    const bool spanScan = h->spanPath && h->m > 0 && h->k > 0 && h->nnzA > 0 && h->nnzB > 0;
+    if (spanScan) {
+        BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)(small0 + S_SPAN), (int)0x80000000, 2, h->stream));
+        BHS_HIP(hipMemsetAsync(small0 + S_SPAN + 2, 0, sizeof(int), h->stream));
+        const long long gb = std::max<long long>(1, std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 8));
+        const long long ga = std::max<long long>(1, std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 8));
+        hipLaunchKernelGGL(k_b_reach, dim3((unsigned)gb), dim3(256), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_SPAN);
+        hipLaunchKernelGGL(k_a_width, dim3((unsigned)ga), dim3(256), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SPAN + 2);
+        BHS_HIP(hipGetLastError());
+    }
     int* hscan = (int*)h->hostSmall;                                // (pinned)
     BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 6, hipMemcpyDeviceToHost, h->stream));
     if (checkB) {
         BHS_HIP(hipMemcpyAsync(hscan + 6, small0 + S_SORTED, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipMemcpyAsync(hscan + 7, small0 + S_CT_SLOTS, sizeof(int) * 64, hipMemcpyDeviceToHost, h->stream));
     }
+    if (spanScan) BHS_HIP(hipMemcpyAsync(hscan + 72, small0 + S_SPAN, sizeof(int) * 3, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
+    h->spanState = 0;
+    h->reachL = h->reachR = h->widthA = 0x3fffffff;              // (no scan: never fits)
+    if (spanScan && hscan[72] != (int)0x80000000) { h->reachL = hscan[72]; h->reachR = hscan[73]; h->widthA = hscan[74]; }
     const int maxRowA = hscan[0];
     h->maxRowA = maxRowA;
     h->maxRowB = hscan[2];

@@ -17,6 +17,7 @@
 #include "bhs_kernels.hip.h"
 #include "bhs_row_wg.hip.h"
 #include "bhs_row_wave.hip.h"
+#include "bhs_row_span.hip.h"
 #include "bhs_row_window.hip.h"
 #include "bhs_row_quad.hip.h"
 #include "bhs_compress.hip.h"
@@ -136,6 +137,9 @@ struct bhs_handle {
     const int *dAp = nullptr, *dAj = nullptr, *dBp = nullptr, *dBj = nullptr;
     const value_t *dAx = nullptr, *dBx = nullptr;
     DevBuf ownA[3], ownB[3];
+    int spanPath = 0;                    // rows accumulated over their column span (bhs_row_span.hip.h) where the hand-over's scans say every row's span fits: 1 when they do, 0 (default) never -- measured 2.7 + 4.6 ms against the hash kernels' 0.66 + 1.68 on the banded input (profiles/r05_experiments.md)
+    int spanState = 0;                   //   -1: a row beyond the bitmap was met on the device, the data set stays on the hash kernels
+    int reachL = 0, reachR = 0, widthA = 0;   //   how far left / right of its own number a row of B reaches, the widest row of A (first to last entry)
     int sortedScan = 1;                  // the sortedness scan of B at hand-over: 1 element-parallel (k_sorted_flat + k_sorted_starts), 0 row by row (k_check_sorted)
     int bSorted = 1;
     int logL = 5, ubG = 8, ubLong = kUbLongA;   // k_upper_bound: lanes per row of A, rows beyond ubLong entries go to its long list
@@ -247,6 +251,7 @@ struct bhs_handle {
         unsigned long long symSums[kMaxBins * 3];
         bool numDirectFull = false;
         int rangesRun = 0;
+        int spanWPL = 0;                 // this multiply's wave bins run k_row_span with this many bitmap words per lane (0: hash kernels)
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
         long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
     } ps;
@@ -275,7 +280,8 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
        S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
                        the length of A's grid lines */,
-       S_SMALL_INTS = 454 };
+       S_SPAN = 454 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
+       S_SMALL_INTS = 460 };
 
 template <int V> struct template_int { static constexpr int value = V; };
 

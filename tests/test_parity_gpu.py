@@ -951,6 +951,56 @@ def test_two_handles_back_to_back_on_the_general_pipeline(oracle):
             assert bh.freePlatform() == 0
 
 
+@pytest.mark.parametrize("kind", ["banded", "blocks", "grid"])
+def test_rows_accumulated_over_their_column_span(oracle, kind):
+    """bhs_row_span.hip.h (round 5; off by default -- it lost to the hash kernels, profiles/r05_experiments.md): option
+    "span_path" = 1 before the hand-over lets its scans choose the span kernels where every row of C is narrow.  Same C as
+    the oracle's, the kernels did run (bhs_get_info "span_words"), and the same handle without the option agrees."""
+    rng = np.random.default_rng(5)
+    if kind == "banded":
+        m = 6000
+        bw = rng.integers(2, 20, m)
+        rows = [np.arange(max(0, i - bw[i]), min(m, i + bw[i] + 1)) for i in range(m)]
+    elif kind == "blocks":
+        m, rows, i = 0, [], 0
+        sizes = rng.integers(3, 30, 400)
+        m = int(sizes.sum())
+        for sz in sizes:
+            for _ in range(sz):
+                rows.append(np.arange(i, i + sz))
+            i += sz
+    else:
+        n = 70
+        m = n * n
+        rows = []
+        for y in range(n):
+            for x in range(n):
+                c = [yy * n + xx for yy in (y - 1, y, y + 1) for xx in (x - 2, x - 1, x, x + 1, x + 2) if 0 <= yy < n and 0 <= xx < n]
+                rows.append(np.array(c))
+    rp = np.zeros(m + 1, np.int32)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    col = np.concatenate(rows).astype(np.int32)
+    val = rng.integers(1, 10, len(col)).astype(np.float64)
+    ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    for span in (1, 0):
+        assert bh.set_option("span_path", span) == 0
+        assert bh.set_option("class_path", 0) == 0
+        Cp = np.zeros(m + 1, np.int32)
+        assert bh.initData(m, m, m, len(col), val, rp, col, len(col), val, rp, col, Cp) == 0
+        assert bh.spgemm() == 0
+        assert (bh.get_info("span_words") > 0) == (span == 1)
+        nnzC = bh.get_nnzC()
+        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+        assert bh.free_mem() == 0
+    assert bh.freePlatform() == 0
+
+
 def test_errors_are_codes_not_exceptions():
     plats = [False] * bhmod.NUM_PLATFORMS
     plats[bhmod.BHSPARSE_HIP] = True
