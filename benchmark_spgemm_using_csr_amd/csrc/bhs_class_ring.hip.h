@@ -25,6 +25,9 @@
 
 namespace bhs {
 
+#ifndef BHS_RING_LOAD_AUX      // cache policy of the slab loads (gfx940 cpol bits: 1 sc0, 2 nt, 16 sc1)
+#define BHS_RING_LOAD_AUX 0
+#endif
 #ifndef BHS_RING_WAVES
 #define BHS_RING_WAVES 4
 #endif
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 if (j * 64 * kClassEpl < slab) {
                     const bool piece = (dma[j] & 0xFF00) != 0;
                     if (piece && (long long)src[j] + kClassEpl <= nnzB)
-                        __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, BHS_RING_LOAD_AUX);
                     else if (piece)                                  // (the last few values of valB: no 16-byte load past its end)
                         for (int e2 = 0; e2 < kClassEpl; ++e2)
                             if ((long long)src[j] + e2 < nnzB) ring[loadSlot * slab + (j * 64 + lane) * kClassEpl + e2] = Bx[src[j] + e2];
