@@ -405,6 +405,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "span_path")) { h->spanPath = value ? 1 : 0; h->spanState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "early_fill")) { h->earlyFill = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sorted_scan")) { h->sortedScan = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_heads")) { h->classHeadsOn = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_numeric")) { h->classNumeric = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }

@@ -129,6 +129,24 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches++;
     h->stats[ep->stat].rows += m;
+    // the queues are filled while the host waits for the bin counts (their starts: k_bin_starts, the host's own sum below)
+    const bool earlyFill = h->earlyFill != 0;
+    auto fill_sym = [&]() -> int {
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           symKeys, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
+                           small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
+                           (unsigned long long*)(small + S_SYM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        return BHS_SUCCESS;
+    };
+    if (earlyFill) {
+        hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_SYM_COUNT), small + S_SYM_START);
+        BHS_TRY(fill_sym());
+    }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     symStart[0] = 0;
@@ -153,20 +171,10 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     // 7pt, 9pt), that bin's queue would list the rows 0..m-1 in order -- the fill pass is skipped and the kernel
     // derives its descriptors from rowPtrA (and rowPtrC) itself.
     symDirect = h->directBins && (symCount[kLaneBin] == m || symCount[1] == m);
-    if (!symDirect) {
+    if (!symDirect && !earlyFill) {
     memcpy(hs + S_SMALL_INTS, symStart, sizeof(int) * kMaxBins);        // pinned staging: a truly asynchronous H2D
     BHS_HIP(hipMemcpyAsync(small + S_SYM_START, hs + S_SMALL_INTS, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
-    {
-        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
-        BHS_TRY(timed_begin(h, "fill_queues", &ep));
-        hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
-                           symKeys, h->dAp, (const int*)h->ub.p, (const int*)(small + S_SYM_START),
-                           small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
-                           (unsigned long long*)(small + S_SYM_SUMS));
-        BHS_HIP(hipGetLastError());
-        BHS_TRY(timed_end(h, ep));
-        h->stats[ep->stat].launches++;
-    }
+    BHS_TRY(fill_sym());
     }
     }   // !noUpperBound
     const int4* symQueue = symDirect ? nullptr : (const int4*)h->queue.p;
@@ -469,6 +477,23 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     h->stats[ep->stat].launches += 3;
     }
     }
+    // ... the numeric queues likewise, where the symbolic stage went by queues (then the numeric stage will): k_scan_onepass
+    // has left the numeric bins' counts
+    h->ps.numQueueFilled = false;
+    // (not where this data set's last multiply ran its numeric stage straight from the row pointers: a hint, it costs or saves a launch)
+    if (!useClass && h->earlyFill && h->scanOnePass && !sc.noUpperBound && !sc.symDirect && h->numDirectHint != 1) {
+        hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_NUM_COUNT), small + S_NUM_START);
+        long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
+        BHS_TRY(timed_begin(h, "fill_queues", &ep));
+        hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)grid), dim3(256), 0, h->stream, m,
+                           (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_START),
+                           small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
+                           (unsigned long long*)(small + S_NUM_SUMS));
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->ps.numQueueFilled = true;
+    }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     if (useClass) {
@@ -637,7 +662,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
             numDirect = true;
         }
     }
-    if (!numDirect) {
+    if (!numDirect && !(full && h->ps.numQueueFilled)) {
         memcpy(hs + S_SMALL_INTS + kMaxBins, numStart, sizeof(int) * kMaxBins);
         BHS_HIP(hipMemcpyAsync(small + S_NUM_START, hs + S_SMALL_INTS + kMaxBins, sizeof(int) * kMaxBins, hipMemcpyHostToDevice, h->stream));
         long long grid = std::min<long long>(((long long)m + kFillTile - 1) / kFillTile, (long long)h->numCU * 8);
@@ -650,7 +675,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
     }
-    if (full) h->ps.numDirectFull = numDirect;
+    if (full) { h->ps.numDirectFull = numDirect; h->numDirectHint = numDirect ? 1 : 0; }
     h->ps.rangesRun++;
     const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
     h->ps.midRows = h->ps.longRows = 0;

@@ -319,6 +319,17 @@ __global__ __launch_bounds__(256) void k_upper_bound_long_finish(const int2* __r
 // a block stay together so queue order stays close to row order (L2 locality
 // of the B rows they touch).
 // ---------------------------------------------------------------------------
+// The bins' queue starts from their counts, on the device: start[0] = 0, start[b + 1] = start[b] + (b ? count[b] : 0) -- what
+// the host computes from the same counts once it has read them back; with this the queues can be filled WHILE the host
+// waits for that read-back (round 5: the general pipeline's host-visible gaps, ~40 us each on a web graph).
+__global__ void k_bin_starts(const int* __restrict__ count, int* __restrict__ start)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int at = 0;
+        for (int b = 0; b < kMaxBins; ++b) { start[b] = at; at += b == 0 ? 0 : count[b]; }
+    }
+}
+
 constexpr int kFillRounds = BHS_FILL_ROUNDS;     // rows per thread per reservation
 constexpr int kFillTile = 256 * kFillRounds;     // rows per block per global reservation
 

@@ -140,6 +140,8 @@ struct bhs_handle {
     int spanPath = 0;                    // rows accumulated over their column span (bhs_row_span.hip.h) where the hand-over's scans say every row's span fits: 1 when they do, 0 (default) never -- measured 2.7 + 4.6 ms against the hash kernels' 0.66 + 1.68 on the banded input (profiles/r05_experiments.md)
     int spanState = 0;                   //   -1: a row beyond the bitmap was met on the device, the data set stays on the hash kernels
     int reachL = 0, reachR = 0, widthA = 0;   //   how far left / right of its own number a row of B reaches, the widest row of A (first to last entry)
+    int numDirectHint = -1;              // this data set's last whole multiply ran its numeric stage without queues (1), with them (0); -1: none yet
+    int earlyFill = 1;                   // general pipeline: the queues filled while the host waits for the bin counts (starts computed on the device)
     int sortedScan = 1;                  // the sortedness scan of B at hand-over: 1 element-parallel (k_sorted_flat + k_sorted_starts), 0 row by row (k_check_sorted)
     int bSorted = 1;
     int logL = 5, ubG = 8, ubLong = kUbLongA;   // k_upper_bound: lanes per row of A, rows beyond ubLong entries go to its long list
@@ -251,6 +253,7 @@ struct bhs_handle {
         unsigned long long symSums[kMaxBins * 3];
         bool numDirectFull = false;
         int rangesRun = 0;
+        bool numQueueFilled = false;     // the numeric queues of the whole multiply were filled behind the scan
         int spanWPL = 0;                 // this multiply's wave bins run k_row_span with this many bitmap words per lane (0: hash kernels)
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
         long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
