@@ -231,8 +231,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 BHS_TICK_CLS(1);
             }
             if (!ringOK || oneRow || row != lastRow + 1) {           // a stretch begins: its first slabs, all at once, from the slot the ring is at
-                const int ajv = lane < nA ? Aj[apT + lane] : -1;
-                const int bo = ajv >= 0 ? Bp[ajv] : 0;
+                // (BHS_CLS_LAB & 16384, wrong results: what the two dependent round trips of a stretch's start cost)
+                const int ajv = (BHS_CLS_LAB & 16384) ? -1 : (lane < nA ? Aj[apT + lane] : -1);
+                const int bo = ajv >= 0 ? Bp[ajv] : ((BHS_CLS_LAB & 16384) ? (apT & 0xFFFF) * 16 : 0);
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) src[j] = (unsigned)(__shfl(bo, (dma[j] >> 16) & 63, 64) + (dma[j] & 255));
                 loadSlot = phase;
