@@ -774,7 +774,44 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         srt[p] = sv;
     }
     __syncthreads();
-    bitonic();
+    // The products in the order (entry of C, product number).  Round 5: not a second bitonic sort (55 stages, a barrier
+    // each: most of this kernel's 49 us): an entry's products come from DIFFERENT entries of the A row (a row of B holds a
+    // column once), so a 64-bit mask per entry of C says which -- the entry's products are as many as its mask has bits,
+    // a product's rank inside its entry is the number of bits below its A entry's, and the entries' starts are one scan.
+    // (A row of B with a column twice breaks the premise: the counts then do not add up to P, and the sort runs.)
+    {
+        unsigned long long* emask = reinterpret_cast<unsigned long long*>(bits);          // [kClassMaxNnz] (the bitmap's words are free now)
+        int* estart = reinterpret_cast<int*>(bits) + 2 * kClassMaxNnz;                    // [kClassMaxNnz]
+        for (int e = tid; e < kClassMaxNnz; e += 256) emask[e] = 0ull;
+        __syncthreads();
+        for (int p = tid; p < P; p += 256) atomicOr(&emask[srt[p] >> 10], 1ull << (pk[p] & 63));
+        __syncthreads();
+        const int c0 = 2 * tid < nnz ? __popcll(emask[2 * tid]) : 0, c1 = 2 * tid + 1 < nnz ? __popcll(emask[2 * tid + 1]) : 0;
+        scan[tid] = c0 + c1;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const int excl = scan[tid] - c0 - c1;
+        estart[2 * tid] = excl;
+        estart[2 * tid + 1] = excl + c0;
+        const bool unique = scan[255] == P;
+        __syncthreads();
+        if (unique) {
+            for (int p = tid; p < P; p += 256) {
+                const int l = srt[p] >> 10, kA = pk[p] & 63;
+                keys[estart[l] + __popcll(emask[l] & ((1ull << kA) - 1ull))] = srt[p];
+            }
+            __syncthreads();
+            for (int p = tid; p < N2; p += 256) srt[p] = p < P ? keys[p] : 0x7fffffff;
+            __syncthreads();
+        } else {
+            bitonic();
+        }
+    }
     const int U = (P + 63) >> 6;
     const unsigned spare = (unsigned)nnz * (unsigned)sizeof(acc_t);           // the slot behind the row's entries
     for (int idx = tid; idx < kClassMaxSteps * 64; idx += 256) {
