@@ -1140,6 +1140,24 @@ def _kron_ones(rp, col, dof):
     return A.shape[0], A.indptr.astype(np.int32), A.indices.astype(np.int32)
 
 
+def test_row_classes_with_a_column_twice_in_rows_of_b(oracle):
+    """k_class_patterns ranks a class's products inside their entry of C by the A entry they come from (round 5: a mask per
+    entry instead of a second sort) -- on the premise that a row of B holds a column once.  A row of B that holds one
+    twice (the reference adds such duplicates up like any others) must send the class back to the sort: same C as the
+    oracle's, on the class kernels."""
+    rng = np.random.default_rng(12)
+    m = k = n = 3000
+    A = _toeplitz(m, k, (-30, -1, 0, 1, 30), rng)
+    B = _toeplitz(k, n, (-30, -2, 0, 0, 2, 2, 30), rng)           # columns j and j + 2 twice in every interior row
+    ref = oracle.spgemm(m, k, n, *A, *B)
+    for opts in ({"class_path": 2, "sort_b": 0}, {"class_path": 2}, {"class_path": 0}):
+        Cp, Cj, Cx, info = spgemm_csr(m, k, n, *A, *B, options=opts)
+        assert info["nnzC"] == ref[0][-1]
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"], opts
+        if opts.get("class_path") == 2 and "sort_b" in opts:
+            assert "numeric_class" in _kernel_names(info)
+
+
 @pytest.mark.parametrize("case", ["p27", "p5", "p7", "p9", "rect_toeplitz", "holes", "float_values", "f32_build",
                                   "unsorted_b", "row_block", "fem_3dof", "fem_4dof", "fem_3dof_f32", "long_b_rows",
                                   "fem_3dof_row_block"])
