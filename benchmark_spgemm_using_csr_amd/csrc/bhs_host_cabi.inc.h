@@ -383,6 +383,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "tiny_rows")) { h->tinyRows = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }

@@ -555,6 +555,19 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
 {
     const unsigned grid = (unsigned)(((long long)qn + 255) / 256);
     const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
+    // every row's products in registers where the longest rows of A and B seen at hand-over keep them to 32 (checked per
+    // row on the device): bhs_row_tiny.hip.h
+    if (h->tinyRows && h->forcePath == 0 && h->maxRowA > 0 && h->maxRowB > 0 && (long long)h->maxRowA * h->maxRowB <= 32) {
+#define BHS_TINY(KA, LB)                                                                                              \
+        if (h->maxRowA <= KA && h->maxRowB <= LB) {                                                                    \
+            hipLaunchKernelGGL((k_row_tiny<KA, LB, NUM>), dim3(grid), dim3(256), 0, h->ls, queue, qn, h->dAp, h->dAj, h->dAx, h->dBp, \
+                               h->dBj, h->dBx, CpOrCnt, out_cj(h), out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR);        \
+            BHS_HIP(hipGetLastError());                                                                                \
+            return BHS_SUCCESS;                                                                                        \
+        }
+        BHS_TINY(5, 5) BHS_TINY(4, 8) BHS_TINY(8, 4) BHS_TINY(2, 16) BHS_TINY(16, 2)
+#undef BHS_TINY
+    }
 #define BHS_LANE(KK)                                                                                          \
     case KK:                                                                                                  \
         if (smallB)                                                                                           \

@@ -22,6 +22,7 @@
 #include "bhs_row_quad.hip.h"
 #include "bhs_compress.hip.h"
 #include "bhs_row_lane.hip.h"
+#include "bhs_row_tiny.hip.h"
 #include "bhs_sort.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
@@ -201,6 +202,7 @@ struct bhs_handle {
     int directBins = 1;                  // skip the queue of a stage whose rows all sit in the lane or quad bin
     int sortB = 1;                       // unsorted rows of B are sorted (on a private copy) at set_data time
     int laneRows = 1;                    // lane-per-row kernel for tiny rows: 0 never, 1 when every A row has <= 12 entries, 2 always
+    int tinyRows = 0;                    // rows of <= 32 products with every product in registers (bhs_row_tiny.hip.h) where the hand-over's longest rows allow: 1 yes, 0 (default) never -- measured 0.044 + 0.150 ms against k_row_lane's 0.036 + 0.113 on poisson5pt 1024^2
     int laneNumeric = 2;                 // numeric stage of lane-bin rows through k_row_lane too: 0 never, 1 always, 2 when K <= 8 (where it wins)
     int maxRowA = 0;
     int periodA = 1, periodB = 1;        // rows repeat the row this many rows back (k_row_period: a hint for k_class_heads)

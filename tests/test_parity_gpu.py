@@ -1001,6 +1001,18 @@ def test_rows_accumulated_over_their_column_span(oracle, kind):
     assert bh.freePlatform() == 0
 
 
+@pytest.mark.parametrize("stencil,dims", [("poisson5pt", (61, 47, 1)), ("poisson5pt", (9, 200, 1))])
+def test_rows_of_at_most_32_products_in_registers(oracle, stencil, dims):
+    """bhs_row_tiny.hip.h (round 5; off by default -- slower than the lane-per-row merge, profiles/r05_experiments.md):
+    option "tiny_rows" = 1 takes rows of <= 5 x 5 products through a register sorting network.  Same C as the oracle's."""
+    m, rp, col, val = poisson_case(stencil, *dims)
+    ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    for tiny in (1, 0):
+        Cp, Cj, Cx, info = spgemm_csr(m, m, m, rp, col, val, rp, col, val, options={"tiny_rows": tiny, "class_path": 0})
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+        assert "numeric_lane" in _kernel_names(info)
+
+
 def test_errors_are_codes_not_exceptions():
     plats = [False] * bhmod.NUM_PLATFORMS
     plats[bhmod.BHSPARSE_HIP] = True
