@@ -1139,6 +1139,27 @@ __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int
 }
 
 // ---------------------------------------------------------------------------
+// Speculative numeric launch (pipeline_symbolic, bhs_host_pipeline.inc.h).  Between k_class_scan and the numeric kernel the
+// host reads the classes' figures back -- which kernel, how much LDS, how large C is -- and the device idles for that round
+// trip (30 us of a 0.4 .. 1.6 ms multiply).  On a data set's second and later multiplies the host assumes the figures of the
+// multiply before instead and launches at once; this kernel compares what it assumed with what this multiply's kernels found,
+// and the numeric kernel returns before its first load unless word == 1 (the host sees the word at the end of the multiply
+// and runs it again the slow way: borrowed arrays may change between multiplies, nothing kept from an earlier one is trusted).
+// ---------------------------------------------------------------------------
+struct ClassSpecKey { int cs[CS_INTS]; long long nnzC; };
+__global__ __launch_bounds__(64) void k_class_spec_check(ClassSpecKey key, const int* __restrict__ stats, const long long* __restrict__ total,
+                                                         const int* __restrict__ err, int* __restrict__ word)
+{
+    const int i = threadIdx.x;
+    bool ok = *err == 0 && *total == key.nnzC;
+    // (the products' partial sums and the scan's ticket are not decisions: CS_SUMS .. CS_RANGE and CS_SCANTICKET are left out)
+    for (int j = i; j < CS_INTS; j += 64)
+        if (!(j >= CS_SUMS && j < CS_RANGE) && j != CS_SCANTICKET) ok = ok && stats[j] == key.cs[j];
+    const bool all = __ballot(!ok) == 0ull;
+    if (i == 0) *word = all ? 1 : 2;
+}
+
+// ---------------------------------------------------------------------------
 // Numeric pass, round 2's form (kept as the default until the workgroup form of bhs_class_wg.hip.h beats it
 // everywhere; option class_numeric).  A wave takes runs of kClassRunA consecutive rows (neighbouring rows share their B rows: L1 / L2 hits,
 // and the rows of C they write are adjacent); blocks are dealt to the XCDs so that each XCD's L2 sees one contiguous

@@ -66,8 +66,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classRing, const int* __restrict__ classRel,
     const int* __restrict__ classLane, const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx,
-    int ringBytes, int accStride, int rowBase, int superRows, int chunkRows)     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
+    int ringBytes, int accStride, int rowBase, int superRows, int chunkRows,     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
+    const int* __restrict__ specWord)                                             // launched before the host saw this multiply's classes (k_class_spec_check): go on only if 1
 {
+    if (specWord != nullptr && *specWord != 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
     const int lane = threadIdx.x;
     // the ring (ringBytes: a power of two, at LDS address 0 -- the kernel has no static LDS), acc[accStride], the row's A values

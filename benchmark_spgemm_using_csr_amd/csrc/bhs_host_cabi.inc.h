@@ -364,6 +364,11 @@ int bhs_get_kernel_stats(bhs_handle* h, bhs_kernel_stat* out, int cap)
 int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
 {
     if (!h || !key) return BHS_ERR_INVALID_ARG;
+    h->classSpec.valid = false;                                     // (any option may change what a multiply decides)
+    if (!strcmp(key, "spec_numeric")) { h->specNumeric = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_tile_piece")) { h->classTilePiece = (int)std::max<long long>(0, std::min<long long>(value, 1 << 17)); return BHS_SUCCESS; }
+    if (!strcmp(key, "class_tile")) { h->classTile = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "spin_wait")) { h->spinWait = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "force_path")) { h->forcePath = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "max_table_log2")) {
         if (value < 6 || value > 15) return BHS_ERR_INVALID_ARG;
@@ -430,6 +435,8 @@ int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
     if (!h->hasData) return BHS_ERR_NOT_READY;
     if (!strcmp(key, "b_sorted")) { *value_out = h->bSorted; return BHS_SUCCESS; }
     if (!strcmp(key, "span_words")) { *value_out = h->ps.spanWPL; return BHS_SUCCESS; }   // bitmap words per lane of the last multiply's span kernels (0: hash kernels)
+    if (!strcmp(key, "spec_launches")) { *value_out = h->specLaunches; return BHS_SUCCESS; }   // multiplies whose numeric kernel went out before the host saw the classes, so far
+    if (!strcmp(key, "spec_refuted")) { *value_out = h->specRefuted; return BHS_SUCCESS; }     // ... of them, refuted on the device and run again
     if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
     if (!strcmp(key, "local_a")) { *value_out = h->localA; return BHS_SUCCESS; }

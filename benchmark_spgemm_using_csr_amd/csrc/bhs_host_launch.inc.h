@@ -313,7 +313,8 @@ int launch_class_ring_impl(bhs_handle* h, int r0, int r1)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.bytes, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        (long long)h->nnzA, h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
                        (const unsigned*)h->classRing.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
-                       out_cx(h), lds.ringBytes, lds.accStride, r0, superRows, chunkRows);
+                       out_cx(h), lds.ringBytes, lds.accStride, r0, superRows, chunkRows,
+                       h->ps.specLaunched ? (const int*)h->small.p + S_SPEC : (const int*)nullptr);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }

@@ -1,6 +1,26 @@
 // bhs_host_pipeline.inc.h -- one multiply: the class path and the general pipeline, stage by stage; the multiply in two halves
 // (A part of bhsparse_hip.hip's translation unit: included there, inside its unnamed namespace where that applies.)
 
+constexpr int kSpecRefuted = -1000;      // pipeline_finish to run_pipeline_impl only: never leaves the library
+
+// The host waits for h->stream in the middle of a multiply (the bins' counts, nnzC) and at its end.  hipStreamSynchronize puts
+// the thread to sleep when the wait is long, and waking it costs ~20 us -- of a multiply of 0.2 .. 2 ms, two or three times.
+// Poll instead (option "spin_wait", on by default) for at most 50 ms, then sleep as before.
+int wait_stream(bhs_handle* h)
+{
+    if (h->spinWait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) return BHS_SUCCESS;
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); return BHS_ERR_LAUNCH; }
+            if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        }
+    }
+    BHS_HIP(hipStreamSynchronize(h->stream));
+    return BHS_SUCCESS;
+}
+
 int pow2_at_least(double x, int lo, int hi)
 {
     int v = lo;
@@ -148,7 +168,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
         BHS_TRY(fill_sym());
     }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
-    BHS_HIP(hipStreamSynchronize(h->stream));
+    BHS_TRY(wait_stream(h));
     symStart[0] = 0;
     for (int b = 0; b < kMaxBins; ++b) {
         symCount[b] = hs[S_SYM_COUNT + b];
@@ -335,6 +355,21 @@ int symbolic_class(bhs_handle* h)
                 // 128^3; 1024: 0.355), the old kernels' piece otherwise
                 int piece = class_head_piece(GG);
                 if (GG < 32 && (long long)n >= 512LL * 16 * h->numCU) piece = 512;
+                if constexpr (GG * E <= 32) {
+                    // a lane per row, the rows' column indices through a tile in LDS (bhs_class_tile.hip.h)
+                    if (h->classTile && period == 1) {
+                        // whole steps of 63 new rows, and as many of them as give every wave slot of the device (16 per CU) ONE piece:
+                        // 2 M rows in pieces of 504 are 4161 waves for 4096 slots -- a second round for 65 of them (classify_rows
+                        // 0.227 -> ... ms on poisson27pt 128^3)
+                        const long long slots = (long long)h->numCU * 16;
+                        int pieceT = 63 * (int)std::max<long long>(4, std::min<long long>(64, ((long long)n + slots * 63 - 1) / (slots * 63)));
+                        if (h->classTilePiece > 0) pieceT = std::max(63, h->classTilePiece / 63 * 63);
+                        const long long perBlockT = (long long)(kClassTileBlock / 64) * pieceT;
+                        hipLaunchKernelGGL((k_class_tile<IS_A, GG, E>), dim3((unsigned)std::max<long long>(1, ((long long)n + perBlockT - 1) / perBlockT)), dim3(kClassTileBlock), 0,
+                                           h->stream, n, Rp, Rj, cb, out, tab, cstats, (long long)(IS_A ? h->nnzA : h->nnzB), pieceT, rng);
+                        return (int)BHS_SUCCESS;
+                    }
+                }
                 const long long perBlock = (long long)(kClassHeadsBlock / 64) * piece;
                 hipLaunchKernelGGL((k_class_fused<IS_A, GG, E>), dim3((unsigned)std::max<long long>(1, ((long long)n + perBlock - 1) / perBlock)), dim3(kClassHeadsBlock), 0,
                                    h->stream, n, Rp, Rj, cb, out, tab, cstats, (long long)(IS_A ? h->nnzA : h->nnzB), piece, rng, period);
@@ -381,6 +416,32 @@ int symbolic_class(bhs_handle* h)
 
 // restart: the same multiply starting over on another path (a refuted speculation, rows without a class): the
 // timers and kernel statistics of the abandoned attempt stay in -- it ran inside this multiply.
+int stage_rowptr_and_open(bhs_handle* h);
+
+// May this multiply's numeric kernel go out on the figures of the last one?  Sets h->ps's class fields from them if so.
+bool class_spec_try(bhs_handle* h)
+{
+    const bhs_handle::ClassSpec& sp = h->classSpec;
+    if (!h->specNumeric || !sp.valid || h->lazyOut || h->classNumeric < 2) return false;
+    const int* cs = sp.cs;
+    if (cs[CS_FLAGS] || cs[CS_CLASSES] == 0 || cs[CS_BIGCOUNT]) return false;
+    if (h->classHeadsOn && h->classPath != 2 && (long long)cs[CS_HEADS] * 4 > (long long)h->m) return false;
+    const size_t need = (size_t)std::max<long long>(sp.nnzC, 1);
+    if (h->extCj ? sp.nnzC > h->extCap : (!h->Cj.p || !h->Cx.p || h->Cj.cap < need * sizeof(int) || h->Cx.cap < need * sizeof(value_t))) return false;
+    h->ps.useClass = true;
+    h->ps.classMaxP = cs[CS_MAXP];
+    h->ps.classMaxNnz = cs[CS_MAXNNZ];
+    h->ps.classMaxNA = cs[CS_MAXNA];
+    h->ps.classMaxLB = cs[CS_MAXLB];
+    h->ps.classMaxRing = cs[CS_MAXRING];
+    h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
+    h->ps.classMaxSlab = cs[CS_MAXSLAB];
+    h->ps.classBig = 0;
+    h->ps.classBigMaxP = cs[CS_BIGMAXP];
+    if (!class_ring2_fits(h)) { h->ps.useClass = false; return false; }
+    return true;
+}
+
 int pipeline_symbolic(bhs_handle* h, bool restart = false)
 {
     h->ls = h->stream;
@@ -402,7 +463,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     if (m == 0 || h->nnzA == 0 || h->nnzB == 0) {
         BHS_HIP(hipMemsetAsync(h->Cp.p, 0, sizeof(int) * ((size_t)m + 1), h->stream));
         for (int i = 1; i < 5; ++i) BHS_HIP(hipEventRecord(h->ev[i], h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
+        BHS_TRY(wait_stream(h));
         h->hasC = true;
         h->ps.open = true;
         h->ps.empty = true;
@@ -494,8 +555,29 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->stats[ep->stat].launches++;
         h->ps.numQueueFilled = true;
     }
+    // The classes' figures of the data set's last multiply stand in for this one's (bhs_class.hip.h, k_class_spec_check): no
+    // round trip to the host between the scan and the numeric kernel.  Only for a whole multiply on the ring kernel whose C
+    // fits the arrays at hand; pipeline_finish sees the device's verdict.
+    if (useClass && !restart && class_spec_try(h)) {
+        ClassSpecKey key;
+        memcpy(key.cs, h->classSpec.cs, sizeof(key.cs));
+        key.nnzC = h->classSpec.nnzC;
+        hipLaunchKernelGGL(k_class_spec_check, dim3(1), dim3(64), 0, h->stream, key, (const int*)(small + S_CT_SLOTS),
+                           (const long long*)(small + S_TOTAL_C), (const int*)(small + S_ERR), small + S_SPEC);
+        BHS_HIP(hipGetLastError());
+        h->ps.specLaunched = true;
+        h->specLaunches++;
+        h->nnzC = h->classSpec.nnzC;
+        h->nnzCt = h->classSpec.nnzCt;                 // (pipeline_finish puts this multiply's own count here)
+        h->ps.noUpperBound = noUpperBound;
+        h->ps.symDirect = symDirect;
+        h->ps.laneK = laneK;
+        h->ps.numSpec = numSpec;
+        BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+        return stage_rowptr_and_open(h);
+    }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
-    BHS_HIP(hipStreamSynchronize(h->stream));
+    BHS_TRY(wait_stream(h));
     if (useClass) {
         const int* cs = hs + S_CT_SLOTS;
         if (cs[CS_FLAGS] || cs[CS_CLASSES] == 0) {
@@ -527,6 +609,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         h->ps.classMaxSlab = cs[CS_MAXSLAB];
         h->ps.classBig = cs[CS_BIGCOUNT];
         h->ps.classBigMaxP = cs[CS_BIGMAXP];
+        memcpy(h->classSpec.cs, cs, sizeof(h->classSpec.cs));          // (valid once nnzC is known, below)
         if (h->verbose > 1) printf("  [row classes: %d classes, <= %d products and <= %d entries per row; slabs of <= %d values]\n", cs[CS_CLASSES], cs[CS_MAXP], cs[CS_MAXNNZ], cs[CS_MAXSLAB]);
     } else if (noUpperBound) {                           // product count: the symbolic kernel's 64 partial sums
         unsigned long long t = 0, v;
@@ -566,7 +649,15 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
         BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     }
+    if (useClass) { h->classSpec.nnzC = nnzC; h->classSpec.nnzCt = h->nnzCt; h->classSpec.valid = true; }
     BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+    return stage_rowptr_and_open(h);
+}
+
+// the end of pipeline_symbolic: rowPtrC on its way to the host where the caller wants it there, the multiply open
+int stage_rowptr_and_open(bhs_handle* h)
+{
+    const int m = h->m;
     h->rowPtrStaged = false;
     if (h->wantHostRowPtr) {
         // rowPtrC is final after the scan: ship it to pinned host memory on a second stream while the
@@ -641,7 +732,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         BHS_HIP(hipGetLastError());
         BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
         BHS_HIP(hipMemcpyAsync(hr + kMaxBins, small + S_MAXCNT, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        BHS_HIP(hipStreamSynchronize(h->stream));
+        BHS_TRY(wait_stream(h));
         for (int b = 0; b < kMaxBins; ++b) numCount[b] = hr[b];
         maxCnt = hr[kMaxBins];
     }
@@ -734,7 +825,13 @@ int pipeline_finish(bhs_handle* h)
     int* hs = h->hostSmall;
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipEventRecord(h->ev[4], h->stream));
-    BHS_HIP(hipStreamSynchronize(h->stream));
+    BHS_TRY(wait_stream(h));
+    if (h->ps.specLaunched) {
+        if (hs[S_SPEC] != 1) return kSpecRefuted;       // (the numeric kernel has written nothing: run_pipeline_impl starts over)
+        unsigned long long t = 0, v;
+        for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, hs + S_CT_SLOTS + CS_SUMS + 2 * i, 8); t += v; }
+        h->nnzCt = h->classSpec.nnzCt = (long long)t;
+    }
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
     const bool oneRange = h->ps.rangesRun == 1;
     for (int b = 1; b < kMaxBins; ++b) {
@@ -769,6 +866,14 @@ int pipeline_finish(bhs_handle* h)
 
 int run_pipeline_impl(bhs_handle* h)
 {
+    BHS_TRY(pipeline_symbolic(h));
+    BHS_TRY(numeric_stage(h, 0, h->m));
+    const int rc = pipeline_finish(h);
+    if (rc != kSpecRefuted) return rc;
+    // the arrays are not what they were a multiply ago: once more, every decision from this multiply's own figures
+    h->classSpec.valid = false;
+    h->specRefuted++;
+    if (h->verbose > 1) printf("  [speculative numeric launch refuted on the device: the multiply again]\n");
     BHS_TRY(pipeline_symbolic(h));
     BHS_TRY(numeric_stage(h, 0, h->m));
     return pipeline_finish(h);

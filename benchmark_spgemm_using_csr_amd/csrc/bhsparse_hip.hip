@@ -29,6 +29,7 @@
 #include "bhs_class_wg.hip.h"
 #include "bhs_class_ring.hip.h"
 #include "bhs_class_fused.hip.h"
+#include "bhs_class_tile.hip.h"
 #include "bhs_class_big.hip.h"
 
 #include <algorithm>
@@ -141,6 +142,14 @@ struct bhs_handle {
     int spanPath = 0;                    // rows accumulated over their column span (bhs_row_span.hip.h) where the hand-over's scans say every row's span fits: 1 when they do, 0 (default) never -- measured 2.7 + 4.6 ms against the hash kernels' 0.66 + 1.68 on the banded input (profiles/r05_experiments.md)
     int spanState = 0;                   //   -1: a row beyond the bitmap was met on the device, the data set stays on the hash kernels
     int reachL = 0, reachR = 0, widthA = 0;   //   how far left / right of its own number a row of B reaches, the widest row of A (first to last entry)
+    // the classes' figures of this data set's last whole multiply on the ring kernel: the next one launches its numeric kernel on
+    // them before it has seen its own (pipeline_symbolic), checked on the device (k_class_spec_check)
+    struct ClassSpec { bool valid = false; int cs[CS_INTS]; long long nnzC = 0, nnzCt = 0; } classSpec;
+    int classTilePiece = 0;              // option "class_tile_piece": rows per wave of that classifier (0: one piece per wave slot)
+    int classTile = 1;                   // option "class_tile": the classifier with a lane per row (bhs_class_tile.hip.h) where rows have at most 32 entries
+    int specNumeric = 1;                 // option "spec_numeric": 0 never launch speculatively
+    int spinWait = 1;                    // option "spin_wait": the multiply's waits for its stream poll (wait_stream)
+    long long specLaunches = 0, specRefuted = 0;
     int numDirectHint = -1;              // this data set's last whole multiply ran its numeric stage without queues (1), with them (0); -1: none yet
     int earlyFill = 1;                   // general pipeline: the queues filled while the host waits for the bin counts (starts computed on the device)
     int sortedScan = 1;                  // the sortedness scan of B at hand-over: 1 element-parallel (k_sorted_flat + k_sorted_starts), 0 row by row (k_check_sorted)
@@ -258,6 +267,7 @@ struct bhs_handle {
         bool numQueueFilled = false;     // the numeric queues of the whole multiply were filled behind the scan
         int spanWPL = 0;                 // this multiply's wave bins run k_row_span with this many bitmap words per lane (0: hash kernels)
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
+        bool specLaunched = false;       // the numeric kernel goes out on the last multiply's figures (classSpec), k_class_spec_check decides
         long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
     } ps;
     // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
@@ -279,7 +289,7 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
        S_SCAN_TICKET = 104 + 194 /* tile numbers of k_scan_onepass */,
        S_ZERO_END = 104 + 195,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_MAXROW = 301, S_OVF = 302 /* (free) */,
+       S_SORTED = 300, S_MAXROW = 301, S_SPEC = 302 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
        S_LONG_B = 303 /* rows on k_check_sorted's long list */,
        S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
        S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,

@@ -1130,6 +1130,61 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
         assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
+@pytest.mark.gpu
+def test_speculative_numeric_launch_is_verified_on_the_device(oracle):
+    """From a data set's second multiply on, the class path launches its numeric kernel on the figures of the multiply before
+    -- how many classes, their longest lists, the LDS they need, nnzC -- without reading this multiply's back first
+    (k_class_spec_check decides on the device; `spec_launches` / `spec_refuted`).  Values changed in the borrowed arrays: the
+    launch stands and the product has the new values.  One column index of A changed (a new relative pattern: one class more):
+    the launch is refuted, the multiply runs again the slow way and is right; the multiply after that speculates again."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m, rp, col, val = poisson_case("poisson27pt", 24, 24, 24)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Bp, Bj, Bx = t(rp), t(col), t(val)
+    Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.set_option("class_path", 2) == 0
+    assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
+
+    def check(acol, aval):
+        ref = oracle.spgemm(m, m, m, rp, acol, aval, rp, col, val)
+        assert bh.spgemm() == 0
+        assert "numeric_class" in {s["name"] for s in bh.kernel_stats()}
+        Cp = bh.get_rowptrC()
+        nnzC = bh.get_nnzC()
+        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert bh.nnzCt == oracle.nnzCt(rp, acol, rp)
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+
+    check(col, val)
+    assert bh.get_info("spec_launches") == 0
+    check(col, val); check(col, val)
+    assert bh.get_info("spec_launches") == 2 and bh.get_info("spec_refuted") == 0
+    val2 = val.copy(); val2[::7] += 3.0
+    Ax.copy_(t(val2)); torch.cuda.synchronize()
+    check(col, val2)
+    assert bh.get_info("spec_launches") == 3 and bh.get_info("spec_refuted") == 0
+    # an interior row's first column moves one to the left (still ascending, still inside the matrix)
+    r = m // 2
+    col2 = col.copy()
+    assert col2[rp[r]] > 0 and (rp[r] == rp[r - 1] or True)
+    col2[rp[r]] -= 1
+    Aj.copy_(t(col2)); torch.cuda.synchronize()
+    check(col2, val2)
+    assert bh.get_info("spec_launches") == 4 and bh.get_info("spec_refuted") == 1
+    check(col2, val2)
+    assert bh.get_info("spec_launches") == 5 and bh.get_info("spec_refuted") == 1
+    assert bh.set_option("spec_numeric", 0) == 0
+    check(col2, val2); check(col2, val2)
+    assert bh.get_info("spec_launches") == 5
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
 def _toeplitz(m, n, offsets, rng, holes=()):
     """m x n matrix whose row i has the columns i + o for o in offsets (those inside the matrix): every interior row
     has the same relative pattern.  `holes`: rows left empty."""

@@ -12,7 +12,7 @@ if name == "weblike":
     Bp, Bj = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
 else:
     st, dims = {"p27_128": ("poisson27pt", (128, 128, 128)), "p5_1024": ("poisson5pt", (1024, 1024, 1)), "p5_256": ("poisson5pt", (256, 256, 1)),
-                "p27_51": ("poisson27pt", (51, 51, 51)), "p9_1024": ("poisson9pt", (1024, 1024, 1)), "p7_128": ("poisson7pt", (128, 128, 128))}[name]
+                "p27_51": ("poisson27pt", (51, 51, 51)), "p27_160": ("poisson27pt", (160, 160, 160)), "p9_1024": ("poisson9pt", (1024, 1024, 1)), "p7_128": ("poisson7pt", (128, 128, 128))}[name]
     Bp, Bj = gallery.poisson_csr_torch(st, *dims, device=dev)
 Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
 Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
