@@ -19,7 +19,7 @@
 
 namespace bhs {
 
-constexpr int kClassTileBlock = 256;
+constexpr int kClassTileBlock = 512;
 #ifdef BHS_TILE_DEBUG
 __device__ int g_tileDbg[64 * 8];
 #endif
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
     constexpr int GPW = 64 / G;                                    // heads through the table at a time
     constexpr int WPB = kClassTileBlock / 64;
     constexpr int TCAP = 64 * LMAX;                                // column indices of a tile
-    constexpr int PW = LMAX, NC = 16;                              // the block's class cache: patterns of at most LMAX entries
+    constexpr int PW = LMAX, NC = 32;                              // the block's class cache: patterns of at most LMAX entries
     constexpr unsigned kBusy = 0xFFFFFFFEu;
     __shared__ unsigned ctag[NC];                                  // the block's cache of the class table (as in k_class_fused)
     __shared__ int cpat[NC][PW];

@@ -62,7 +62,7 @@ for kk, d in sorted(agg.items()):
     if n and have_r and have_w:
         out[n] = int(e["read_bytes"] + e["write_bytes"])
         out[n + " (read, write)"] = [int(e["read_bytes"]), int(e["write_bytes"])]
-    if have_r and ("k_check_sorted" in kk or "k_class_heads<false" in kk or "k_class_fused<false" in kk):
+    if have_r and ("k_check_sorted" in kk or "k_class_heads<false" in kk or "k_class_fused<false" in kk or "k_class_tile<false" in kk):
         check[kk + ": read / (4 nnzB + 4 (k + 1))"] = round(e["read_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
         if e["fetch_size_bytes"]:
             check[kk + ": FETCH_SIZE / same"] = round(e["fetch_size_bytes"] / (4.0 * nnzB + 4.0 * (k + 1)), 4)
