@@ -1185,6 +1185,50 @@ def test_speculative_numeric_launch_is_verified_on_the_device(oracle):
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 1, 3])
+@pytest.mark.parametrize("kind", ["grid", "band32_holes"])
+def test_lane_per_row_classifier(oracle, kind, shift):
+    """k_class_tile (bhs_class_tile.hip.h) brings 63 rows' column indices in as 16-byte loads from the 16-byte boundary at
+    or below the first of them: the borrowed colInd arrays are handed over `shift` ints off such a boundary, A's ending on
+    the allocation's last byte.  Rows of exactly 32 entries (the most a class row of this kernel has), empty rows in between,
+    more rows than one piece; against the oracle and against the lane-group classifier (class_tile = 0)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    if kind == "grid":
+        m, rp, col, val = poisson_case("poisson27pt", 19, 18, 17)
+    else:
+        m = 9000
+        rp, col, val = _toeplitz(m, m, tuple(range(-40, 88, 4)), rng, holes=(0, 1, 500, 501, 502, 4000, m - 1))
+        assert np.diff(rp).max() == 32
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def shifted(a):                                   # the array at `shift` elements into a buffer that ends with it
+        buf = torch.empty(len(a) + shift, dtype=torch.int32, device=dev)
+        buf[shift:] = t(a)
+        return buf[shift:]
+    Bp, Bj, Bx = t(rp), shifted(col), t(val)
+    Ap, Aj, Ax = t(rp), shifted(col), t(val)
+    ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    for tile in (1, 0):
+        bh = bhmod.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        assert bh.set_option("class_path", 2) == 0 and bh.set_option("class_tile", tile) == 0
+        assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
+        for _ in range(2):
+            assert bh.spgemm() == 0
+            assert "numeric_class" in {s["name"] for s in bh.kernel_stats()}
+            Cp = bh.get_rowptrC()
+            nnzC = bh.get_nnzC()
+            Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+            assert bh.get_C(Cj, Cx) == 0
+            assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
 def _toeplitz(m, n, offsets, rng, holes=()):
     """m x n matrix whose row i has the columns i + o for o in offsets (those inside the matrix): every interior row
     has the same relative pattern.  `holes`: rows left empty."""
