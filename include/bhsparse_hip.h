@@ -243,6 +243,14 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     rows before it takes it through the class table itself (bhs_class_fused.hip.h; period: sampled
  *                     at bhs_set_data time, the unknowns per node); 1: rounds 3-4's three launches per matrix (list
  *                     the rows that differ, classify the list, hand the classes on); 0: every row through the table
+ *   "class_tile"      1 (default): the classifier gives a row to ONE lane where rows have at most 32 entries (63 rows'
+ *                     column indices as 16-byte loads through a tile in LDS, bhs_class_tile.hip.h); 0: G lanes per row
+ *                     everywhere.  "class_tile_piece": rows a wave of it walks (0, default: one piece per wave slot)
+ *   "spec_numeric"    1 (default): from a data set's second multiply on, the class path launches its numeric kernel on
+ *                     the classes' figures of the multiply before (k_class_spec_check compares them with this multiply's
+ *                     on the device; a refuted launch writes nothing and the multiply runs again); 0: always wait for
+ *                     the read-back.  bhs_get_info: "spec_launches", "spec_refuted"
+ *   "spin_wait"       1 (default): a multiply's waits for its stream poll (<= 50 ms) before they sleep; 0: sleep at once
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),
