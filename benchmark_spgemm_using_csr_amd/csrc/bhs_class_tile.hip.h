@@ -5,15 +5,23 @@
 // them eight partly used cache lines, and for A as many scattered reads of B's classes again.  The pass is bound by those
 // instructions (classify_rows 0.25 ms on 128^3: 1.9 - 2.3 TB/s), not by its bytes.
 //
-// Here a wave takes 64 consecutive rows at a time:
-//   * their column indices are ONE contiguous piece of colInd: it comes in as 16-byte loads, 1 KB per instruction, straight
-//     into the wave's tile in LDS (7 instructions for 64 rows of 27);
-//   * lane i then owns row i: it reads its entries from the tile one by one (rows 27 words apart: no two lanes on a bank),
-//     gets the row before's from lane i - 1 by DPP, and compares.  For A the classes of the B rows behind entry e are
-//     classB[c + i] for 64 consecutive i on a grid -- one coalesced load per entry;
+// Here a wave takes 63 consecutive rows per step (lane 0 holds the row before them once more: every lane finds the row before
+// its own in the lane below, and nothing is carried from step to step):
+//   * their column indices are ONE contiguous piece of colInd: it comes in as 16-byte loads from the 16-byte boundary at or
+//     below its first entry, 1 KB per instruction (7 instructions for 63 rows of 27), into registers and from there into the
+//     wave's tile in LDS when the step begins -- the tile of step s + 1 and the row pointers of step s + 2 are on their way
+//     while step s is compared;
+//   * lane i owns row i: it reads its entries from the tile (rows 27 words apart: no two lanes on a bank), gets the row
+//     before's from lane i - 1 by DPP (wave_shr:1), and compares.  For A the classes of the B rows behind entry e are
+//     classB[c + i] for 64 consecutive i on a grid -- one coalesced load per entry, eight entries in flight;
 //   * a row that differs from the row before it (a head: one in fifty on a grid) goes through the class table exactly as in
 //     k_class_fused -- G lanes, E entries each, read back from the tile -- eight heads at a time; the classes are handed on
-//     along the wave's walk in the same way.
+//     along the wave's walk by a running maximum of (position, class);
+//   * 512 lanes per workgroup share the block's class cache; 16 waves per CU (128 VGPRs, 9 KB of LDS per wave); the host cuts
+//     the rows into one piece per wave slot of the device.
+// Everything that crosses lanes (DPP moves, shuffles, ballots) is computed by ALL lanes, unconditionally: behind `a || b` the
+// lanes that have their answer are masked out, and a masked-out lane hands its neighbour nothing (the first form of this
+// kernel made every row behind a head a head that way).
 // Rows compared `period` apart (block-structured matrices) stay with k_class_fused.
 #pragma once
 
