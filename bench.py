@@ -337,21 +337,31 @@ def main():
     stage = np.zeros(4)
     t_compute = 0.0
     step_ms = []
+    # (the per-kernel timers of every step are fetched inside the loop -- one C call into an array set up beforehand -- and read
+    # after it: the bookkeeping between two multiplies is this script's, not the multiply's, and took 40-50 us of Python a step)
+    from benchmark_spgemm_using_csr_amd import _lib as _rawlib
+    raw_stats = [(_rawlib.KernelStat * 64)() for _ in range(args.steps)]
+    raw_n = [0] * args.steps
+    stage_l, tcomp_l = [None] * args.steps, [0.0] * args.steps
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
         tc = time.perf_counter()
         full = step()
         step_ms.append((time.perf_counter() - tc) * 1e3)
-        for s in bh.kernel_stats():
+        raw_n[i_] = bh.kernel_stats_raw(raw_stats[i_])
+        stage_l[i_] = bh.stage_ms
+        tcomp_l[i_] = bh.time_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for i_ in range(args.steps):
+        for s in bh.decode_kernel_stats(raw_stats[i_], raw_n[i_]):
             d = kstats.setdefault(s["name"], {"ms": 0.0, "launches": 0, "rows": 0, "products": 0, "nnz_out": 0,
                                               "nnzA_rows": 0, "steps": 0})
             d["ms"] += s["ms"]; d["launches"] += s["launches"]; d["steps"] += 1
             for kk in ("rows", "products", "nnz_out", "nnzA_rows"):
                 d[kk] = s[kk]
-        stage += np.array(bh.stage_ms)
-        t_compute += bh.time_ms
-    barrier()
-    elapsed = time.perf_counter() - t0
+        stage += np.array(stage_l[i_])
+        t_compute += tcomp_l[i_]
     state_after = gpu_state() if rank == 0 else None
     # ... and once UNDER LOAD (outside the timed region): rocm-smi is asked while this rank keeps multiplying for about a
     # second -- boxes of the pool differ by up to 15 % on the same build, and the clocks an idle GPU reports say nothing

@@ -227,6 +227,17 @@ class bhsparse(object):
             raise BhsparseError("bhs_get_rowptrC", err)
         return out
 
+    def kernel_stats_raw(self, arr):
+        """bhs_get_kernel_stats into a caller's (_lib.KernelStat * 64)(): the number of records (decode_kernel_stats reads
+        them later -- a timed loop pays one C call per multiply, not a dozen dictionaries)"""
+        return self._lib.bhs_get_kernel_stats(self._h, arr, 64)
+
+    @staticmethod
+    def decode_kernel_stats(arr, nrec):
+        return [{"name": arr[i].name.decode(), "launches": arr[i].launches, "ms": arr[i].ms, "rows": arr[i].rows,
+                 "products": arr[i].products, "nnz_out": arr[i].nnz_out, "nnzA_rows": arr[i].nnzA_rows}
+                for i in range(min(nrec, 64))]
+
     def kernel_stats(self):
         arr = (_lib.KernelStat * 64)()
         nrec = self._lib.bhs_get_kernel_stats(self._h, arr, 64)
