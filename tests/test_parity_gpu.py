@@ -1371,9 +1371,25 @@ def test_row_class_path_randomized(oracle, seed):
     """Randomised structured inputs against the oracle with the class kernels forced on: random offset lists (a few to
     64 entries per row), rectangular shapes, rows cut off at the borders, a sprinkling of rows with extra or missing
     entries (more classes, some met once), empty rows, B rows stored in random order, values of either sign."""
+    _randomized_class_case(oracle, seed, big=False)
+
+
+if os.environ.get("BHS_SOAK") == "1":             # (BHS_SOAK=1 python -m pytest tests -m gpu -k soak -n 4: 1.5 minutes)
+    @pytest.mark.parametrize("seed", list(range(100, 220)))
+    def test_row_class_path_soak(oracle, seed):
+        """The same draw with up to 40 000 rows of at most 32 entries: many steps and pieces of the lane-per-row classifier
+        (bhs_class_tile.hip.h), heads in every lane, last steps of every length.  Round 5: 120 of 120 bit-exact."""
+        _randomized_class_case(oracle, seed, big=True)
+
+
+def _randomized_class_case(oracle, seed, big):
     rng = np.random.default_rng(1000 + seed)
-    m = int(rng.integers(200, 3000)); k = int(rng.integers(200, 3000)); n = int(rng.integers(200, 4000))
-    na = int(rng.choice([1, 2, 5, 9, 17, 31, 64])); nb = int(rng.choice([1, 3, 7, 15, 16, 33]))
+    if big:
+        m = int(rng.integers(2000, 40000)); k = int(rng.integers(2000, 40000)); n = int(rng.integers(2000, 50000))
+        na = int(rng.choice([1, 2, 5, 9, 17, 27, 31, 32])); nb = int(rng.choice([1, 3, 7, 15, 16, 27, 32]))
+    else:
+        m = int(rng.integers(200, 3000)); k = int(rng.integers(200, 3000)); n = int(rng.integers(200, 4000))
+        na = int(rng.choice([1, 2, 5, 9, 17, 31, 64])); nb = int(rng.choice([1, 3, 7, 15, 16, 33]))
 
     def structured(rows, cols, cnt, noise):
         offs = np.unique(rng.integers(-cols // 3, cols // 3 + 1, cnt))
