@@ -362,7 +362,7 @@ int symbolic_class(bhs_handle* h)
                         // 2 M rows in pieces of 504 are 4161 waves for 4096 slots -- a second round for 65 of them (classify_rows
                         // 0.227 -> ... ms on poisson27pt 128^3)
                         const long long slots = (long long)h->numCU * 16;
-                        int pieceT = 63 * (int)std::max<long long>(2, std::min<long long>(64, ((long long)n + slots * 63 - 1) / (slots * 63)));
+                        int pieceT = 63 * (int)std::max<long long>(2, std::min<long long>(4096, ((long long)n + slots * 63 - 1) / (slots * 63)));   // (a row's place in its piece has 18 bits)
                         if (h->classTilePiece > 0) pieceT = std::max(63, h->classTilePiece / 63 * 63);
                         const long long perBlockT = (long long)(kClassTileBlock / 64) * pieceT;
                         hipLaunchKernelGGL((k_class_tile<IS_A, GG, E>), dim3((unsigned)std::max<long long>(1, ((long long)n + perBlockT - 1) / perBlockT)), dim3(kClassTileBlock), 0,
