@@ -72,6 +72,10 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
     if (threadIdx.x < NC) { ctag[threadIdx.x] = 0xFFFFFFFFu; clen[threadIdx.x] = -1; }
     __syncthreads();
     const long long wave = (long long)blockIdx.x * WPB + wv;
+    if (pieceRows <= 0) {                                          // one piece per wave of the launch, whole steps: the rows in question are known here, not on the host
+        const long long rows = max(0ll, (long long)nrows - first), waves = (long long)gridDim.x * WPB;
+        pieceRows = 63 * (int)max(1ll, (rows + waves * 63 - 1) / (waves * 63));
+    }
     const long long pieceBegin = first + wave * pieceRows;
     const long long pieceEnd = min((long long)nrows, pieceBegin + pieceRows);
     // a step takes 63 new rows: lane 0 holds the row BEFORE them (classified by the step before, or by the wave before) once

@@ -358,14 +358,21 @@ int symbolic_class(bhs_handle* h)
                 if constexpr (GG * E <= 32) {
                     // a lane per row, the rows' column indices through a tile in LDS (bhs_class_tile.hip.h)
                     if (h->classTile && period == 1) {
-                        // whole steps of 63 new rows, and as many of them as give every wave slot of the device (16 per CU) ONE piece:
-                        // 2 M rows in pieces of 504 are 4161 waves for 4096 slots -- a second round for 65 of them (classify_rows
-                        // 0.227 -> ... ms on poisson27pt 128^3)
+                        // as many waves as the device has slots for them (16 per CU), ONE piece each, in whole steps of 63 new rows: 2 M
+                        // rows in pieces of 504 were 4161 waves for 4096 slots -- a second round for 65 of them (classify_rows 0.227 ->
+                        // 0.176 ms on poisson27pt 128^3).  The kernel works the piece out itself: with a row range (A a row block of a
+                        // larger product: only the rows of B that A points at) the rows in question are known on the device only.
                         const long long slots = (long long)h->numCU * 16;
-                        int pieceT = 63 * (int)std::max<long long>(2, std::min<long long>(4096, ((long long)n + slots * 63 - 1) / (slots * 63)));   // (a row's place in its piece has 18 bits)
-                        if (h->classTilePiece > 0) pieceT = std::max(63, h->classTilePiece / 63 * 63);
-                        const long long perBlockT = (long long)(kClassTileBlock / 64) * pieceT;
-                        hipLaunchKernelGGL((k_class_tile<IS_A, GG, E>), dim3((unsigned)std::max<long long>(1, ((long long)n + perBlockT - 1) / perBlockT)), dim3(kClassTileBlock), 0,
+                        // (at most 4096 steps per piece: a row's place in its piece has 18 bits)
+                        const long long wavesT = std::max<long long>(std::max<long long>(1, ((long long)n + 63 * 4096 - 1) / (63 * 4096)), std::min<long long>(slots, ((long long)n + 125) / 126));
+                        long long blocksT = (wavesT + kClassTileBlock / 64 - 1) / (kClassTileBlock / 64);
+                        int pieceT = 0;
+                        if (h->classTilePiece > 0) {
+                            pieceT = std::max(63, h->classTilePiece / 63 * 63);
+                            const long long perBlockT = (long long)(kClassTileBlock / 64) * pieceT;
+                            blocksT = std::max<long long>(1, ((long long)n + perBlockT - 1) / perBlockT);
+                        }
+                        hipLaunchKernelGGL((k_class_tile<IS_A, GG, E>), dim3((unsigned)blocksT), dim3(kClassTileBlock), 0,
                                            h->stream, n, Rp, Rj, cb, out, tab, cstats, (long long)(IS_A ? h->nnzA : h->nnzB), pieceT, rng);
                         return (int)BHS_SUCCESS;
                     }
