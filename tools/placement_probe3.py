@@ -15,7 +15,7 @@ Bx = gallery.fill_values_torch(Bj.numel(), device=dev)
 Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
 m = Bp.numel() - 1
 plats = [False] * 9; plats[3] = True
-bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
+bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0   # (BHSPARSE_HIP_LIB picks the build)
 assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Bj.numel(), Bx, Bp, Bj) == 0
 assert bh.spgemm() == 0
 nnzC = bh.get_nnzC()
