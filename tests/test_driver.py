@@ -267,3 +267,61 @@ def test_driver_gpus_option_one_process_per_gpu(driver, args, expect):
     assert "[ HIP x 1 ] SpGEMM + all-gatherv time:" in out and "row blocks (balanced by products): 0" in out
     assert "RowPtrC PASS!" in out and "ColIndC/csrValC PASS!" in out and '"gpus": 1' in out and '"pass": true' in out
     assert expect in out
+
+
+# ---- the reference's OWN driver, unchanged, on top of the facade (literal drop-in proof) ----
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "ref_main_on_hip")
+
+
+def _ref_main():
+    """oracle/_ref/ref_main_on_hip = /root/reference/SpGEMM_opencl/main.cpp compiled AS IT LIES (oracle/Makefile,
+    oracle/ref_main_dropin.cpp) against host/common.h + host/bhsparse.h and linked to libbhsparse_hip.so.  Built in
+    the development container (the reference tree is not on the GPU box; the binary travels like the other .so)."""
+    if not os.path.exists(REF_MAIN):
+        if os.path.isdir("/root/reference/SpGEMM_opencl"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/ref_main_on_hip"])
+        else:
+            pytest.skip("oracle/_ref/ref_main_on_hip was not built (needs /root/reference at build time)")
+    return REF_MAIN
+
+
+def test_reference_main_unchanged_links_the_facade():
+    """CPU side: the binary exists, is linked against the product library (and not the oracle), and -- without a
+    GPU -- fails the way the reference's main prints a failure (main.cpp:447)."""
+    exe = _ref_main()
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    libs = [ln.split()[0] for ln in ldd.splitlines() if ln.strip()]
+    assert "libbhsparse_hip.so" in libs and not any("oracle" in x or "OpenCL" in x for x in libs), libs
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe, "-opencl", "-spgemm", "0"], capture_output=True, text=True, timeout=60)
+        assert "Found an err, code = -2" in p.stdout
+
+
+@pytest.mark.gpu
+def test_reference_main_unchanged_small_test_and_cage4(hiplib):
+    """`./spgemm -opencl -spgemm 0` and `./spgemm -opencl -spgemm cage4.mtx` (README.md:56-58) through the
+    reference's own main(): its prints, our multiply."""
+    exe = _ref_main()
+    out = _run(exe, "-opencl", "-spgemm", "0")
+    assert "nnzC = 6" in out and "Found an err" not in out and "[ HIP ] SpGEMM time:" in out
+    out = _run(exe, "-opencl", "-spgemm", os.path.join(GOLDEN, "cage4.mtx"))
+    assert "( n = 9, nnz = 49 )" in out and "nnzC = 81" in out and "Found an err" not in out
+    out = _run(exe, "-opencl-hcmp", "-spgemm", os.path.join(GOLDEN, "cage4.mtx"))     # use_host_mem: accepted, ignored
+    assert "nnzC = 81" in out and "Found an err" not in out
+
+
+@pytest.mark.gpu
+def test_reference_main_unchanged_stencil_file(hiplib, tmp_path):
+    """A bigger file through the reference's own reader and main(): poisson27pt 40^3 written as a symmetric
+    Matrix-Market file (its reader mirrors the lower triangle, main.cpp:100-196, and leaves rows in file order,
+    i.e. UNSORTED -- the multiply has to cope) -> nnz(C) of the closed form."""
+    from benchmark_spgemm_using_csr_amd import gallery
+    import numpy as np
+    rp, col = gallery.poisson_csr("poisson27pt", 40, 40, 40)
+    m = len(rp) - 1
+    path = tmp_path / "p27_40.mtx"
+    _write_mtx(str(path), m, m, rp, col, np.ones(len(col)), symmetric=True)
+    out = _run(_ref_main(), "-opencl", "-spgemm", str(path), timeout=600)
+    assert "( n = %d, nnz = %d )" % (m, len(col)) in out, out[-800:]
+    assert "nnzC = %d" % ((5 * 40 - 6) ** 3) in out and "Found an err" not in out, out[-800:]
