@@ -40,6 +40,9 @@ constexpr int kClassBigMaxP = 8192;        //   grids -- several unknowns per no
 constexpr int kClassBigCap = 1024;         // big classes per multiply
 constexpr int kClassMaxNnz = 512;          // entries per row of C
 constexpr unsigned long long kClassEmpty = ~0ull;
+constexpr int kClassDummy = kClassSlots;    // mixed mode: the "class" of a row without one -- slot kClassSlots of classInfo / classRing / classLane, all zeros: no entries, no products
+constexpr int kClassManyClasses = 256;     // more classes than this in a multiply: are they classes, or single rows? (the mixed flow counts)
+constexpr int kClassMixMinRows = 4;        // mixed mode (bhs_class_mix.hip.h): a class with fewer rows than this is not worked out, its rows are irregular
 
 // `stats` block written by k_class_rows / k_class_patterns (ints)
 constexpr int kClassSumSlots = 32;
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
                                                         unsigned* __restrict__ classMapA,
                                                         int* __restrict__ classRel, int* __restrict__ classLane,
                                                         unsigned* __restrict__ classRing,   // nullptr: not wanted
-                                                        int* __restrict__ stats)
+                                                        int* __restrict__ stats,
+                                                        const int* __restrict__ rowCount = nullptr)   // round 6 (bhs_class_mix.hip.h): rows per class; a class of a few rows is not worked out (z = -1: its rows are irregular)
 {
     __shared__ int keys[kClassMaxP], srt[kClassMaxP], pk[kClassMaxP];
     __shared__ int sIncl[kClassMaxRow], sB0[kClassMaxRow], scan[256];
@@ -642,6 +646,10 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         return;
     }
     const int rep = (int)(unsigned)v;
+    if (rowCount != nullptr && rowCount[s] < kClassMixMinRows) {
+        if (tid == 0) classInfo[s] = make_int4(0, 0, -1, rep);
+        return;
+    }
     const int a0 = Ap[rep], nA = Ap[rep + 1] - a0;               // <= kClassMaxRowBig (k_class_rows)
     if (nA > kClassMaxRow) {                                       // a big class: k_class_patterns_big's (z = -2: not done yet)
         if (tid == 0) classInfo[s] = make_int4(nA, 0, -2, rep);
@@ -1062,7 +1070,8 @@ __global__ __launch_bounds__(256) void k_class_expand_columns(int n, int row0, c
 constexpr int kClassScanBlock = 1024, kClassScanPer = 8, kClassScanTile = kClassScanBlock * kClassScanPer;   // (few tiles: short look-backs)
 __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int* __restrict__ classC, const int4* __restrict__ classInfo,
                                                     int* __restrict__ Cp, unsigned long long* __restrict__ state,
-                                                    long long* __restrict__ totalOut, int* __restrict__ stats)
+                                                    long long* __restrict__ totalOut, int* __restrict__ stats,
+                                                    bool mixed)       // round 6 (bhs_class_mix.hip.h): a row without a class has its count in Cp already (the general pipeline's symbolic kernels)
 {
     constexpr int NW = kClassScanBlock / 64;
     __shared__ int sTile, wsum[NW];
@@ -1080,11 +1089,13 @@ __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int
     for (int j = 0; j < kClassScanPer; ++j) {
         v[j] = 0;
         const int c = base + j < m ? classC[base + j] : -1;
-        if (c >= 0) {
+        if (c >= 0 && c != kClassDummy) {
             const int4 ci = classInfo[c];
             v[j] = ci.z > 0 ? ci.z : 0;
             products += (unsigned long long)ci.y;
             pending = pending || ci.z == -2;
+        } else if (mixed && c == kClassDummy) {
+            v[j] = Cp[base + j];                                  // (read and overwritten by this thread alone)
         }
         mine += v[j];
     }

@@ -102,6 +102,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
         if (lane < nr) { r.ap = Ap[row0 + lane]; r.ap1 = Ap[row0 + lane + 1]; r.cp = Cp[row0 + lane]; r.cls = classC[row0 + lane]; }
         return r;
     };
+    // Where the chunk of A's values that starts at row s of a block ends (exclusive): G rows on, at the block's end -- or,
+    // mixed mode (bhs_class_mix.hip.h), in front of and behind a row without a class (kClassDummy): such a row may be longer
+    // than the 128 entries a chunk holds, so it is a chunk of its own (loaded, never looked at) and the rows of a class behind
+    // it start a new one.  Scalar arithmetic on a ballot, where a chunk is taken up: nothing here lives across rows.
+    auto chunk_end = [&](const Ptrs& p, int s, int nrB) -> int {
+        const unsigned long long dummy = __ballot(p.cls == kClassDummy);      // (lanes beyond the block's rows carry -1)
+        unsigned long long ends = dummy | (dummy >> 1) | (1ull << (nrB - 1));
+        if (s + chunkRows - 1 < 64) ends |= 1ull << (s + chunkRows - 1);
+        return s + __builtin_ctzll(ends >> s) + 1;
+    };
     // a chunk of valA: the entries [base, base + nE), nE <= 128, two per lane (the last value of valA is not read as the
     // first half of a pair)
     auto load_chunk = [&](int base, int nE) {
@@ -157,7 +167,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     };
 
     // ---- prologue: the first block's pointers, the first chunk of A's values, the next chunk's request
-    const int G = chunkRows;
     int nr = 0, nrN = 0;
     int row0 = block_of(0, nr), row0N = 0;
     Ptrs pc = load_ptrs(row0, nr), pn{0, 0, 0, -1};
@@ -167,11 +176,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     bool nxtValid = false;
     int nEnd = 0;                                                // the requested chunk: rows [.., nEnd) of its block
     if (nr > 0) {
-        cEnd = min(G, nr);
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);                    // (the first block's classes: chunk_end looks at them)
+        cEnd = chunk_end(pc, 0, nr);
         curBase = __builtin_amdgcn_readlane(pc.ap, 0);
         axCur = load_chunk(curBase, __builtin_amdgcn_readlane(pc.ap1, cEnd - 1) - curBase);
         if (cEnd < nr) {
-            nEnd = min(cEnd + G, nr);
+            nEnd = chunk_end(pc, cEnd, nr);
             const int b = __builtin_amdgcn_readlane(pc.ap, cEnd);
             axNxt = load_chunk(b, __builtin_amdgcn_readlane(pc.ap1, nEnd - 1) - b);
             nxtValid = true;
@@ -186,7 +196,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
         pn = load_ptrs(row0N, nrN);                              // (consumed behind this block's first vmcnt(0) at the earliest)
         BHS_TICK_CLS(0);
         for (int t = 0; t < nr; ++t) {
-            const int cls = __builtin_amdgcn_readlane(pc.cls, t);    // (>= 0: a multiply with an unclassified row was sent back)
+            // (>= 0.  Mixed mode, bhs_class_mix.hip.h: a row without a class carries kClassDummy, the class of no entries and no
+            // products whose tables are all zeros -- the row loads nothing, multiplies nothing and stores nothing, it ends a
+            // stretch like any change of class, and this loop has no branch for it: at <= 128 VGPRs and 33 spilled SGPRs one more
+            // edge to the loop's latch cost 150 spilled VGPRs.)
+            const int cls = __builtin_amdgcn_readlane(pc.cls, t);
             const int row = row0 + t;
             const int apT = __builtin_amdgcn_readlane(pc.ap, t);
             if (cls != cur) {                                        // (wave-uniform)
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 const bool more = t + 1 < nr;                        // the next chunk is in this block
                 if (more || nrN > 0) {
                     const int s0 = more ? t + 1 : 0, nrB = more ? nr : nrN;
-                    const int e0 = min(s0 + G, nrB);
+                    const int e0 = more ? chunk_end(pc, s0, nrB) : chunk_end(pn, s0, nrB);
                     const int b0 = more ? __builtin_amdgcn_readlane(pc.ap, s0) : __builtin_amdgcn_readlane(pn.ap, 0);
                     if (nxtValid) axCur = axNxt;
                     else {                                           // (a block of one chunk: on demand)
@@ -329,12 +343,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                     // behind it, if that is the next block (its pointers are here); else on demand
                     nxtValid = false;
                     if (e0 < nrB) {
-                        const int e1 = min(e0 + G, nrB);
+                        const int e1 = more ? chunk_end(pc, e0, nrB) : chunk_end(pn, e0, nrB);
                         const int b1 = more ? __builtin_amdgcn_readlane(pc.ap, e0) : __builtin_amdgcn_readlane(pn.ap, e0);
                         axNxt = load_chunk(b1, (more ? __builtin_amdgcn_readlane(pc.ap1, e1 - 1) : __builtin_amdgcn_readlane(pn.ap1, e1 - 1)) - b1);
                         nxtValid = true;
                     } else if (more && nrN > 0) {
-                        const int e1 = min(G, nrN);
+                        const int e1 = chunk_end(pn, 0, nrN);
                         const int b1 = __builtin_amdgcn_readlane(pn.ap, 0);
                         axNxt = load_chunk(b1, __builtin_amdgcn_readlane(pn.ap1, e1 - 1) - b1);
                         nxtValid = true;

@@ -106,6 +106,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
     release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRing); release(h->classRel); release(h->classLane);
     release(h->classBigIdx); release(h->classBigMap);
+    release(h->mixList); release(h->classCount);
     release(h->bWin); release(h->bWinTab); release(h->bWinSpill);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
@@ -368,6 +369,8 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "spec_numeric")) { h->specNumeric = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile_piece")) { h->classTilePiece = (int)std::max<long long>(0, std::min<long long>(value, 1 << 17)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile")) { h->classTile = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_mixed")) { h->mixOn = value ? 1 : 0; h->classMixed = 0; if (h->classState < 0) h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "class_mixed_max_pct")) { h->mixMaxPct = (int)std::max<int64_t>(0, std::min<int64_t>(value, 100)); return BHS_SUCCESS; }
     if (!strcmp(key, "spin_wait")) { h->spinWait = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "force_path")) { h->forcePath = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "max_table_log2")) {
@@ -437,6 +440,8 @@ int bhs_get_info(bhs_handle* h, const char* key, int64_t* value_out)
     if (!strcmp(key, "span_words")) { *value_out = h->ps.spanWPL; return BHS_SUCCESS; }   // bitmap words per lane of the last multiply's span kernels (0: hash kernels)
     if (!strcmp(key, "spec_launches")) { *value_out = h->specLaunches; return BHS_SUCCESS; }   // multiplies whose numeric kernel went out before the host saw the classes, so far
     if (!strcmp(key, "spec_refuted")) { *value_out = h->specRefuted; return BHS_SUCCESS; }     // ... of them, refuted on the device and run again
+    if (!strcmp(key, "mixed_rows")) { *value_out = h->ps.mixed ? h->ps.mixRows : 0; return BHS_SUCCESS; }   // rows of the last multiply that went through the general kernels beside the class kernels
+    if (!strcmp(key, "class_state")) { *value_out = h->classState < 0 ? -1 : (h->classMixed ? 2 : 1); return BHS_SUCCESS; }   // -1 general pipeline for good, 1 row classes, 2 row classes with irregular rows
     if (!strcmp(key, "max_row_a")) { *value_out = h->maxRowA; return BHS_SUCCESS; }
     if (!strcmp(key, "max_row_b")) { *value_out = h->maxRowB; return BHS_SUCCESS; }
     if (!strcmp(key, "local_a")) { *value_out = h->localA; return BHS_SUCCESS; }
@@ -453,7 +458,7 @@ int bhs_get_class_tables_device(bhs_handle* h, const int** d_classC, const void*
     if (slots_out) *slots_out = kClassSlots;                       // (the table geometry is a property of the build)
     if (rel_stride_out) *rel_stride_out = kClassMaxNnz;
     if (!h->hasC && !h->ps.open) return BHS_ERR_NOT_READY;
-    const bool usable = h->ps.useClass && !h->ps.classBig && !h->ps.empty;
+    const bool usable = h->ps.useClass && !h->ps.classBig && !h->ps.empty && !h->ps.mixed;   // (a row without a class has no columns to rebuild)
     *usable_out = usable ? 1 : 0;
     if (d_classC) *d_classC = usable ? (const int*)h->classC.p : nullptr;
     if (d_classInfo) *d_classInfo = usable ? (const void*)h->classInfo.p : nullptr;

@@ -1,6 +1,20 @@
 // bhs_host_launch.inc.h -- the launch helpers: grid, LDS and template instance of every kernel family
 // (A part of bhsparse_hip.hip's translation unit: included there, inside its unnamed namespace where that applies.)
 
+// The classifier's kernels are sized by the longest row.  Where only a few rows are long (a constraint row, a handful of
+// boundary rows: fewer than one in 64) the others' longest row sizes them instead: a longer row finds no class and goes
+// through the general pipeline's kernels, mixed mode (bhs_class_mix.hip.h).  A hint like every other: checked per row.
+int cls_row(const bhs_handle* h, int maxRow, const int* st, int rows)
+{
+    int eff = maxRow;
+    if (!h->mixOn) return eff;
+    if (eff > kClassMaxRowBig && st[2] > 0 && (long long)st[2] * 64 <= rows) eff = st[3];
+    if (eff > kClassMaxRow && st[0] > 0 && (long long)st[0] * 64 <= rows) eff = st[1];
+    return eff;
+}
+int cls_row_a(const bhs_handle* h) { return cls_row(h, h->maxRowA, h->lenStatsA, h->m); }
+int cls_row_b(const bhs_handle* h) { return cls_row(h, h->maxRowB, h->lenStatsB, h->k); }
+
 template <int LOG2TS, int BLOCK, bool NUM>
 int launch_row_block(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, const int* qnPtr = nullptr)
 {
@@ -308,7 +322,7 @@ int launch_class_ring_impl(bhs_handle* h, int r0, int r1)
     const long long nSuper = ((long long)mR + superRows - 1) / superRows;
     long long grid = std::min<long long>(nSuper, (long long)h->numCU * useCU);
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
-    const int chunkRows = std::max(1, std::min(64, 128 / std::max(1, h->ps.classMaxNA)));   // whole rows, <= 128 entries of A
+    const int chunkRows = std::max(1, std::min(64, 128 / std::max(1, h->ps.classMaxNA)));   // whole rows of a class, <= 128 entries of A (a row without a class is a chunk of its own: chunk_end)
     if (h->verbose > 1) printf("  [class numeric (ring, round 5): %d waves per CU by the occupancy API, %d used, %zu bytes of LDS each, grid %lld, %d rows per chunk]\n", perCU, useCU, lds.bytes, grid, chunkRows);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.bytes, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        (long long)h->nnzA, h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,

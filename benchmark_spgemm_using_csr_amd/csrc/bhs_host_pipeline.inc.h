@@ -30,14 +30,15 @@ int pow2_at_least(double x, int lo, int hi)
 
 // Concurrent bins: fork the side streams from `stream`, give every bin its own stream (round robin) and ticket
 // word, join them back.  Otherwise everything stays on `stream`, one kernel after another.
-int fork_bins(bhs_handle* h, const int* count, int nbins)
+int fork_bins(bhs_handle* h, const int* count, int nbins, bool always = false)
 {
     h->ls = h->stream;
     int used = 0;
     for (int b = 1; b < nbins; ++b) used += count[b] > 0;
     // forking and joining four streams costs ~70 us of event traffic: it pays for power-law matrices whose rows
     // spread over many small bins, not for a stencil with one dominant bin
-    h->binsForked = h->concurrentBins == 1 || (h->concurrentBins == 2 && used >= 8);
+    // (always: mixed mode's numeric stage -- the bins of the irregular rows run beside the ring kernel)
+    h->binsForked = always || h->concurrentBins == 1 || (h->concurrentBins == 2 && used >= 8);
     if (!h->binsForked) return BHS_SUCCESS;
     BHS_HIP(hipEventRecord(h->evFork, h->stream));
     for (int i = 0; i < bhs_handle::kBinStreams; ++i) BHS_HIP(hipStreamWaitEvent(h->binStream[i], h->evFork, 0));
@@ -284,23 +285,38 @@ int class_dispatch(int G, int E, F&& f)
 // Stages 1 and 2 by row classes (bhs_class.hip.h): classify the rows of B and A, work out every class's pattern,
 // write the per-row counts.  Everything is launched without a host round trip; stage 3's read-back tells whether every
 // row found a class (otherwise the multiply starts over on the general pipeline).
-int symbolic_class(bhs_handle* h)
+// rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
+int hub_min_products(const bhs_handle* h)
+{
+    return (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25)) ? h->hubMin : 0;
+}
+
+// mixed: the flow of bhs_class_mix.hip.h -- B's single-row classes are pruned before A is classified, classes of a few rows
+// are not worked out, the irregular rows of A are listed and get their product counts (symSpec: their symbolic bins)
+int symbolic_class(bhs_handle* h, bool mixed, const BinSpec& symSpec)
 {
     const int m = h->m, k = h->k;
+    const int clsA = cls_row_a(h), clsB = cls_row_b(h);           // the longest rows the classifier is sized for
     int* small = (int*)h->small.p;
     EventPair* ep;
     BHS_TRY(ensure(h, h->classB, sizeof(int) * (size_t)std::max(k, 1)));
     BHS_TRY(ensure(h, h->classC, sizeof(int) * (size_t)std::max(m, 1)));
     BHS_TRY(ensure(h, h->classTab, sizeof(unsigned long long) * 2 * kClassSlots));
-    BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * kClassSlots));
+    // (one slot more than the table has: kClassDummy, the class of the rows without one in mixed mode -- all zeros, written by nobody)
+    BHS_TRY(ensure(h, h->classInfo, sizeof(int4) * (kClassSlots + 1), true));
     BHS_TRY(ensure(h, h->classMap, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
     BHS_TRY(ensure(h, h->classMapA, sizeof(unsigned) * (size_t)kClassSlots * kClassMaxP));
-    BHS_TRY(ensure(h, h->classRing, sizeof(unsigned) * (size_t)kClassSlots * kClassRingStride));
+    BHS_TRY(ensure(h, h->classRing, sizeof(unsigned) * (size_t)(kClassSlots + 1) * kClassRingStride, true));
     BHS_TRY(ensure(h, h->classRel, sizeof(int) * (size_t)kClassSlots * kClassMaxNnz));
-    BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)kClassSlots * kClassLaneInts));
+    BHS_TRY(ensure(h, h->classLane, sizeof(int) * (size_t)(kClassSlots + 1) * kClassLaneInts, true));
     BHS_TRY(ensure(h, h->classHeads, sizeof(int) * ((size_t)std::max(std::max(m, k), 1) + (size_t)kClassHeadSegs * (kClassHeadsBlock / 64) * kClassHeadPiece)));
     // classes beyond the register kernels' tables are possible: their lists and the big numeric kernel (bhs_class_big.hip.h)
-    const bool bigPossible = h->maxRowA > kClassMaxRow || h->maxRowB > kClassMaxRow || (long long)h->maxRowA * h->maxRowB > kClassMaxP;
+    const bool bigPossible = clsA > kClassMaxRow || clsB > kClassMaxRow || (long long)clsA * clsB > kClassMaxP;
+    if (mixed) {
+        BHS_TRY(ensure(h, h->mixList, sizeof(int) * (size_t)std::max(m, 1)));
+        BHS_TRY(ensure(h, h->classCount, sizeof(int) * 2 * kClassSlots));
+        BHS_HIP(hipMemsetAsync(h->classCount.p, 0, sizeof(int) * 2 * kClassSlots, h->stream));
+    }
     BHS_TRY(ensure(h, h->classBigIdx, sizeof(int) * kClassSlots));
     if (bigPossible) BHS_TRY(ensure(h, h->classBigMap, sizeof(unsigned) * (size_t)kClassBigCap * kClassBigMaxP));
     BHS_TRY(ensure(h, h->classHeadCnt, sizeof(int) * 2 * 16 * kClassHeadSegs));
@@ -338,8 +354,8 @@ int symbolic_class(bhs_handle* h)
     int* nHeadsB = (int*)h->classHeadCnt.p;
     int* nHeadsA = nHeadsB + 16 * kClassHeadSegs;
     // (~2 entries per lane in flight; a data set with rows of more than kClassMaxRow entries: 64 lanes, 2 or 4 entries each)
-    const int GB = h->maxRowB > kClassMaxRow ? 64 : pow2_at_least(h->avgRowB / h->classPerLane, 4, 64);
-    const int GA = h->maxRowA > kClassMaxRow ? 64 : pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);
+    const int GB = clsB > kClassMaxRow ? 64 : pow2_at_least(h->avgRowB / h->classPerLane, 4, 64);
+    const int GA = clsA > kClassMaxRow ? 64 : pow2_at_least(h->avgRowA / h->classPerLane, 4, 64);
     const int periodA = std::max(1, std::min(8, h->periodA)), periodB = std::max(1, std::min(8, h->periodB));
     const unsigned rowsGridList = (unsigned)std::max(1, h->numCU / (2 * kClassHeadSegs));
     const unsigned propGrid = (unsigned)std::max<long long>(1, std::min<long long>(((long long)std::max(m, k) + 255) / 256, (long long)h->numCU * 8));
@@ -392,10 +408,21 @@ int symbolic_class(bhs_handle* h)
             return (int)BHS_SUCCESS;
         });
     };
-    int rc = classify(template_int<0>{}, k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, nHeadsB, GB, h->maxRowB, periodB);
+    int* countB = (int*)h->classCount.p;
+    int* countA = mixed ? countB + kClassSlots : nullptr;
+    const unsigned histGridB = (unsigned)std::max<long long>(1, std::min<long long>(((long long)k + kMixHistBlock - 1) / kMixHistBlock, (long long)h->numCU * 2));
+    const unsigned histGridA = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + kMixHistBlock - 1) / kMixHistBlock, (long long)h->numCU * 2));
+    int rc = classify(template_int<0>{}, k, h->dBp, h->dBj, (const int*)nullptr, tabB, (int*)h->classB.p, bRange, nHeadsB, GB, clsB, periodB);
+    if (rc == BHS_SUCCESS && mixed) {
+        // a row of B that is the only one of its kind (a perturbed row) loses its class: the rows of A that point at it
+        // would each claim a class of their own in A's table
+        hipLaunchKernelGGL(k_mix_class_hist, dim3(histGridB), dim3(kMixHistBlock), 0, h->stream, k, (const int*)h->classB.p, countB, bRange);
+        hipLaunchKernelGGL(k_mix_prune, dim3(propGrid), dim3(256), 0, h->stream, k, (int*)h->classB.p, (const int*)countB, bRange);
+    }
     if (rc == BHS_SUCCESS)
-        rc = classify(template_int<1>{}, m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, nHeadsA, GA, h->maxRowA, periodA);
+        rc = classify(template_int<1>{}, m, h->dAp, h->dAj, (const int*)h->classB.p, tabA, (int*)h->classC.p, (const int*)nullptr, nHeadsA, GA, clsA, periodA);
     if (rc != BHS_SUCCESS) return rc;
+    if (mixed) hipLaunchKernelGGL(k_mix_class_hist, dim3(histGridA), dim3(kMixHistBlock), 0, h->stream, m, (const int*)h->classC.p, countA, (const int*)nullptr);
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches += h->classHeadsOn == 1 ? 6 : 2;
@@ -405,7 +432,7 @@ int symbolic_class(bhs_handle* h)
     hipLaunchKernelGGL(k_class_patterns, dim3(kClassSlots), dim3(256), 0, h->stream, (const unsigned long long*)tabA,
                        h->dAp, h->dAj, h->dBp, h->dBj, (int4*)h->classInfo.p,
                        (unsigned*)h->classMap.p, (unsigned*)h->classMapA.p, (int*)h->classRel.p, (int*)h->classLane.p,
-                       (unsigned*)h->classRing.p, cstats);
+                       (unsigned*)h->classRing.p, cstats, (const int*)countA);
     if (bigPossible) {
         const size_t smemBig = sizeof(int) * 2 * kClassBigMaxP;
         int unused = 0;
@@ -417,6 +444,19 @@ int symbolic_class(bhs_handle* h)
     BHS_HIP(hipGetLastError());
     BHS_TRY(timed_end(h, ep));
     h->stats[ep->stat].launches += bigPossible ? 2 : 1;
+    if (mixed) {
+        // the irregular rows: listed, their product counts and symbolic bins
+        BHS_TRY(timed_begin(h, "irregular_rows", &ep));
+        const unsigned gc = (unsigned)std::max<long long>(1, std::min<long long>(((long long)m + kMixCollectTile - 1) / kMixCollectTile, (long long)h->numCU * 8));
+        hipLaunchKernelGGL(k_mix_collect, dim3(gc), dim3(256), 0, h->stream, m, (int*)h->classC.p, (const int4*)h->classInfo.p,
+                           (int*)h->mixList.p, small + S_MIX_COUNT);
+        hipLaunchKernelGGL(k_mix_upper_bound, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream, (const int*)h->mixList.p,
+                           (const int*)(small + S_MIX_COUNT), h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,
+                           (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, symSpec);
+        BHS_HIP(hipGetLastError());
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches += 2;
+    }
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
     return BHS_SUCCESS;
 }
@@ -489,16 +529,96 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     // per row) 4.85 -> 2.1 ms on the class kernels, poisson9pt 1024^2 (81) 0.57 -> 0.47 ms, poisson7pt 128^3 (49) 0.73 ->
     // 0.78 ms, poisson5pt 1024^2 (25) 0.23 -> 0.42 ms: from class_min_products = 64 products per row on
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
-                          h->maxRowA <= kClassMaxRowBig && h->maxRowB <= kClassMaxRowBig &&
+                          cls_row_a(h) <= kClassMaxRowBig && cls_row_b(h) <= kClassMaxRowBig &&
                           (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
                                                  // ... and enough of them: every block of the classifier meets every class once
                                                  // (poisson27pt 51^3, 90 M products: 0.44 ms general, 0.41 ms by classes;
                                                  // poisson9pt 512^2, 21 M: 0.20 against 0.25)
                                                  (double)h->m * h->avgRowA * h->avgRowB >= 6e7));
+    // Mixed mode (bhs_class_mix.hip.h): this data set's last multiply met rows without a class -- they go through the general
+    // pipeline's kernels, everything else stays on the class kernels.  mixRows: how many this multiply found.
+    const bool mixedFlow = useClass && h->mixOn && h->classMixed;
+    int mixRows = 0;
+    int mixSymCount[kMaxBins], mixSymStart[kMaxBins + 1];
+    unsigned long long mixProducts = 0;
     if (useClass) {
-        BHS_TRY(symbolic_class(h));
+        const int hubMin = mixedFlow ? hub_min_products(h) : 0;
+        const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, true, 0, hubMin);
+        BHS_TRY(symbolic_class(h, mixedFlow, symSpec));
         sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)
-        sc.numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, true, 0, 0);
+        sc.numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, true, 0, hubMin);
+        if (mixedFlow) {
+            // what the classes look like and how many rows have none: the first of the mixed flow's two read-backs
+            BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
+            BHS_TRY(wait_stream(h));
+            const int* cs = hs + S_CT_SLOTS;
+            mixRows = hs[S_MIX_COUNT];
+            memcpy(&mixProducts, hs + S_TOTAL_CT, 8);
+            auto to_general = [&](const char* why) {
+                h->classState = -1;
+                if (h->verbose > 1) printf("  [row classes, mixed: %s (%d of %d rows without a class, %d classes, %d rows start a stretch): general pipeline]\n", why, mixRows, m, cs[CS_CLASSES], cs[CS_HEADS]);
+                return pipeline_symbolic(h, true);
+            };
+            if (hs[S_ERR]) return BHS_ERR_INTERNAL;
+            if (cs[CS_CLASSES] == 0) return to_general("no class");
+            if (mixRows > 0) {
+                if ((long long)mixRows * 100 > (long long)h->mixMaxPct * m) return to_general("too many rows without a class");
+                if (cs[CS_BIGCOUNT]) return to_general("big classes");        // (k_class_numeric_big takes every row)
+                h->ps.classMaxNnz = cs[CS_MAXNNZ];
+                h->ps.classMaxNA = cs[CS_MAXNA];
+                h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
+                if (h->classNumeric < 2 || !class_ring2_fits(h)) return to_general("classes beyond the ring kernel");
+            }
+            // (an irregular row is a head, and so is the row behind it: they are not what the verdict below is about)
+            if (h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && ((long long)cs[CS_HEADS] - 2LL * mixRows) * 4 > (long long)m)
+                return to_general("rows classify each for itself");
+            if (mixRows == 0) { h->classMixed = 0; h->mixProbed = true; }   // (every row has a class worth its pattern: the clean flow from the next multiply on)
+            if (h->verbose > 1) printf("  [row classes, mixed: %d of %d rows without a class -> the general pipeline's kernels; %d classes]\n", mixRows, m, cs[CS_CLASSES]);
+        }
+        if (mixRows > 0) {
+            // their symbolic pass, bin by bin: exact counts into Cp[row] (the general pipeline's stage 2 on the listed rows)
+            mixSymStart[0] = 0;
+            for (int b = 0; b < kMaxBins; ++b) {
+                mixSymCount[b] = hs[S_SYM_COUNT + b];
+                mixSymStart[b + 1] = mixSymStart[b] + (b == 0 ? 0 : mixSymCount[b]);
+            }
+            h->nnzCt = (long long)mixProducts;                    // (launch_hub sizes its item list by it)
+            h->cmpActive = false;
+            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_SYM_COUNT), small + S_SYM_START);
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            BHS_TRY(timed_begin(h, "fill_queues", &ep));
+            hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)gridF), dim3(256), 0, h->stream, m, (const int*)h->ub.p, h->dAp,
+                               (const int*)h->ub.p, (const int*)(small + S_SYM_START), small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
+                               (unsigned long long*)(small + S_SYM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
+            BHS_HIP(hipGetLastError());
+            BHS_TRY(timed_end(h, ep));
+            h->stats[ep->stat].launches++;
+            const int4* symQueue = (const int4*)h->queue.p;
+            BHS_TRY(fork_bins(h, mixSymCount, kNumSymBins));
+            if (mixSymCount[kHubBin]) {
+                bin_stream(h, kHubBin);
+                BHS_TRY(timed_begin(h, "symbolic_hub_rows", &ep));
+                int rc = launch_hub<false>(h, symQueue + mixSymStart[kHubBin], mixSymCount[kHubBin], (int*)h->Cp.p);
+                if (rc) { h->ls = h->stream; return rc; }
+                BHS_TRY(timed_end(h, ep));
+                h->stats[ep->stat].launches++;
+                h->stats[ep->stat].rows += mixSymCount[kHubBin];
+                h->ps.symStat[kHubBin] = ep->stat;
+            }
+            for (int i = 1; i < kNumSymBins; ++i) {
+                const int b = kNumSymBins - i;
+                if (!mixSymCount[b]) continue;
+                bin_stream(h, b);
+                BHS_TRY(timed_begin(h, kSymNames[b], &ep));
+                int rc = dispatch_bin<false>(h, kSymCfg[b], symQueue + mixSymStart[b], mixSymCount[b], (int*)h->Cp.p);
+                if (rc) { h->ls = h->stream; return rc; }
+                BHS_TRY(timed_end(h, ep));
+                h->stats[ep->stat].launches++;
+                h->stats[ep->stat].rows += mixSymCount[b];
+                h->ps.symStat[b] = ep->stat;
+            }
+            BHS_TRY(join_bins(h));
+        }
     } else {
         BHS_TRY(symbolic_general(h, sc));
     }
@@ -514,10 +634,27 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         // (blockSum holds the tile words, cleared by k_class_reset)
         hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(kClassScanBlock), 0, h->stream, m, (const int*)h->classC.p,
                            (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
-                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS);
+                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS, mixRows > 0);
         BHS_HIP(hipGetLastError());
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches += 1;
+        if (mixRows > 0) {
+            // the irregular rows' numeric bins and queue (rowPtrC is final), on the device while the host waits for nnz(C)
+            const BinSpec& ns = sc.numSpec;
+            BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));     // counts, starts, cursors
+            const long long gridH = std::max<long long>(1, std::min<long long>(((long long)mixRows + 255) / 256, (long long)h->numCU * 4));
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            BHS_TRY(timed_begin(h, "fill_queues", &ep));
+            hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)gridH), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp, ns, small + S_NUM_COUNT,
+                               small + S_MAXCNT, (const int*)h->ub.p, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
+            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_NUM_COUNT), small + S_NUM_START);
+            hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
+                               (const int*)h->ub.p, (const int*)(small + S_NUM_START), small + S_NUM_CURSOR, (int4*)h->queue.p, ns,
+                               (unsigned long long*)(small + S_NUM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
+            BHS_HIP(hipGetLastError());
+            BHS_TRY(timed_end(h, ep));
+            h->stats[ep->stat].launches += 2;
+        }
     } else {
     if (h->scanOnePass) {
         // one pass with look-back over the tiles before (k_scan_onepass); the tile words carry this multiply's epoch
@@ -565,7 +702,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     // The classes' figures of the data set's last multiply stand in for this one's (bhs_class.hip.h, k_class_spec_check): no
     // round trip to the host between the scan and the numeric kernel.  Only for a whole multiply on the ring kernel whose C
     // fits the arrays at hand; pipeline_finish sees the device's verdict.
-    if (useClass && !restart && class_spec_try(h)) {
+    if (useClass && !restart && !mixedFlow && class_spec_try(h)) {
         ClassSpecKey key;
         memcpy(key.cs, h->classSpec.cs, sizeof(key.cs));
         key.nnzC = h->classSpec.nnzC;
@@ -587,8 +724,24 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     BHS_TRY(wait_stream(h));
     if (useClass) {
         const int* cs = hs + S_CT_SLOTS;
-        if (cs[CS_FLAGS] || cs[CS_CLASSES] == 0) {
-            // a row without a class, or a class beyond the tables: this data set is for the general pipeline
+        // (... or a great many classes: single rows that found room in the table, each with a pattern of its own to work out --
+        // the mixed flow counts the rows of every class and leaves the classes of a few rows out; asked once per data set)
+        bool manyClasses = false;
+        if (!mixedFlow && !cs[CS_FLAGS] && cs[CS_CLASSES] > kClassManyClasses && !h->mixProbed && !cs[CS_BIGCOUNT] && h->classNumeric >= 2) {
+            h->ps.classMaxNnz = cs[CS_MAXNNZ];                    // (only where the mixed flow's ring kernel can take the classes)
+            h->ps.classMaxNA = cs[CS_MAXNA];
+            h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
+            manyClasses = class_ring2_fits(h);
+        }
+        if (!mixedFlow && (cs[CS_FLAGS] || manyClasses) && cs[CS_CLASSES] > 0 && h->mixOn) {
+            // a row without a class, or a class beyond the tables: the same multiply once more, with those rows on the general
+            // pipeline's kernels (mixed mode, bhs_class_mix.hip.h) -- and this data set's next multiplies that way from the start
+            h->classMixed = 1;
+            if (h->verbose > 1) printf("  [row classes: flags %d, %d classes: the multiply again in mixed mode]\n", cs[CS_FLAGS], cs[CS_CLASSES]);
+            return pipeline_symbolic(h, true);
+        }
+        if (!mixedFlow && (cs[CS_FLAGS] || cs[CS_CLASSES] == 0)) {
+            // ... with mixed mode off, or no class at all: this data set is for the general pipeline
             h->classState = -1;
             if (h->verbose > 1) printf("  [row classes: flags %d, %d classes: general pipeline]\n", cs[CS_FLAGS], cs[CS_CLASSES]);
             return pipeline_symbolic(h, true);
@@ -598,15 +751,20 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         // them change class every row: 3.4 ms against 1.9 ms on the general pipeline for 2^20 rows in blocks of 4..32.
         // More than a quarter of the rows through the table: this data set goes to the general pipeline (class_path = 2
         // insists on the classes).
-        if (h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && (long long)cs[CS_HEADS] * 4 > (long long)m) {
+        if (!mixedFlow && h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && (long long)cs[CS_HEADS] * 4 > (long long)m) {
             h->classState = -1;
             if (h->verbose > 1) printf("  [row classes: %d of %d rows start a stretch: general pipeline]\n", cs[CS_HEADS], m);
             return pipeline_symbolic(h, true);
         }
         unsigned long long t = 0, v;
         for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, cs + CS_SUMS + 2 * i, 8); t += v; }
-        h->nnzCt = (long long)t;
+        h->nnzCt = (long long)t + (long long)mixProducts;         // (the rows with a class, the rows without)
         h->ps.useClass = true;
+        h->ps.mixed = mixRows > 0;
+        h->ps.mixRows = mixRows;
+        h->ps.mixNumFilled = mixRows > 0;
+        h->ps.mixProducts = (long long)mixProducts;
+        for (int b = 0; b < kMaxBins; ++b) { h->ps.mixSymCount[b] = mixRows > 0 ? mixSymCount[b] : 0; h->ps.mixNumCount[b] = mixRows > 0 ? hs[S_NUM_COUNT + b] : 0; }
         h->ps.classMaxP = cs[CS_MAXP];
         h->ps.classMaxNnz = cs[CS_MAXNNZ];
         h->ps.classMaxNA = cs[CS_MAXNA];
@@ -656,7 +814,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         BHS_TRY(ensure(h, h->Cj, sizeof(int) * (size_t)std::max<long long>(nnzC, 1)));
         BHS_TRY(ensure(h, h->Cx, sizeof(value_t) * (size_t)std::max<long long>(nnzC, 1)));
     }
-    if (useClass) { h->classSpec.nnzC = nnzC; h->classSpec.nnzCt = h->nnzCt; h->classSpec.valid = true; }
+    if (useClass) { h->classSpec.nnzC = nnzC; h->classSpec.nnzCt = h->nnzCt; h->classSpec.valid = !mixedFlow; }
     BHS_HIP(hipEventRecord(h->ev[3], h->stream));
     return stage_rowptr_and_open(h);
 }
@@ -698,6 +856,76 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     const int laneK = h->ps.laneK;
     int (&numStat)[kMaxBins] = h->ps.numStat;
     h->ls = h->stream;
+    if (h->ps.useClass && h->ps.mixed) {
+        // Mixed mode (bhs_class_mix.hip.h): the ring kernel on the rows with a class -- it skips the others -- and, beside it on
+        // the side streams, the general pipeline's numeric kernels on the queue of the rows without
+        h->ps.rangesRun++;
+        int numCount[kMaxBins], numStart[kMaxBins + 1];
+        if (full && h->ps.mixNumFilled) {
+            for (int b = 0; b < kMaxBins; ++b) numCount[b] = h->ps.mixNumCount[b];
+        } else {
+            // the listed rows inside [r0, r1): their bins and queue anew (one small round trip per range, as in the general pipeline)
+            int* hr = hs + S_SMALL_INTS + 2 * kMaxBins;
+            BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));
+            BHS_HIP(hipMemsetAsync(small + S_NUM_SUMS, 0, sizeof(unsigned long long) * 3 * kMaxBins, h->stream));
+            const long long gridH = std::max<long long>(1, std::min<long long>(((long long)h->ps.mixRows + 255) / 256, (long long)h->numCU * 4));
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)h->ps.mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)gridH), dim3(256), 0, h->stream, h->m, (const int*)h->Cp.p, h->dAp, numSpec, small + S_NUM_COUNT,
+                               small + S_MAXCNT, (const int*)h->ub.p, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), r0, r1);
+            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_NUM_COUNT), small + S_NUM_START);
+            hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, h->m, (const int*)h->Cp.p, h->dAp,
+                               (const int*)h->ub.p, (const int*)(small + S_NUM_START), small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
+                               (unsigned long long*)(small + S_NUM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), r0, r1);
+            BHS_HIP(hipGetLastError());
+            BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
+            BHS_TRY(wait_stream(h));
+            for (int b = 0; b < kMaxBins; ++b) numCount[b] = hr[b];
+            h->ps.mixNumFilled = false;                               // (the queue now holds this range's rows)
+        }
+        numStart[0] = 0;
+        for (int b = 0; b < kMaxBins; ++b) numStart[b + 1] = numStart[b] + (b == 0 ? 0 : numCount[b]);
+        const int4* numQueue = (const int4*)h->queue.p;
+        h->ps.midRows = h->ps.longRows = 0;
+        for (int b = 2; b < kNumNumBins; ++b)
+            if (bin_takes_lds_bitmap<true>(h, kNumCfg[b])) (kNumCfg[b].win ? h->ps.longRows : h->ps.midRows) += numCount[b];
+        for (int b = 2; b < kNumNumBins; ++b)
+            if (numCount[b] && bin_takes_wave_window<true>(h, kNumCfg[b])) BHS_TRY(ensure_b_windows(h));
+        int anyBin = 0;
+        for (int b = 1; b < kMaxBins; ++b) anyBin += numCount[b] > 0;
+        // The bins first, side by side on the side streams, THEN the ring kernel: its 16 waves per CU take all of a CU's LDS and
+        // all of its vector registers, and whatever is launched beside it waits for its waves to finish (measured on
+        // poisson27pt 128^3 with 55 k irregular rows: their bins, 0.2 ms of work, ended 0.8 ms after the ring kernel beside
+        // which they were launched; launched just in front of it, the last of them still did).
+        BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0));
+        if (numCount[kHubBin]) {
+            bin_stream(h, kHubBin);
+            BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));
+            BHS_TRY(launch_hub<true>(h, numQueue + numStart[kHubBin], numCount[kHubBin], (int*)h->Cp.p));
+            BHS_TRY(timed_end(h, ep));
+            h->stats[ep->stat].launches++;
+            h->stats[ep->stat].rows += numCount[kHubBin];
+            numStat[kHubBin] = ep->stat;
+        }
+        for (int i = 1; i < kNumNumBins; ++i) {
+            const int b = kNumNumBins - i;
+            if (!numCount[b]) continue;
+            bin_stream(h, b);
+            BHS_TRY(timed_begin(h, kNumNames[b], &ep));
+            BHS_TRY(dispatch_bin<true>(h, kNumCfg[b], numQueue + numStart[b], numCount[b], (int*)h->Cp.p, 0));
+            BHS_TRY(timed_end(h, ep));
+            h->stats[ep->stat].launches++;
+            h->stats[ep->stat].rows += numCount[b];
+            numStat[b] = ep->stat;
+        }
+        BHS_TRY(join_bins(h));
+        BHS_TRY(timed_begin(h, "numeric_class", &ep));
+        BHS_TRY(launch_class_ring(h, r0, r1));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += r1 - r0;
+        if (full) { h->stats[ep->stat].products += h->nnzCt - h->ps.mixProducts; h->stats[ep->stat].nnzA_rows += h->nnzA; }
+        return BHS_SUCCESS;
+    }
     if (h->ps.useClass) {
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
@@ -837,6 +1065,8 @@ int pipeline_finish(bhs_handle* h)
         if (hs[S_SPEC] != 1) return kSpecRefuted;       // (the numeric kernel has written nothing: run_pipeline_impl starts over)
         unsigned long long t = 0, v;
         for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, hs + S_CT_SLOTS + CS_SUMS + 2 * i, 8); t += v; }
+        // (numeric_stage booked the numeric kernel's products on the figure of the multiply before: put this multiply's there)
+        h->stats[stat_index(h, "numeric_class")].products += (long long)t - h->nnzCt;
         h->nnzCt = h->classSpec.nnzCt = (long long)t;
     }
     if (hs[S_ERR]) return BHS_ERR_INTERNAL;
@@ -881,7 +1111,7 @@ int run_pipeline_impl(bhs_handle* h)
     h->classSpec.valid = false;
     h->specRefuted++;
     if (h->verbose > 1) printf("  [speculative numeric launch refuted on the device: the multiply again]\n");
-    BHS_TRY(pipeline_symbolic(h));
+    BHS_TRY(pipeline_symbolic(h, true));            // (restart: the refuted attempt's timers and kernel records stay in -- it ran inside this multiply)
     BHS_TRY(numeric_stage(h, 0, h->m));
     return pipeline_finish(h);
 }

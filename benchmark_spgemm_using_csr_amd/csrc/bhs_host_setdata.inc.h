@@ -47,13 +47,13 @@ int finish_set_data(bhs_handle* h)
     h->periodA = h->periodB = 1;
     if (h->m > 0) {
         const long long gmr = std::min<long long>(((long long)h->m + 255) / 256, (long long)h->numCU * 2);
-        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_SCAN);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmr), dim3(256), 0, h->stream, h->m, h->dAp, small0 + S_SCAN, small0 + S_ROWLEN);
         hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SCAN + 1, small0 + S_SCAN + 4, h->k, small0 + S_SCAN + 5);
         BHS_HIP(hipGetLastError());
     }
     if (h->k > 0) {
         const long long gmb = std::min<long long>(((long long)h->k + 255) / 256, (long long)h->numCU * 2);
-        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_SCAN + 2);
+        hipLaunchKernelGGL(k_max_row, dim3((unsigned)gmb), dim3(256), 0, h->stream, h->k, h->dBp, small0 + S_SCAN + 2, small0 + S_ROWLEN + 4);
         hipLaunchKernelGGL(k_row_period, dim3(1), dim3(64), 0, h->stream, h->k, h->dBp, h->dBj, small0 + S_SCAN + 3, (int*)nullptr, 0);
         BHS_HIP(hipGetLastError());
     }
@@ -125,6 +125,7 @@ int finish_set_data(bhs_handle* h)
         BHS_HIP(hipMemcpyAsync(hscan + 7, small0 + S_CT_SLOTS, sizeof(int) * 64, hipMemcpyDeviceToHost, h->stream));
     }
     if (spanScan) BHS_HIP(hipMemcpyAsync(hscan + 72, small0 + S_SPAN, sizeof(int) * 3, hipMemcpyDeviceToHost, h->stream));
+    BHS_HIP(hipMemcpyAsync(hscan + 76, small0 + S_ROWLEN, sizeof(int) * 8, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipStreamSynchronize(h->stream));
     h->spanState = 0;
     h->reachL = h->reachR = h->widthA = 0x3fffffff;              // (no scan: never fits)
@@ -133,6 +134,10 @@ int finish_set_data(bhs_handle* h)
     h->maxRowA = maxRowA;
     h->maxRowB = hscan[2];
     if (h->m > 0) h->periodA = hscan[1];
+    memcpy(h->lenStatsA, hscan + 76, sizeof(h->lenStatsA));
+    memcpy(h->lenStatsB, hscan + 80, sizeof(h->lenStatsB));
+    h->classMixed = 0;
+    h->mixProbed = false;
     h->localA = h->m > 0 ? hscan[4] : 1;
     // a wave of the ring kernel takes whole grid lines when A has them (rows whose lengths repeat with that period,
     // the matrix a whole number of them) -- a stretch of rows ends where a line ends anyway
@@ -188,8 +193,8 @@ int finish_set_data(bhs_handle* h)
     // A data set that will try the row classes first (pipeline_symbolic's test) and has rows below the old gate leaves the
     // count to its first multiply on the general pipeline, if it ever gets there (cmpState 0: that multiply measures the
     // ratio, the ones after it use the verdict) -- poisson27pt's hand-over does not pay a pass over B for nothing.
-    const bool classFirst = h->classPath && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->maxRowA <= kClassMaxRowBig &&
-                            h->maxRowB <= kClassMaxRowBig &&
+    const bool classFirst = h->classPath && h->forcePath == 0 && h->maxTableLog2 >= 15 && cls_row_a(h) <= kClassMaxRowBig &&
+                            cls_row_b(h) <= kClassMaxRowBig &&
                             (h->classPath == 2 || (avgA * avgB >= (double)h->classMinProducts && (double)h->m * avgA * avgB >= 6e7));
     if (h->compressB == 1 && (avgA * avgB < 256.0 || !h->bSorted)) h->cmpState = -1;
     else if (h->compressB == 1 && classFirst && avgA * avgB <= 1536.0) h->cmpState = 0;

@@ -338,13 +338,18 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
                                                      const int* __restrict__ Ap, const int* __restrict__ ub,
                                                      const int* __restrict__ binStart,
                                                      int* __restrict__ binCursor, int4* __restrict__ queue,
-                                                     BinSpec spec, unsigned long long* __restrict__ binSums)
+                                                     BinSpec spec, unsigned long long* __restrict__ binSums,
+                                                     // round 6 (bhs_class_mix.hip.h): the rows list[0 .. *listCount) that lie in
+                                                     // [rlo, rhi) instead of the rows 0 .. m - 1 (nullptr: all rows)
+                                                     const int* __restrict__ list = nullptr, const int* __restrict__ listCount = nullptr,
+                                                     int rlo = 0, int rhi = 0x7fffffff)
 {
     __shared__ int hist[kMaxBins];
     __shared__ int base[kMaxBins];
     __shared__ unsigned long long sums[kMaxBins * 3];   // per bin: products, nnz(C rows), nnz(A rows)
     const int tid = threadIdx.x;
     if (tid < kMaxBins * 3) sums[tid] = 0;
+    if (list != nullptr) m = *listCount;
     for (long long r0 = (long long)blockIdx.x * kFillTile; r0 < m; r0 += (long long)gridDim.x * kFillTile) {
         if (tid < kMaxBins) hist[tid] = 0;
         __syncthreads();
@@ -352,9 +357,14 @@ __global__ __launch_bounds__(256) void k_fill_queues(int m, const int* __restric
         int4 dd[kFillRounds];
 #pragma unroll
         for (int r = 0; r < kFillRounds; ++r) {
-            const long long row = r0 + (long long)r * 256 + tid;
+            const long long idx = r0 + (long long)r * 256 + tid;
+            long long row = idx;
+            if (list != nullptr) {
+                row = idx < m ? list[idx] : 0x7fffffff;
+                if (row < rlo || row >= rhi) row = 0x7fffffff;       // (outside the range: as if beyond the last row)
+            }
             int b = 0, pos = 0, a0 = 0, a1 = 0, outBase = 0, v = 0, ubv = 0;
-            if (row < m) {
+            if (row < (list != nullptr ? 0x7fffffffLL : (long long)m)) {
                 if (FROM_ROWPTR) { outBase = key[row]; v = key[row + 1] - outBase; } else v = key[row];
                 a0 = Ap[row];
                 a1 = Ap[row + 1];
@@ -603,7 +613,10 @@ __global__ __launch_bounds__(kScan1Block) void k_scan_onepass(int m, int* __rest
 
 __global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__ Cp, const int* __restrict__ Ap,
                                                   BinSpec spec, int* __restrict__ binCount, int* __restrict__ maxCnt,
-                                                  const int* __restrict__ ub)
+                                                  const int* __restrict__ ub,
+                                                  // round 6 (bhs_class_mix.hip.h): the listed rows inside [rlo, rhi) only
+                                                  const int* __restrict__ list = nullptr, const int* __restrict__ listCount = nullptr,
+                                                  int rlo = 0, int rhi = 0x7fffffff)
 {
     __shared__ int hist[kMaxBins];
     __shared__ int wmax[4];
@@ -611,7 +624,13 @@ __global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__
     if (tid < kMaxBins) hist[tid] = 0;
     __syncthreads();
     int mx = 0;
-    for (long long i = (long long)blockIdx.x * 256 + tid; i < m; i += (long long)gridDim.x * 256) {
+    if (list != nullptr) m = *listCount;
+    for (long long idx = (long long)blockIdx.x * 256 + tid; idx < m; idx += (long long)gridDim.x * 256) {
+        long long i = idx;
+        if (list != nullptr) {
+            i = list[idx];
+            if (i < rlo || i >= rhi) continue;
+        }
         const int v = Cp[i + 1] - Cp[i];
         mx = max(mx, v);
         const int b = bin_of(spec, v, Ap[i + 1] - Ap[i], v, spec.hubMin > 0 ? ub[i] : 0);
@@ -631,19 +650,38 @@ __global__ __launch_bounds__(256) void k_bin_hist(int m, const int* __restrict__
 // longest row of a CSR matrix (chooses the lanes-per-row of k_upper_bound for skewed inputs).  One same-address
 // atomic per BLOCK: with one per wave (8192 of them on a 2 M-row matrix) the kernel took 98 us for 8 MB, all of
 // it atomics queueing on one L2 word.
-__global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ Ap, int* __restrict__ out)
+// lenStats (round 6, the classifier's sizes where a FEW rows are long -- bhs_class_mix.hip.h): [0] rows beyond 64 entries, [1] the
+// longest row within 64, [2] rows beyond 256, [3] the longest within 256
+__global__ __launch_bounds__(256) void k_max_row(int m, const int* __restrict__ Ap, int* __restrict__ out, int* __restrict__ lenStats = nullptr)
 {
-    __shared__ int wmax[4];
-    int mx = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256)
-        mx = max(mx, Ap[i + 1] - Ap[i]);
+    __shared__ int wmax[4], w64[4], w256[4], n64[4], n256[4];
+    int mx = 0, mx64 = 0, mx256 = 0, c64 = 0, c256 = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256) {
+        const int len = Ap[i + 1] - Ap[i];
+        mx = max(mx, len);
+        if (len <= 64) mx64 = max(mx64, len); else ++c64;
+        if (len <= 256) mx256 = max(mx256, len); else ++c256;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, __shfl_xor(mx, o, 64));
+        mx64 = max(mx64, __shfl_xor(mx64, o, 64));
+        mx256 = max(mx256, __shfl_xor(mx256, o, 64));
+        c64 += __shfl_xor(c64, o, 64);
+        c256 += __shfl_xor(c256, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; wmax[w] = mx; w64[w] = mx64; w256[w] = mx256; n64[w] = c64; n256[w] = c256; }
     __syncthreads();
     if (threadIdx.x == 0) {
         mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         if (mx) atomicMax(out, mx);
+        if (lenStats != nullptr) {
+            const int a = n64[0] + n64[1] + n64[2] + n64[3], b = n256[0] + n256[1] + n256[2] + n256[3];
+            if (a) atomicAdd(&lenStats[0], a);
+            atomicMax(&lenStats[1], max(max(w64[0], w64[1]), max(w64[2], w64[3])));
+            if (b) atomicAdd(&lenStats[2], b);
+            atomicMax(&lenStats[3], max(max(w256[0], w256[1]), max(w256[2], w256[3])));
+        }
     }
 }
 

@@ -26,6 +26,7 @@
 #include "bhs_sort.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
+#include "bhs_class_mix.hip.h"
 #include "bhs_class_wg.hip.h"
 #include "bhs_class_ring.hip.h"
 #include "bhs_class_fused.hip.h"
@@ -181,6 +182,15 @@ struct bhs_handle {
     int classNumeric = 2;                // numeric kernel of the class path: 2 round 5's ring kernel (bhs_class_ring.hip.h) where its LDS fits, 1 round 4's (bhs_class_wg.hip.h), 0 k_class_numeric_atomic (round 2) always
     int classPath = 1;                   // 0 never; 1 for data sets whose rows of A and B have <= 64 entries and >= classMinProducts products on average (2: any), until one multiply finds
     int classState = 0;                  //   rows it cannot classify (classState -1: the data set stays on the general pipeline)
+    // Round 6, mixed mode (bhs_class_mix.hip.h): rows without a class go through the general pipeline's kernels, the others
+    // stay on the class kernels.  classMixed: this data set's last multiply had such rows -- the next one runs the mixed
+    // flow from the start (everything it decides it works out anew on the device); option "class_mixed" 0: one row without
+    // a class sends the data set to the general pipeline, as until round 5.
+    int mixOn = 1, classMixed = 0;
+    bool mixProbed = false;              // the mixed flow found every class of this data set worth its pattern: many classes alone no longer ask for it
+    int mixMaxPct = 30;                  // option "class_mixed_max_pct": more irregular rows than this share of all rows -> the general pipeline
+    int lenStatsA[4] = {0, 0, 0, 0}, lenStatsB[4] = {0, 0, 0, 0};   // bhs_set_data's scan (k_max_row): rows beyond 64 entries, the longest within 64, rows beyond 256, the longest within 256
+    DevBuf mixList, classCount;          // the irregular rows of A; rows per class (B's table, then A's)
     DevBuf classB, classC, classTab, classInfo, classMap, classMapA, classRing, classRel, classLane, classHeads, classHeadCnt, classBigIdx, classBigMap;
     DevBuf longList, longPart;           // rows k_upper_bound / k_check_sorted leave to their *_long kernels; partial sums
     int mergeBitmapBins = 1;
@@ -268,6 +278,11 @@ struct bhs_handle {
         int spanWPL = 0;                 // this multiply's wave bins run k_row_span with this many bitmap words per lane (0: hash kernels)
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
         bool specLaunched = false;       // the numeric kernel goes out on the last multiply's figures (classSpec), k_class_spec_check decides
+        bool mixed = false;              // class path with irregular rows on the general kernels (bhs_class_mix.hip.h)
+        int mixRows = 0;                 // ... how many
+        bool mixNumFilled = false;       // ... their numeric queue (all rows) was filled behind the scan
+        int mixSymCount[kMaxBins], mixNumCount[kMaxBins];
+        long long mixProducts = 0;       // ... their products
         long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
     } ps;
     // external output arrays for the numeric half (bhs_set_output_device): C lands in the caller's buffers
@@ -288,15 +303,18 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_NUM_SUMS = 104 + 96,
        S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
        S_SCAN_TICKET = 104 + 194 /* tile numbers of k_scan_onepass */,
-       S_ZERO_END = 104 + 195,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 300, S_MAXROW = 301, S_SPEC = 302 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
-       S_LONG_B = 303 /* rows on k_check_sorted's long list */,
-       S_TICKETS = 304 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
-       S_CT_SLOTS = 320 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SCAN = 448 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
+       S_MIX_COUNT = 104 + 195 /* rows on the mixed mode's list of irregular rows (bhs_class_mix.hip.h) */,
+       S_ZERO_END = 104 + 196,   /* everything below is zeroed at the start of every spgemm */
+       S_SORTED = 302, S_MAXROW = 303, S_SPEC = 304 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
+       S_LONG_B = 305 /* rows on k_check_sorted's long list */,
+       S_TICKETS = 306 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
+       S_CT_SLOTS = 322 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
+       S_SCAN = 450 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
                        the length of A's grid lines */,
-       S_SPAN = 454 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
-       S_SMALL_INTS = 460 };
+       S_SPAN = 456 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
+       S_ROWLEN = 460 /* bhs_set_data's scans for the classifier's sizes (k_max_row): per matrix rows beyond 64 entries, the
+                         longest row within 64, rows beyond 256, the longest within 256 -- A's four, then B's */,
+       S_SMALL_INTS = 468 };
 
 template <int V> struct template_int { static constexpr int value = V; };
 

@@ -1478,6 +1478,147 @@ def test_row_class_path_big_classes_randomized(oracle, seed):
         seed, d, na * d, nb * d, "numeric_class" if "numeric_class" in _kernel_names(info) else "general pipeline"))
 
 
+def _mixed_run(oracle, m, k, n, A, B, options=None, multiplies=2, expect_rows=None, value_dtype=np.float64):
+    """One data set on the class path with irregular rows (mixed mode, bhs_class_mix.hip.h): every multiply gives the
+    oracle's C bit for bit, numeric_class runs, and the irregular rows are few.  Returns the last multiply's kernel names
+    and its number of irregular rows."""
+    ref = oracle.spgemm(m, k, n, *A, *B)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse(value_dtype=value_dtype)
+    assert bh.initPlatform(plats) == 0
+    for key, val in dict({"class_path": 2}, **(options or {})).items():
+        assert bh.set_option(key, val) == 0
+    Cp = np.zeros(m + 1, np.int32)
+    A = (A[0], A[1], np.ascontiguousarray(A[2], value_dtype)); B = (B[0], B[1], np.ascontiguousarray(B[2], value_dtype))
+    assert bh.initData(m, k, n, len(A[1]), A[2], A[0], A[1], len(B[1]), B[2], B[0], B[1], Cp) == 0
+    names, rows = set(), 0
+    for it in range(multiplies):
+        assert bh.spgemm() == 0
+        names = {s_["name"] for s_ in bh.kernel_stats() if s_["launches"]}
+        rows = bh.get_info("mixed_rows")
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), value_dtype)
+        assert bh.get_C(Cj, Cx) == 0
+        assert bh.nnzCt == oracle.nnzCt(A[0], A[1], B[0])
+        res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0 if value_dtype == np.float64 else REL_TOL)
+        assert res["ok"], (it, res)
+        check_csr_invariants(m, n, Cp, Cj)
+        assert "numeric_class" in names, (it, names)
+    if expect_rows is not None:
+        assert expect_rows[0] <= rows <= expect_rows[1], rows
+        # (a handful of odd rows may each find room in the class table: then there is nothing irregular about them)
+        assert bh.get_info("class_state") == (2 if rows > 0 else 1)
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+    return names, rows
+
+
+@pytest.mark.parametrize("case", ["p27_extra_entries", "p27_one_long_row", "p27_hub_row", "p9_extra_entries", "tridiagonal_long_row",
+                                  "rect_toeplitz_extra", "p27_empty_rows", "p27_f32", "p27_long_row_first_and_last",
+                                  "p27_one_percent"])
+def test_row_class_path_mixed_mode(oracle, case):
+    """Round 6: a structured matrix with a few irregular rows stays on the class kernels; the irregular rows -- and the rows
+    of A that point at an irregular row of B -- go through the general pipeline's kernels inside the same multiply, one
+    scan gives rowPtrC (SpGEMM_cuda/bhsparse.h:483-586: the reference bins every row for itself)."""
+    from benchmark_spgemm_using_csr_amd import gallery
+    rng = np.random.default_rng(61)
+    vd = np.float32 if case == "p27_f32" else np.float64
+    if case.startswith("p27"):
+        nx, ny, nz = 24, 22, 20
+        rp, col = gallery.poisson_csr("poisson27pt", nx, ny, nz)
+        m = k = n = len(rp) - 1
+        if case in ("p27_extra_entries", "p27_f32"):
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.002, seed=5)
+            expect = (20, 1200)
+        elif case == "p27_one_percent":
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.01, seed=6)
+            expect = (100, int(0.3 * m))
+        elif case == "p27_one_long_row":
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(m // 2 + 7, 300))
+            expect = (1, 700)
+        elif case == "p27_hub_row":
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(m // 3, 6000))      # 6000 x 27 products: hub / long-row bins
+            expect = (1, 8000)
+        elif case == "p27_long_row_first_and_last":
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(0, 200))
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(m - 1, 150))
+            expect = (2, 900)
+        else:                                                    # rows without entries: no class, no products
+            keep = np.ones(len(col), bool)
+            for r in (0, 100, 101, 5000, m - 1):
+                keep[rp[r]:rp[r + 1]] = False
+            lens = np.diff(rp).copy(); lens[[0, 100, 101, 5000, m - 1]] = 0
+            rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum(lens)
+            col = col[keep]
+            expect = (0, 400)                                    # (an empty row is a class like any other; the rows that point at one find room in the table)
+        A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+    elif case == "p9_extra_entries":
+        rp, col = gallery.poisson_csr("poisson9pt", 120, 90, 1)
+        m = k = n = len(rp) - 1
+        rp, col = gallery.perturb_rows_csr(rp, col, n, 0.003, seed=9)
+        A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+        expect = (10, 600)
+    elif case == "tridiagonal_long_row":
+        m = k = n = 20000
+        rp, col, val = _toeplitz(m, k, (-1, 0, 1), rng)
+        rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(700, 300))
+        A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+        expect = (1, 400)
+    else:
+        m, k, n = 9000, 9500, 10000
+        A = _toeplitz(m, k, (-3, -1, 0, 2, 40), rng)
+        B = _toeplitz(k, n, (-2, 0, 1, 7), rng)
+        rpa, cola = gallery.perturb_rows_csr(A[0], A[1], k, 0.002, seed=3)
+        rpb, colb = gallery.perturb_rows_csr(B[0], B[1], n, 0.002, seed=4)
+        A = (rpa, cola, rng.integers(1, 10, len(cola)).astype(np.float64))
+        B = (rpb, colb, rng.integers(1, 10, len(colb)).astype(np.float64))
+        expect = (0, 400)
+    _mixed_run(oracle, m, k, n, A, B, expect_rows=expect, value_dtype=vd)
+
+
+def test_mixed_mode_in_row_ranges_and_back_to_clean(oracle):
+    """The multiply in two halves with the numeric half in row ranges (what the multi-GPU layer runs) on a data set with
+    irregular rows; then the arrays change under the handle (borrowed pointers): a clean data set runs the clean flow again,
+    and mixed mode switched off sends the perturbed one to the general pipeline as until round 5."""
+    from benchmark_spgemm_using_csr_amd import gallery
+    rng = np.random.default_rng(62)
+    rp0, col0 = gallery.poisson_csr("poisson27pt", 20, 18, 16)
+    m = k = n = len(rp0) - 1
+    rp, col = gallery.perturb_rows_csr(rp0, col0, n, 0.003, seed=8, long_row=(m // 2, 400))
+    val = rng.integers(1, 10, len(col)).astype(np.float64)
+    ref = oracle.spgemm(m, k, n, rp, col, val, rp, col, val)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0 and bh.set_option("class_path", 2) == 0
+    Cp = np.zeros(m + 1, np.int32)
+    assert bh.initData(m, k, n, len(col), val, rp, col, len(col), val, rp, col, Cp) == 0
+    assert bh.spgemm() == 0                                      # (finds the irregular rows; the data set is "mixed" from here on)
+    for nranges in (1, 3, 5):
+        assert bh.spgemm_symbolic() == 0
+        nnzCt, nnzC = bh.nnzCt, bh.nnzC
+        assert nnzCt == oracle.nnzCt(rp, col, rp) and nnzC == ref[0][-1]
+        cuts = np.linspace(0, m, nranges + 1).astype(int)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            assert bh.spgemm_numeric(int(a), int(b)) == 0
+        assert bh.spgemm_finish() == 0
+        assert bh.get_info("mixed_rows") > 0
+        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"], nranges
+    assert bh.free_mem() == 0
+    # mixed mode off: the general pipeline, for good
+    assert bh.set_option("class_mixed", 0) == 0
+    assert bh.initData(m, k, n, len(col), val, rp, col, len(col), val, rp, col, Cp) == 0
+    for it in range(2):
+        assert bh.spgemm() == 0
+        names = {s_["name"] for s_ in bh.kernel_stats() if s_["launches"]}
+        assert "numeric_class" not in names                      # (a 400-entry row: with mixed mode off the hand-over hint keeps the class path away)
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
 @pytest.mark.parametrize("case", ["random_short_rows", "too_many_products", "one_long_row", "too_many_entries"])
 def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     """Inputs the class tables cannot take: more classes than table slots (unstructured rows), a class with more than
@@ -1504,10 +1645,14 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
         m = k = n = 2000
         rp, col, val = _toeplitz(m, k, (-1, 0, 1), rng)
         rows = [col[rp[i]:rp[i + 1]] for i in range(m)]
-        rows[700] = np.arange(600, 900)        # 300 entries: the hint from bhs_set_data keeps the class path away
+        rows[700] = np.arange(600, 900)        # 300 entries: until round 5 the hint from bhs_set_data kept the class path away
         rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum([len(r) for r in rows])
         col = np.concatenate(rows).astype(np.int32)
         A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+        # round 6: ONE odd row no longer moves the other rows off the class kernels (mixed mode: numeric_class DID run); with
+        # mixed mode off it still does, and that is what the loop below checks
+        names, rows_irregular = _mixed_run(oracle, m, k, n, A, B, expect_rows=(1, 400))
+        assert "classify_rows" in names and "numeric_class" in names
         tried = False
     ref = oracle.spgemm(m, k, n, *A, *B)
     plats = [False] * bhmod.NUM_PLATFORMS
@@ -1516,6 +1661,8 @@ def test_row_class_path_gives_way_to_the_general_pipeline(oracle, case):
     assert bh.initPlatform(plats) == 0
     Cp = np.zeros(m + 1, np.int32)
     assert bh.set_option("class_path", 2) == 0
+    if case == "one_long_row":
+        assert bh.set_option("class_mixed", 0) == 0
     assert bh.initData(m, k, n, len(A[1]), A[2], A[0], A[1], len(B[1]), B[2], B[0], B[1], Cp) == 0
     for it in range(2):
         assert bh.spgemm() == 0
