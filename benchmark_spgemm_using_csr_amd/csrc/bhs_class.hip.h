@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
     // by those round trips (SQ_WAIT_ANY 60-80 % of the wave cycles), so short rows -- few entries per lane -- take
     // more row sets: R * E = 16 entries per lane in flight.
     constexpr int R = E >= 8 ? 2 : (E >= 4 ? 4 : 8);
+    bool noClass = false;                                          // a row of this wave's found no class
     long long first = 0;
     if (rowList != nullptr) {                                      // (positions in the segment's list from here on)
         rowList += (size_t)blockIdx.y * segCap;
@@ -296,9 +297,10 @@ __global__ __launch_bounds__(kClassRowsBlock) void k_class_rows(int nrows, const
                 s = (s + 1) & (kClassSlots - 1);
             }
             if (live[r] && g == 0) classOut[row] = cls;
-            if (__any(live[r] && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
+            noClass = noClass || __any(live[r] && cls < 0);          // (told once, when the wave ends: bhs_class_tile.hip.h)
         }
     }
+    if (noClass && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1071,10 +1073,13 @@ constexpr int kClassScanBlock = 1024, kClassScanPer = 8, kClassScanTile = kClass
 __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int* __restrict__ classC, const int4* __restrict__ classInfo,
                                                     int* __restrict__ Cp, unsigned long long* __restrict__ state,
                                                     long long* __restrict__ totalOut, int* __restrict__ stats,
-                                                    bool mixed)       // round 6 (bhs_class_mix.hip.h): a row without a class has its count in Cp already (the general pipeline's symbolic kernels)
+                                                    bool mixed,       // round 6 (bhs_class_mix.hip.h): a row without a class has its count in Cp already (the general pipeline's symbolic kernels)
+                                                    const int* __restrict__ Ap, const int* __restrict__ ub, BinSpec numSpec,
+                                                    int* __restrict__ binCount)   // ... and is counted into its numeric bin here
 {
     constexpr int NW = kClassScanBlock / 64;
-    __shared__ int sTile, wsum[NW];
+    __shared__ int sTile, wsum[NW], hist[kMaxBins];
+    if (mixed && threadIdx.x < kMaxBins) hist[threadIdx.x] = 0;       // (before the ticket's barrier)
     __shared__ long long sPrefix;
     __shared__ unsigned long long wprod[NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1096,6 +1101,8 @@ __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int
             pending = pending || ci.z == -2;
         } else if (mixed && c == kClassDummy) {
             v[j] = Cp[base + j];                                  // (read and overwritten by this thread alone)
+            const int b = bin_of(numSpec, v[j], Ap[base + j + 1] - Ap[base + j], v[j], numSpec.hubMin > 0 ? ub[base + j] : 0);
+            if (b > 0) atomicAdd(&hist[b], 1);
         }
         mine += v[j];
     }
@@ -1147,6 +1154,7 @@ __global__ __launch_bounds__(kClassScanBlock) void k_class_scan(int m, const int
         for (int w = 0; w < NW; ++w) all += wprod[w];
         atomicAdd(reinterpret_cast<unsigned long long*>(stats + CS_SUMS) + (tile % kClassSumSlots), all);
     }
+    if (mixed && tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);     // (behind the barriers above)
 }
 
 // ---------------------------------------------------------------------------

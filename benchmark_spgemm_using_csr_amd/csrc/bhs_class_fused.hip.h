@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, con
     const long long wave = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
     const long long pieceBegin = first + wave * PIECE;
     const long long pieceEnd = min((long long)nrows, pieceBegin + PIECE);
+    bool noClass = false;                                          // a row of this wave's found no class
     bool okP = false;                                              // the pass before's last row (lane g of every group)
     int lenP = 0, elP[E], cbP[E], followP = 0;                       // followP: (position of the last head << 13) | (its class + 1)
 #pragma unroll
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, con
                 }
                 s = (s + 1) & (kClassSlots - 1);
             }
-            if (__any(head[r] && cls[r] < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
+            noClass = noClass || __any(head[r] && cls[r] < 0);       // (told once, when the wave ends: bhs_class_tile.hip.h)
         }
         // the head every row follows: the last head at or before it in the wave's walk, as (position << 13) | (class + 1)
         int lastIn = 0;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, con
         followP = max(followP, __builtin_amdgcn_readlane(incl, 63));
     }
     }
+    if (noClass && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
     // (statistics: the rows of A that went through the class table -- the host's verdict "rows in stretches, or every row
     // for itself?")
     __syncthreads();

@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_mix_collect(int m, int* __restrict__ cl
     // (one reservation of list space per tile of 4096 rows: with one per wave -- 27 k same-address atomics on poisson27pt 128^3
     // with 0.1 % of its rows perturbed -- the kernel took 0.27 ms, all of it atomics queueing on one L2 word)
     __shared__ int wtot[4], sBase;
+    __shared__ unsigned char sNoPattern[kClassSlots];                // class -> not worked out (one pass over classInfo per block instead of a gather per row)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int c = tid; c < kClassSlots; c += 256) sNoPattern[c] = classInfo[c].z < 0 ? 1 : 0;
+    __syncthreads();
     for (long long t0 = (long long)blockIdx.x * kMixCollectTile; t0 < m; t0 += (long long)gridDim.x * kMixCollectTile) {
         unsigned badBits = 0;
         int pos[kMixCollectPer], mine = 0;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void k_mix_collect(int m, int* __restrict__ cl
             bool bad = false;
             if (i < m) {
                 const int c = classC[i];
-                bad = c < 0 || c == kClassDummy || classInfo[c].z < 0;
+                bad = c < 0 || c >= kClassSlots || sNoPattern[c] != 0;
                 if (bad) classC[i] = kClassDummy;
             }
             const unsigned long long mask = __ballot(bad);
@@ -120,12 +123,13 @@ __global__ __launch_bounds__(256) void k_mix_collect(int m, int* __restrict__ cl
 __global__ __launch_bounds__(256) void k_mix_upper_bound(const int* __restrict__ list, const int* __restrict__ count,
                                                          const int* __restrict__ Ap, const int* __restrict__ Aj, const int* __restrict__ Bp,
                                                          int* __restrict__ ub, int* __restrict__ cnt, unsigned long long* __restrict__ total,
-                                                         int* __restrict__ binCount, BinSpec spec)
+                                                         int* __restrict__ binCount, BinSpec spec,
+                                                         int* __restrict__ binCount2, BinSpec spec2)   // the same on a second ladder: the host chooses when it knows how many rows there are
 {
-    __shared__ int hist[kMaxBins];
+    __shared__ int hist[kMaxBins], hist2[kMaxBins];
     __shared__ unsigned long long bsum;
     const int tid = threadIdx.x, lane = tid & 63, g = lane & 15, grp = lane >> 4;
-    if (tid < kMaxBins) hist[tid] = 0;
+    if (tid < kMaxBins) hist[tid] = hist2[tid] = 0;
     if (tid == 0) bsum = 0;
     __syncthreads();
     const int n = *count;
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(256) void k_mix_upper_bound(const int* __restrict__
         ub[row] = v;
         if (v == 0) cnt[row] = 0;
         atomicAdd(&hist[bin_of(spec, v, nA, v, v)], 1);
+        atomicAdd(&hist2[bin_of(spec2, v, nA, v, v)], 1);
         mySum += (unsigned long long)tot;
     };
     const int nPad = (n + 15) / 16 * 16;                             // whole waves take part in the ballots
@@ -171,7 +176,56 @@ __global__ __launch_bounds__(256) void k_mix_upper_bound(const int* __restrict__
     if (mySum) atomicAdd(&bsum, mySum);
     __syncthreads();
     if (tid < kMaxBins && hist[tid]) atomicAdd(&binCount[tid], hist[tid]);
+    if (tid < kMaxBins && hist2[tid]) atomicAdd(&binCount2[tid], hist2[tid]);
     if (tid == 0 && bsum) atomicAdd(total, bsum);
+}
+
+// The queues of the listed rows, bin by bin (what k_fill_queues does for all rows of a matrix, 4096 rows per block: here a
+// few thousand rows want many small blocks).  FROM_ROWPTR: numeric bins -- key = rowPtrC, v = the row's entries, outBase --,
+// else symbolic bins by ub.  The bins' starts are summed from their counts by every block for itself (count[]: complete
+// when this kernel starts).  A row per thread, 256 rows per reservation; rows outside [rlo, rhi) are left out.
+template <bool FROM_ROWPTR>
+__global__ __launch_bounds__(256) void k_mix_fill(const int* __restrict__ list, const int* __restrict__ listCount, int rlo, int rhi,
+                                                  const int* __restrict__ key, const int* __restrict__ Ap, const int* __restrict__ ub,
+                                                  const int* __restrict__ binCount, int* __restrict__ binCursor, int4* __restrict__ queue,
+                                                  BinSpec spec, unsigned long long* __restrict__ binSums)
+{
+    __shared__ int hist[kMaxBins], base[kMaxBins], start[kMaxBins];
+    __shared__ unsigned long long sums[kMaxBins * 3];
+    const int tid = threadIdx.x;
+    if (tid < kMaxBins * 3) sums[tid] = 0;
+    if (tid == 0) {
+        int at = 0;
+        for (int b = 0; b < kMaxBins; ++b) { start[b] = at; at += b == 0 ? 0 : binCount[b]; }
+    }
+    const int n = *listCount;
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < n; i0 += (long long)gridDim.x * 256) {
+        if (tid < kMaxBins) hist[tid] = 0;
+        __syncthreads();
+        const long long idx = i0 + tid;
+        int row = idx < n ? list[idx] : -1;
+        if (row < rlo || row >= rhi) row = -1;
+        int b = 0, pos = 0, a0 = 0, a1 = 0, outBase = 0, v = 0, ubv = 0;
+        if (row >= 0) {
+            if (FROM_ROWPTR) { outBase = key[row]; v = key[row + 1] - outBase; } else v = key[row];
+            a0 = Ap[row];
+            a1 = Ap[row + 1];
+            ubv = ub[row];
+            b = bin_of(spec, v, a1 - a0, FROM_ROWPTR ? v : ubv, ubv);
+            if (b > 0) {
+                pos = atomicAdd(&hist[b], 1);
+                atomicAdd(&sums[b * 3 + 0], (unsigned long long)(unsigned)ubv);
+                if (FROM_ROWPTR) atomicAdd(&sums[b * 3 + 1], (unsigned long long)(unsigned)v);
+                atomicAdd(&sums[b * 3 + 2], (unsigned long long)(unsigned)(a1 - a0));
+            }
+        }
+        __syncthreads();
+        if (tid < kMaxBins && hist[tid]) base[tid] = start[tid] + atomicAdd(&binCursor[tid], hist[tid]);
+        __syncthreads();
+        if (b > 0) queue[base[b] + pos] = make_int4(row, a0, a1, outBase);
+        __syncthreads();
+    }
+    if (tid < kMaxBins * 3 && sums[tid]) atomicAdd(&binSums[tid], sums[tid]);
 }
 
 }  // namespace bhs

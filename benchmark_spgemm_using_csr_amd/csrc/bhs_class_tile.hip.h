@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
     // in LDS is free) and the row pointers of step s + 2 are.
     int followP = 0;
     int nHeadsMine = 0;
+    bool noClass = false;                                          // a row of this wave's found no class
     constexpr int NV = (TCAP + 3 + 255) / 256;                     // 16-byte loads per lane and tile
     struct Geom { int t0, tlen, off; bool inLds; };
     auto rp_issue = [&](long long base, int& a0, int& a1) {        // the lanes' row pointers of the step at `base`
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
                 }
                 s = (s + 1) & (kClassSlots - 1);
             }
-            if (__any(has && cls < 0) && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
+            noClass = noClass || __any(has && cls < 0);              // (told once, when the wave ends: one same-address atomic per batch of heads -- 150 k of them on poisson27pt 128^3 with 1 % of its rows perturbed -- was 1 ms of queueing at one L2 word)
             if (has && g == 0) sCls[sl] = cls;
         }
         // the head every row follows: the last head at or before it in the wave's walk, as (position << 13) | (class + 1)
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
         followP = max(followP, __builtin_amdgcn_readlane(incl, 63));
         a0 = a0n; a1 = a1n; a0n = a0nn; a1n = a1nn; gm = gmN;
     }
+    if (noClass && lane == 0) atomicOr(&stats[CS_FLAGS], 1);
     // (statistics: the rows of A that went through the class table)
     if (IS_A && lane == 0 && nHeadsMine) atomicAdd(&sCount, nHeadsMine);
     __syncthreads();

@@ -452,7 +452,7 @@ int symbolic_class(bhs_handle* h, bool mixed, const BinSpec& symSpec)
                            (int*)h->mixList.p, small + S_MIX_COUNT);
         hipLaunchKernelGGL(k_mix_upper_bound, dim3((unsigned)(h->numCU * 4)), dim3(256), 0, h->stream, (const int*)h->mixList.p,
                            (const int*)(small + S_MIX_COUNT), h->dAp, h->dAj, h->dBp, (int*)h->ub.p, (int*)h->Cp.p,
-                           (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, symSpec);
+                           (unsigned long long*)(small + S_TOTAL_CT), small + S_SYM_COUNT, symSpec, small + S_MIX_SYM2, coarse_spec(symSpec, kCoarseSym));
         BHS_HIP(hipGetLastError());
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches += 2;
@@ -543,7 +543,7 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     unsigned long long mixProducts = 0;
     if (useClass) {
         const int hubMin = mixedFlow ? hub_min_products(h) : 0;
-        const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, true, 0, hubMin);
+        BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, true, 0, hubMin);
         BHS_TRY(symbolic_class(h, mixedFlow, symSpec));
         sc.noUpperBound = true;                 // (no ub[] either: the numeric bins are never built)
         sc.numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, true, 0, hubMin);
@@ -577,24 +577,30 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         }
         if (mixRows > 0) {
             // their symbolic pass, bin by bin: exact counts into Cp[row] (the general pipeline's stage 2 on the listed rows)
+            // a handful of rows (fewer than one in sixteen): the ladder with fewer steps -- a launch costs more than a table
+            // that is too large for a few hundred rows
+            const bool coarse = (long long)mixRows * 16 <= (long long)m && h->maxTableLog2 >= 15;
+            if (coarse) {
+                symSpec = coarse_spec(symSpec, kCoarseSym);
+                sc.numSpec = coarse_spec(sc.numSpec, kCoarseNum);
+            }
             mixSymStart[0] = 0;
             for (int b = 0; b < kMaxBins; ++b) {
-                mixSymCount[b] = hs[S_SYM_COUNT + b];
+                mixSymCount[b] = hs[(coarse ? S_MIX_SYM2 : S_SYM_COUNT) + b];
                 mixSymStart[b + 1] = mixSymStart[b] + (b == 0 ? 0 : mixSymCount[b]);
             }
             h->nnzCt = (long long)mixProducts;                    // (launch_hub sizes its item list by it)
             h->cmpActive = false;
-            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_SYM_COUNT), small + S_SYM_START);
-            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + 255) / 256, (long long)h->numCU * 8));
             BHS_TRY(timed_begin(h, "fill_queues", &ep));
-            hipLaunchKernelGGL(k_fill_queues<false>, dim3((unsigned)gridF), dim3(256), 0, h->stream, m, (const int*)h->ub.p, h->dAp,
-                               (const int*)h->ub.p, (const int*)(small + S_SYM_START), small + S_SYM_CURSOR, (int4*)h->queue.p, symSpec,
-                               (unsigned long long*)(small + S_SYM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
+            hipLaunchKernelGGL(k_mix_fill<false>, dim3((unsigned)gridF), dim3(256), 0, h->stream, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT),
+                               0, 0x7fffffff, (const int*)h->ub.p, h->dAp, (const int*)h->ub.p, (const int*)(small + (coarse ? S_MIX_SYM2 : S_SYM_COUNT)), small + S_SYM_CURSOR,
+                               (int4*)h->queue.p, symSpec, (unsigned long long*)(small + S_SYM_SUMS));
             BHS_HIP(hipGetLastError());
             BHS_TRY(timed_end(h, ep));
             h->stats[ep->stat].launches++;
             const int4* symQueue = (const int4*)h->queue.p;
-            BHS_TRY(fork_bins(h, mixSymCount, kNumSymBins));
+            BHS_TRY(fork_bins(h, mixSymCount, kNumSymBins, h->mixFork != 0));
             if (mixSymCount[kHubBin]) {
                 bin_stream(h, kHubBin);
                 BHS_TRY(timed_begin(h, "symbolic_hub_rows", &ep));
@@ -634,26 +640,21 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         // (blockSum holds the tile words, cleared by k_class_reset)
         hipLaunchKernelGGL(k_class_scan, dim3((unsigned)nTiles), dim3(kClassScanBlock), 0, h->stream, m, (const int*)h->classC.p,
                            (const int4*)h->classInfo.p, (int*)h->Cp.p, (unsigned long long*)h->blockSum.p,
-                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS, mixRows > 0);
+                           (long long*)(small + S_TOTAL_C), small + S_CT_SLOTS, mixRows > 0, h->dAp, (const int*)h->ub.p, sc.numSpec, small + S_NUM_COUNT);
         BHS_HIP(hipGetLastError());
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches += 1;
         if (mixRows > 0) {
             // the irregular rows' numeric bins and queue (rowPtrC is final), on the device while the host waits for nnz(C)
             const BinSpec& ns = sc.numSpec;
-            BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));     // counts, starts, cursors
-            const long long gridH = std::max<long long>(1, std::min<long long>(((long long)mixRows + 255) / 256, (long long)h->numCU * 4));
-            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)mixRows + 255) / 256, (long long)h->numCU * 8));
             BHS_TRY(timed_begin(h, "fill_queues", &ep));
-            hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)gridH), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp, ns, small + S_NUM_COUNT,
-                               small + S_MAXCNT, (const int*)h->ub.p, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
-            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_NUM_COUNT), small + S_NUM_START);
-            hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, m, (const int*)h->Cp.p, h->dAp,
-                               (const int*)h->ub.p, (const int*)(small + S_NUM_START), small + S_NUM_CURSOR, (int4*)h->queue.p, ns,
-                               (unsigned long long*)(small + S_NUM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), 0, 0x7fffffff);
+            hipLaunchKernelGGL(k_mix_fill<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT),
+                               0, 0x7fffffff, (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_COUNT), small + S_NUM_CURSOR,
+                               (int4*)h->queue.p, ns, (unsigned long long*)(small + S_NUM_SUMS));
             BHS_HIP(hipGetLastError());
             BHS_TRY(timed_end(h, ep));
-            h->stats[ep->stat].launches += 2;
+            h->stats[ep->stat].launches++;
         }
     } else {
     if (h->scanOnePass) {
@@ -869,13 +870,12 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
             BHS_HIP(hipMemsetAsync(small + S_NUM_COUNT, 0, sizeof(int) * 3 * kMaxBins, h->stream));
             BHS_HIP(hipMemsetAsync(small + S_NUM_SUMS, 0, sizeof(unsigned long long) * 3 * kMaxBins, h->stream));
             const long long gridH = std::max<long long>(1, std::min<long long>(((long long)h->ps.mixRows + 255) / 256, (long long)h->numCU * 4));
-            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)h->ps.mixRows + kFillTile - 1) / kFillTile, (long long)h->numCU * 8));
+            const long long gridF = std::max<long long>(1, std::min<long long>(((long long)h->ps.mixRows + 255) / 256, (long long)h->numCU * 8));
             hipLaunchKernelGGL(k_bin_hist, dim3((unsigned)gridH), dim3(256), 0, h->stream, h->m, (const int*)h->Cp.p, h->dAp, numSpec, small + S_NUM_COUNT,
                                small + S_MAXCNT, (const int*)h->ub.p, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), r0, r1);
-            hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(64), 0, h->stream, (const int*)(small + S_NUM_COUNT), small + S_NUM_START);
-            hipLaunchKernelGGL(k_fill_queues<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, h->m, (const int*)h->Cp.p, h->dAp,
-                               (const int*)h->ub.p, (const int*)(small + S_NUM_START), small + S_NUM_CURSOR, (int4*)h->queue.p, numSpec,
-                               (unsigned long long*)(small + S_NUM_SUMS), (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT), r0, r1);
+            hipLaunchKernelGGL(k_mix_fill<true>, dim3((unsigned)gridF), dim3(256), 0, h->stream, (const int*)h->mixList.p, (const int*)(small + S_MIX_COUNT),
+                               r0, r1, (const int*)h->Cp.p, h->dAp, (const int*)h->ub.p, (const int*)(small + S_NUM_COUNT), small + S_NUM_CURSOR,
+                               (int4*)h->queue.p, numSpec, (unsigned long long*)(small + S_NUM_SUMS));
             BHS_HIP(hipGetLastError());
             BHS_HIP(hipMemcpyAsync(hr, small + S_NUM_COUNT, sizeof(int) * kMaxBins, hipMemcpyDeviceToHost, h->stream));
             BHS_TRY(wait_stream(h));
@@ -896,7 +896,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // all of its vector registers, and whatever is launched beside it waits for its waves to finish (measured on
         // poisson27pt 128^3 with 55 k irregular rows: their bins, 0.2 ms of work, ended 0.8 ms after the ring kernel beside
         // which they were launched; launched just in front of it, the last of them still did).
-        BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0));
+        BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0 && h->mixFork != 0));
         if (numCount[kHubBin]) {
             bin_stream(h, kHubBin);
             BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));

@@ -115,6 +115,21 @@ BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, boo
     return s;
 }
 
+// The ladder with fewer steps, for a handful of rows (mixed mode's irregular rows, bhs_class_mix.hip.h): a launch costs more
+// than a table that is too large for a few hundred rows.  keep: the bins that stay; a row of a dropped bin moves up.
+BinSpec coarse_spec(BinSpec s, unsigned keep)
+{
+    s.quadMax = 0;
+    int prev = 0;
+    for (int b = 2; b < s.nbins - 1; ++b) {
+        if (!((keep >> b) & 1u)) s.upper[b] = prev;
+        prev = s.upper[b];
+    }
+    return s;
+}
+constexpr unsigned kCoarseSym = (1u << 4) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);
+constexpr unsigned kCoarseNum = (1u << 4) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10);
+
 struct StatRec {
     const char* name;
     int launches = 0;
@@ -188,6 +203,7 @@ struct bhs_handle {
     // a class sends the data set to the general pipeline, as until round 5.
     int mixOn = 1, classMixed = 0;
     bool mixProbed = false;              // the mixed flow found every class of this data set worth its pattern: many classes alone no longer ask for it
+    int mixFork = 0;                     // option "class_mixed_fork": the irregular rows' bins side by side on the side streams whatever their number (measurement)
     int mixMaxPct = 30;                  // option "class_mixed_max_pct": more irregular rows than this share of all rows -> the general pipeline
     int lenStatsA[4] = {0, 0, 0, 0}, lenStatsB[4] = {0, 0, 0, 0};   // bhs_set_data's scan (k_max_row): rows beyond 64 entries, the longest within 64, rows beyond 256, the longest within 256
     DevBuf mixList, classCount;          // the irregular rows of A; rows per class (B's table, then A's)
@@ -304,17 +320,18 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_MAXCNT = 104 + 192 /* longest row of C */, S_UB_LONG = 104 + 193 /* rows on k_upper_bound's long list */,
        S_SCAN_TICKET = 104 + 194 /* tile numbers of k_scan_onepass */,
        S_MIX_COUNT = 104 + 195 /* rows on the mixed mode's list of irregular rows (bhs_class_mix.hip.h) */,
-       S_ZERO_END = 104 + 196,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 302, S_MAXROW = 303, S_SPEC = 304 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
-       S_LONG_B = 305 /* rows on k_check_sorted's long list */,
-       S_TICKETS = 306 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
-       S_CT_SLOTS = 322 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SCAN = 450 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
+       S_MIX_SYM2 = 104 + 196 /* kMaxBins: their symbolic bins on the coarse ladder (S_SYM_COUNT: on the fine one) */,
+       S_ZERO_END = 104 + 212,   /* everything below is zeroed at the start of every spgemm */
+       S_SORTED = 316, S_MAXROW = 317, S_SPEC = 318 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
+       S_LONG_B = 319 /* rows on k_check_sorted's long list */,
+       S_TICKETS = 320 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
+       S_CT_SLOTS = 336 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
+       S_SCAN = 464 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
                        the length of A's grid lines */,
-       S_SPAN = 456 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
-       S_ROWLEN = 460 /* bhs_set_data's scans for the classifier's sizes (k_max_row): per matrix rows beyond 64 entries, the
+       S_SPAN = 470 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
+       S_ROWLEN = 474 /* bhs_set_data's scans for the classifier's sizes (k_max_row): per matrix rows beyond 64 entries, the
                          longest row within 64, rows beyond 256, the longest within 256 -- A's four, then B's */,
-       S_SMALL_INTS = 468 };
+       S_SMALL_INTS = 482 };
 
 template <int V> struct template_int { static constexpr int value = V; };
 
