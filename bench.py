@@ -599,8 +599,30 @@ def main():
         bh.free_mem()
         del Ap, Aj, Ax, Bp, Bj, Bx
         torch.cuda.empty_cache()
-        for wname in ("p5_1024", "p9_1024", "p27_160", "fem3_40", "weblike_1m", "rmat_s20"):
-            if wname == "rmat_s20":     # a social-network graph (R-MAT, 2^20 rows): rows of C of thousands of entries by the ten thousand (bhs_row_window.hip.h)
+        clean_ms = ms_per_step
+        for wname in ("p5_1024", "p9_1024", "p27_160", "p27_128", "p27_128_perturbed", "p27_128_perturbed_1pct", "p27_128_one_long_row", "fem3_40",
+                      "weblike_1m", "rmat_s20", "p27_256_block_1of8", "p27_256"):
+            k2 = None                                   # (rows of B, where A is not the whole of it)
+            if wname.startswith("p27_128_"):
+                # Round 6 (mixed mode of the class path): the headline matrix with irregular rows -- 0.1 % / 1 % of its rows given
+                # one extra random entry (B = A: every row of A that points at such a row of B is irregular too, 2.6 % / 23.5 %
+                # of the rows), one row replaced by 300 consecutive entries.  vs_clean: this multiply / the headline's.
+                st2, d2 = "poisson27pt + irregular rows (gallery.perturb_rows_csr)", (128, 128, 128)
+                rp0, col0 = gallery.poisson_csr("poisson27pt", 128, 128, 128)
+                mm = len(rp0) - 1
+                if wname == "p27_128_one_long_row":
+                    rpw, colw = gallery.perturb_rows_csr(rp0, col0, mm, 0.0, long_row=(mm // 2 + 5, 300))
+                else:
+                    rpw, colw = gallery.perturb_rows_csr(rp0, col0, mm, 0.01 if wname.endswith("1pct") else 0.001, seed=11)
+                bp2, bj2 = torch.from_numpy(rpw).to(dev), torch.from_numpy(colw).to(dev)
+                del rp0, col0, rpw, colw
+            elif wname == "p27_256_block_1of8":
+                # BASELINE configs[4] seen from one rank (N = 1 anchor): the fourth of eight row blocks of
+                # poisson27pt 256^3 as A, the whole matrix as B -- no gather; what a GPU of the 8-GPU job multiplies per step
+                st2, d2 = "poisson27pt, rows [3/8, 4/8) of A against the whole of B", (256, 256, 256)
+                bp2, bj2 = gallery.poisson_csr_torch("poisson27pt", 256, 256, 256, device=dev)
+                k2 = int(bp2.numel()) - 1
+            elif wname == "rmat_s20":     # a social-network graph (R-MAT, 2^20 rows): rows of C of thousands of entries by the ten thousand (bhs_row_window.hip.h)
                 st2, d2 = "R-MAT graph (gallery.rmat_csr)", (1 << 20,)
                 rpw, colw = gallery.rmat_csr()
                 bp2, bj2 = torch.from_numpy(np.asarray(rpw)).to(dev), torch.from_numpy(np.asarray(colw)).to(dev)
@@ -617,9 +639,15 @@ def main():
                 st2, d2, _ = workload_dims(wname, 1)
                 bp2, bj2 = gallery.poisson_csr_torch(st2, *d2, device=dev)
             bx2 = gallery.fill_values_torch(int(bj2.numel()), device=dev)
-            ap2, aj2, ax2 = bp2.clone(), bj2.clone(), bx2.clone()
-            m2 = int(bp2.numel()) - 1
-            assert bh.initData_device(m2, m2, m2, int(aj2.numel()), ax2, ap2, aj2, int(bj2.numel()), bx2, bp2, bj2) == 0
+            if k2 is not None:
+                q0, q1 = 3 * (k2 // 8), 4 * (k2 // 8)
+                e0, e1 = int(bp2[q0]), int(bp2[q1])
+                ap2, aj2, ax2 = (bp2[q0:q1 + 1] - e0).to(torch.int32).contiguous(), bj2[e0:e1].contiguous(), bx2[e0:e1].contiguous()
+                m2 = q1 - q0
+            else:
+                ap2, aj2, ax2 = bp2.clone(), bj2.clone(), bx2.clone()
+                m2 = k2 = int(bp2.numel()) - 1
+            assert bh.initData_device(m2, k2, k2, int(aj2.numel()), ax2, ap2, aj2, int(bj2.numel()), bx2, bp2, bj2) == 0
             assert bh.set_option("kernel_stats", 0) == 0      # (library default; the headline keeps them for the roofline)
             for _ in range(3):
                 assert bh.spgemm() == 0
@@ -628,7 +656,11 @@ def main():
             for _ in range(10):
                 assert bh.spgemm() == 0
             msq = (time.perf_counter() - tq) / 10 * 1e3
-            balg = 2 * (4 * (m2 + 1) + 12 * int(bj2.numel())) + 4 * (m2 + 1) + 12 * bh.nnzC
+            nb_touched = int(bj2.numel())
+            if wname == "p27_256_block_1of8":        # (the rows of B this block's columns reach: the block and a grid plane + line + 1 either side)
+                halo = 256 * 256 + 256 + 1
+                nb_touched = int(bp2[min(k2, q1 + halo)]) - int(bp2[max(0, q0 - halo)])
+            balg = (4 * (m2 + 1) + 12 * int(aj2.numel())) + (4 * (min(k2, m2 + 2 * (256 * 256 + 257)) + 1) + 12 * nb_touched) + 4 * (m2 + 1) + 12 * bh.nnzC
             extra[wname] = {"workload": "%s %s C=A^2" % (st2, "x".join(map(str, d2))), "ms_per_step": round(msq, 4),
                             "gflops": round(2.0 * bh.nnzCt / (msq * 1e6), 2), "nnzCt": bh.nnzCt, "nnzC": bh.nnzC,
                             "pipeline_frac_of_hbm_peak": round(balg / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -641,6 +673,12 @@ def main():
                     if s_["launches"] > 0:
                         kacc[s_["name"]] = kacc.get(s_["name"], 0.0) + s_["ms"] / 3
             extra[wname]["kernels_ms_per_step"] = {k_: round(v_, 4) for k_, v_ in sorted(kacc.items()) if v_ >= 0.0005}
+            if wname == "p27_128":
+                clean_ms = msq                                      # (the headline's matrix timed the way these short runs are: kernel_stats off)
+            if wname.startswith("p27_128_"):
+                extra[wname]["vs_clean"] = round(msq / clean_ms, 4)
+                extra[wname]["irregular_rows"] = int(bh.get_info("mixed_rows"))
+                extra[wname]["class_state"] = int(bh.get_info("class_state"))
             bh.free_mem()
             del bp2, bj2, bx2, ap2, aj2, ax2
             torch.cuda.empty_cache()

@@ -41,6 +41,7 @@ constexpr int kClassBigCap = 1024;         // big classes per multiply
 constexpr int kClassMaxNnz = 512;          // entries per row of C
 constexpr unsigned long long kClassEmpty = ~0ull;
 constexpr int kClassDummy = kClassSlots;    // mixed mode: the "class" of a row without one -- slot kClassSlots of classInfo / classRing / classLane, all zeros: no entries, no products
+constexpr int kMixBesideRows = 1024;       // mixed mode: up to this many irregular rows their numeric kernels run beside the ring kernel, not in front of it
 constexpr int kClassManyClasses = 256;     // more classes than this in a multiply: are they classes, or single rows? (the mixed flow counts)
 constexpr int kClassMixMinRows = 4;        // mixed mode (bhs_class_mix.hip.h): a class with fewer rows than this is not worked out, its rows are irregular
 

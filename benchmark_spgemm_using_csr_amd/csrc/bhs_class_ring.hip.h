@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classRing, const int* __restrict__ classRel,
     const int* __restrict__ classLane, const int* __restrict__ Cp, int* __restrict__ Cj, value_t* __restrict__ Cx,
     int ringBytes, int accStride, int rowBase, int superRows, int chunkRows,     // m, Ap, classC, Cp are views of the rows [rowBase, rowBase + m)
-    const int* __restrict__ specWord)                                             // launched before the host saw this multiply's classes (k_class_spec_check): go on only if 1
+    const int* __restrict__ specWord,                                             // launched before the host saw this multiply's classes (k_class_spec_check): go on only if 1
+    int* __restrict__ tickets)                                                    // 8 counters, zero at launch: the next super-run of every XCD's band (round 6)
 {
     if (specWord != nullptr && *specWord != 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -85,9 +86,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     const int xcd = blockIdx.x & 7, perX = (nSuper + 7) / 8;
     const int wavesPerX = gridDim.x >> 3, wIdx = blockIdx.x >> 3;
     const int BPS = (superRows + 63) >> 6;                       // blocks per super-run
-    auto block_of = [&](int i, int& nr) -> int {                 // the i-th block of this wave: first row, rows (0: no such block)
+    // A wave's first super-run is its own (wave w of its XCD: the w-th of the band); the ones after it are handed out by the
+    // XCD's counter as the waves come for them (round 6).  Until round 5 wave w took the super-runs w, w + waves, w + 2 waves
+    // ...: 25 600 grid lines over 4096 waves (poisson27pt 160^3) are 6.25 each -- a quarter of the waves walked seven lines
+    // while the others idled behind their six, an eighth of the kernel's time; and a workgroup that starts late (mixed mode:
+    // the irregular rows' kernels still hold its CU) made the whole launch late by as much.
+    int srCur = wIdx;
+    auto block_of = [&](int i, int& nr) -> int {                 // the i-th block of this wave: first row, rows (0: no such block).  Called for i = 0, 1, 2, ...
         nr = 0;
-        const long long sr = (long long)wIdx + (long long)(i / BPS) * wavesPerX;
+        if (i > 0 && i % BPS == 0) {
+            if (tickets != nullptr) {
+                int tk = 0;
+                if (lane == 0) tk = atomicAdd(&tickets[xcd], 1);
+                srCur = wavesPerX + __builtin_amdgcn_readfirstlane(tk);
+            } else {
+                srCur += wavesPerX;                              // (option "ring_dynamic" 0: wave w takes the super-runs w, w + waves, ... as until round 5)
+            }
+        }
+        const long long sr = srCur;
         if (sr >= perX) return 0;
         const long long sup = (long long)xcd * perX + sr;
         if (sup >= nSuper) return 0;

@@ -370,6 +370,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_tile_piece")) { h->classTilePiece = (int)std::max<long long>(0, std::min<long long>(value, 1 << 17)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile")) { h->classTile = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_mixed")) { h->mixOn = value ? 1 : 0; h->classMixed = 0; if (h->classState < 0) h->classState = 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "ring_dynamic")) { h->ringDynamic = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_mixed_fork")) { h->mixFork = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_mixed_max_pct")) { h->mixMaxPct = (int)std::max<int64_t>(0, std::min<int64_t>(value, 100)); return BHS_SUCCESS; }
     if (!strcmp(key, "spin_wait")) { h->spinWait = value ? 1 : 0; return BHS_SUCCESS; }

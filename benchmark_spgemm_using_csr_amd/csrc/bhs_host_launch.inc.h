@@ -324,11 +324,13 @@ int launch_class_ring_impl(bhs_handle* h, int r0, int r1)
     grid = std::max<long long>(8, (grid + 7) / 8 * 8);
     const int chunkRows = std::max(1, std::min(64, 128 / std::max(1, h->ps.classMaxNA)));   // whole rows of a class, <= 128 entries of A (a row without a class is a chunk of its own: chunk_end)
     if (h->verbose > 1) printf("  [class numeric (ring, round 5): %d waves per CU by the occupancy API, %d used, %zu bytes of LDS each, grid %lld, %d rows per chunk]\n", perCU, useCU, lds.bytes, grid, chunkRows);
+    // (the XCDs' counters of super-runs: zero from the multiply's start for its first launch, cleared for a later row range's)
+    if (h->ps.ringLaunches++ > 0) BHS_HIP(hipMemsetAsync((int*)h->small.p + S_RING_TICKETS, 0, sizeof(int) * 8, h->ls));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds.bytes, h->ls, mR, h->dAp + r0, h->dAj, h->dAx,
                        (long long)h->nnzA, h->dBp, h->dBx, (long long)h->nnzB, (const int*)h->classC.p + r0, (const int4*)h->classInfo.p,
                        (const unsigned*)h->classRing.p, (const int*)h->classRel.p, (const int*)h->classLane.p, (const int*)h->Cp.p + r0, out_cj(h),
                        out_cx(h), lds.ringBytes, lds.accStride, r0, superRows, chunkRows,
-                       h->ps.specLaunched ? (const int*)h->small.p + S_SPEC : (const int*)nullptr);
+                       h->ps.specLaunched ? (const int*)h->small.p + S_SPEC : (const int*)nullptr, (h->ringDynamic == 1 || (h->ringDynamic == 2 && h->ps.ringBeside)) ? (int*)h->small.p + S_RING_TICKETS : (int*)nullptr);
     BHS_HIP(hipGetLastError());
     return BHS_SUCCESS;
 }

@@ -48,12 +48,12 @@ int fork_bins(bhs_handle* h, const int* count, int nbins, bool always = false)
 void bin_stream(bhs_handle* h, int bin)
 {
     h->ticketSlot = S_TICKETS + bin;
-    h->ls = h->binsForked ? h->binStream[bin % bhs_handle::kBinStreams] : h->stream;
+    h->ls = h->binsForked ? h->binStream[bin % bhs_handle::kBinStreams] : (h->besideStream ? h->besideStream : h->stream);
 }
 
 int join_bins(bhs_handle* h)
 {
-    h->ls = h->stream;
+    h->ls = h->stream;                    // (the "beside" mode's side stream is joined by its caller)
     h->ticketSlot = S_TICKET;
     if (!h->binsForked) return BHS_SUCCESS;
     h->binsForked = false;
@@ -896,7 +896,17 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // all of its vector registers, and whatever is launched beside it waits for its waves to finish (measured on
         // poisson27pt 128^3 with 55 k irregular rows: their bins, 0.2 ms of work, ended 0.8 ms after the ring kernel beside
         // which they were launched; launched just in front of it, the last of them still did).
+        // ... A HANDFUL of irregular rows (their kernels: a few workgroups, each a chain of round trips -- one row of 8100 products
+        // takes k_row_block 0.09 ms) go to ONE side stream and the ring kernel starts beside them at once: its workgroups on
+        // the few CUs those hold start late, and with its super-runs handed out by the XCDs' counters (ring_dynamic) nobody
+        // waits for them.
+        const bool beside = anyBin > 0 && h->ps.mixRows <= kMixBesideRows && h->ringDynamic != 0 && !h->mixFork;
+        if (beside) {                                            // (their kernels FIRST: what the ring kernel has taken it keeps until it ends)
+            BHS_HIP(hipEventRecord(h->evFork, h->stream));
+            BHS_HIP(hipStreamWaitEvent(h->binStream[0], h->evFork, 0));
+        }
         BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0 && h->mixFork != 0));
+        if (beside) h->besideStream = h->binStream[0];
         if (numCount[kHubBin]) {
             bin_stream(h, kHubBin);
             BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));
@@ -918,12 +928,19 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
             numStat[b] = ep->stat;
         }
         BHS_TRY(join_bins(h));
+        h->besideStream = nullptr;
+        h->ps.ringBeside = beside;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
         BHS_TRY(launch_class_ring(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
+        h->ps.ringBeside = false;
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += r1 - r0;
         if (full) { h->stats[ep->stat].products += h->nnzCt - h->ps.mixProducts; h->stats[ep->stat].nnzA_rows += h->nnzA; }
+        if (beside) {
+            BHS_HIP(hipEventRecord(h->evJoin[0], h->binStream[0]));
+            BHS_HIP(hipStreamWaitEvent(h->stream, h->evJoin[0], 0));
+        }
         return BHS_SUCCESS;
     }
     if (h->ps.useClass) {
@@ -1129,6 +1146,7 @@ void quiesce(bhs_handle* h)
     h->ls = h->stream;
     h->ticketSlot = S_TICKET;
     h->binsForked = false;
+    h->besideStream = nullptr;
     h->rowPtrStaged = false;
 }
 

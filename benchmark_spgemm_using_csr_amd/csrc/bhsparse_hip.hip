@@ -203,6 +203,12 @@ struct bhs_handle {
     // a class sends the data set to the general pipeline, as until round 5.
     int mixOn = 1, classMixed = 0;
     bool mixProbed = false;              // the mixed flow found every class of this data set worth its pattern: many classes alone no longer ask for it
+    // option "ring_dynamic": the ring kernel's super-runs handed out by a counter per XCD -- 1 always, 0 never (a fixed share per
+    // wave), 2 (default) where other kernels run beside it (mixed mode with a handful of irregular rows: its workgroups then
+    // start late on the CUs those kernels hold).  Measured in one process: poisson27pt 160^3 2.5689 against 2.5683 ms,
+    // 128^3 1.3652 / 1.3642, poisson9pt 1024^2 0.3499 / 0.3414 -- an even share costs nothing where the memory system is the
+    // limit (the waves with a line more run while the others' bandwidth is free), the counter costs a round trip per line.
+    int ringDynamic = 2;
     int mixFork = 0;                     // option "class_mixed_fork": the irregular rows' bins side by side on the side streams whatever their number (measurement)
     int mixMaxPct = 30;                  // option "class_mixed_max_pct": more irregular rows than this share of all rows -> the general pipeline
     int lenStatsA[4] = {0, 0, 0, 0}, lenStatsB[4] = {0, 0, 0, 0};   // bhs_set_data's scan (k_max_row): rows beyond 64 entries, the longest within 64, rows beyond 256, the longest within 256
@@ -221,6 +227,7 @@ struct bhs_handle {
     static constexpr int kBinStreams = 4;
     hipStream_t binStream[kBinStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evFork = nullptr, evJoin[kBinStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t besideStream = nullptr;  // mixed mode with a handful of irregular rows: their kernels' stream while the ring kernel runs on `stream`
     hipStream_t ls = nullptr;            // stream the launch helpers use (== stream unless a bin is being launched)
     int ticketSlot = 101;                // ticket word (index into `small`) of the bin being launched; S_TICKET
     int concurrentBins = 2;              // 0 never, 1 always, 2 when a stage has >= 8 non-empty bins
@@ -298,6 +305,8 @@ struct bhs_handle {
         int mixRows = 0;                 // ... how many
         bool mixNumFilled = false;       // ... their numeric queue (all rows) was filled behind the scan
         int mixSymCount[kMaxBins], mixNumCount[kMaxBins];
+        bool ringBeside = false;         // this launch of the ring kernel runs beside other kernels (mixed mode, a handful of irregular rows)
+        int ringLaunches = 0;            // launches of the ring kernel in this multiply (its tickets are zero for the first)
         long long mixProducts = 0;       // ... their products
         long long midRows = 0, longRows = 0;   // rows of the numeric bins between the hash tables and the long rows; the long rows
     } ps;
@@ -321,17 +330,18 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_SCAN_TICKET = 104 + 194 /* tile numbers of k_scan_onepass */,
        S_MIX_COUNT = 104 + 195 /* rows on the mixed mode's list of irregular rows (bhs_class_mix.hip.h) */,
        S_MIX_SYM2 = 104 + 196 /* kMaxBins: their symbolic bins on the coarse ladder (S_SYM_COUNT: on the fine one) */,
-       S_ZERO_END = 104 + 212,   /* everything below is zeroed at the start of every spgemm */
-       S_SORTED = 316, S_MAXROW = 317, S_SPEC = 318 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
-       S_LONG_B = 319 /* rows on k_check_sorted's long list */,
-       S_TICKETS = 320 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
-       S_CT_SLOTS = 336 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
-       S_SCAN = 464 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
+       S_RING_TICKETS = 104 + 212 /* 8: the ring kernel's next super-run per XCD (bhs_class_ring.hip.h) */,
+       S_ZERO_END = 104 + 220,   /* everything below is zeroed at the start of every spgemm */
+       S_SORTED = 324, S_MAXROW = 325, S_SPEC = 326 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
+       S_LONG_B = 327 /* rows on k_check_sorted's long list */,
+       S_TICKETS = 328 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
+       S_CT_SLOTS = 344 /* 64 x u64: product count of a lane-first multiply, spread over 64 counters */,
+       S_SCAN = 472 /* bhs_set_data's scans: longest row of A, its period hint, the same for B, A's entries near the diagonal,
                        the length of A's grid lines */,
-       S_SPAN = 470 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
-       S_ROWLEN = 474 /* bhs_set_data's scans for the classifier's sizes (k_max_row): per matrix rows beyond 64 entries, the
+       S_SPAN = 478 /* bhs_set_data's scans for bhs_row_span.hip.h: left reach of B's rows, right reach, widest row of A */,
+       S_ROWLEN = 482 /* bhs_set_data's scans for the classifier's sizes (k_max_row): per matrix rows beyond 64 entries, the
                          longest row within 64, rows beyond 256, the longest within 256 -- A's four, then B's */,
-       S_SMALL_INTS = 482 };
+       S_SMALL_INTS = 490 };
 
 template <int V> struct template_int { static constexpr int value = V; };
 

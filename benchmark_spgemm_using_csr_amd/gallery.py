@@ -344,24 +344,31 @@ def roadlike_csr(nx=1024, ny=1024, keep=0.62, seed=SEED):
 def perturb_rows_csr(rp, col, ncols, fraction=0.001, seed=SEED, long_row=None):
     """A structured matrix with irregular rows (round 6, mixed mode of the class path): `fraction` of the rows get ONE extra
     entry at a random column they do not hold yet; long_row = (row, entries): that row is replaced by `entries` consecutive
-    columns around its diagonal.  Rows stay sorted and duplicate-free.  Returns (rowPtr int32, colInd int32)."""
-    rp = np.asarray(rp, np.int64)
-    col = np.asarray(col, np.int64)
+    columns around its diagonal.  Rows stay sorted and duplicate-free (the input's rows must be).  Returns (rowPtr int32,
+    colInd int32).  (Splices into the sorted arrays: two seconds for poisson27pt 128^3.)"""
+    rp = np.asarray(rp, np.int64).copy()
+    col = np.asarray(col, np.int32)
     m = len(rp) - 1
     rng = np.random.default_rng(seed)
     nper = int(round(m * fraction))
     rows = np.sort(rng.choice(m, nper, replace=False)) if nper > 0 else np.zeros(0, np.int64)
     newc = rng.integers(0, ncols, nper)
-    row_of = np.repeat(np.arange(m, dtype=np.int64), np.diff(rp))
-    key = row_of * ncols + col
-    add = rows * ncols + newc
     if long_row is not None:
         r, L = long_row
         c0 = max(0, min(ncols - L, r - L // 2))
-        key = key[row_of != r]
-        add = np.concatenate([add[rows != r], r * ncols + np.arange(c0, c0 + L, dtype=np.int64)])
-    allk = np.unique(np.concatenate([key, add]))                      # (a drawn column the row holds already: no change)
-    r2 = allk // ncols
-    rp2 = np.zeros(m + 1, np.int64)
-    np.cumsum(np.bincount(r2, minlength=m), out=rp2[1:])
-    return rp2.astype(np.int32), (allk - r2 * ncols).astype(np.int32)
+        col = np.concatenate([col[:rp[r]], np.arange(c0, c0 + L, dtype=np.int32), col[rp[r + 1]:]])
+        rp[r + 1:] += L - (rp[r + 1] - rp[r])
+        keep = rows != r
+        rows, newc = rows[keep], newc[keep]
+    # where each new entry goes in its row (binary search inside the row), and whether the row holds the column already
+    pos = np.empty(len(rows), np.int64)
+    fresh = np.ones(len(rows), bool)
+    for i, (r, c) in enumerate(zip(rows, newc)):
+        seg = col[rp[r]:rp[r + 1]]
+        k = int(np.searchsorted(seg, c))
+        pos[i] = rp[r] + k
+        fresh[i] = not (k < len(seg) and seg[k] == c)
+    rows, newc, pos = rows[fresh], newc[fresh], pos[fresh]
+    col2 = np.insert(col, pos, newc.astype(np.int32))
+    rp2 = rp + np.searchsorted(rows, np.arange(m + 1), side="left")          # (entries inserted into the rows before row i)
+    return rp2.astype(np.int32), col2
