@@ -147,8 +147,11 @@ __global__ __launch_bounds__(kClassHeadsBlock) void k_class_fused(int nrows, con
             bool differs;
             if (r == 0) {                                         // (group 0: the pass before's last row)
                 const int src = max(lane - G, 0);
-                const bool okB = grp ? (bool)__shfl((int)ok[R - 1], src, 64) : okP;
-                const int lenB = grp ? __shfl(len[R - 1], src, 64) : lenP;
+                // (shuffles by ALL lanes, the selection afterwards: inside a lane-divergent ternary a masked-out lane hands its
+                // neighbour nothing -- bhs_class_tile.hip.h)
+                const int okSh = __shfl((int)ok[R - 1], src, 64), lenSh = __shfl(len[R - 1], src, 64);
+                const bool okB = grp ? okSh != 0 : okP;
+                const int lenB = grp ? lenSh : lenP;
                 differs = (grp == 0 && firstPass) || !ok[0] || !okB || len[0] != lenB;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
 {
     if (specWord != nullptr && *specWord != 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+    // (the LDS addresses below are plain integers counted from 0: the dynamic area must be all the LDS this kernel has --
+    // a compile-time constant, the test costs nothing)
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
     const int lane = threadIdx.x;
     // the ring (ringBytes: a power of two, at LDS address 0 -- the kernel has no static LDS), acc[accStride], the row's A values
     value_t* ring = reinterpret_cast<value_t*>(smemRaw);

@@ -57,6 +57,11 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
     __shared__ int sCount;
     __shared__ __attribute__((aligned(16))) int tileAll[WPB][TCAP + 8 + LMAX];
     __shared__ int sClsAll[WPB][64];
+    // (75 KB at G x E = 32: more than 64 KB of LDS per workgroup is gfx950's -- the Makefile's ARCH is not meant to be anything else)
+    static_assert(sizeof(int) * ((size_t)WPB * (TCAP + 8 + LMAX) + (size_t)NC * PW * 2 + WPB * 64 + 3 * NC) <= 160 * 1024, "k_class_tile: the tiles of a workgroup's waves must fit gfx950's 160 KB of LDS");
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+    static_assert(G * E < 0, "bhs_class_tile.hip.h is written for gfx950 (160 KB of LDS per workgroup)");
+#endif
     const int lane = threadIdx.x & 63, g = lane % G, grp = lane / G, wv = threadIdx.x >> 6;
     const int leaderLane = lane - g;
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull)) << (lane - g);

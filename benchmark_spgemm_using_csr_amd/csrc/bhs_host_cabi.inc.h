@@ -374,6 +374,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_mixed_fork")) { h->mixFork = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_mixed_max_pct")) { h->mixMaxPct = (int)std::max<int64_t>(0, std::min<int64_t>(value, 100)); return BHS_SUCCESS; }
     if (!strcmp(key, "spin_wait")) { h->spinWait = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "spin_wait_us")) { h->spinWaitUs = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1000000)); return BHS_SUCCESS; }
     if (!strcmp(key, "force_path")) { h->forcePath = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "max_table_log2")) {
         if (value < 6 || value > 15) return BHS_ERR_INVALID_ARG;
@@ -399,6 +400,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "window_bitmap")) { h->useWindowBitmap = (int)value; return BHS_SUCCESS; }
+    if (!strcmp(key, "sym_bitmap_min_log2")) { h->symBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap_min_log2")) { h->ldsBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }

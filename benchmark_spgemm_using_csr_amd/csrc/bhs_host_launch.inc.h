@@ -611,7 +611,10 @@ bool bin_takes_lds_bitmap(const bhs_handle* h, const KernelCfg& c)
 {
     if (!(h->useSpa && h->maxTableLog2 >= 15 && h->useLdsBitmap && h->n <= kLdsBitmapCols)) return false;
     if (c.win) return true;
-    return NUM && c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->forcePath == 0;
+    // (symbolic: the workgroup-per-row bin of 32768 slots -- 128 KB of LDS for a hash table where the bitmap's first pass and a
+    // popcount do: option "sym_bitmap_min_log2", 16: never)
+    if (!NUM) return c.block > 64 && c.log2ts >= h->symBitmapMinLog2 && h->forcePath == 0;
+    return c.block > 64 && c.log2ts >= h->ldsBitmapMinLog2 && h->forcePath == 0;
 }
 
 // (only when the multiply has enough such rows to fill the device's wave slots several times over -- h->ps.midRows, set

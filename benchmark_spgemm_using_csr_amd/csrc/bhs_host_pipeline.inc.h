@@ -5,16 +5,21 @@ constexpr int kSpecRefuted = -1000;      // pipeline_finish to run_pipeline_impl
 
 // The host waits for h->stream in the middle of a multiply (the bins' counts, nnzC) and at its end.  hipStreamSynchronize puts
 // the thread to sleep when the wait is long, and waking it costs ~20 us -- of a multiply of 0.2 .. 2 ms, two or three times.
-// Poll instead (option "spin_wait", on by default) for at most 50 ms, then sleep as before.
+// Poll instead (option "spin_wait", on by default), with a pause between polls, for as long as a multiply of this data set
+// may plausibly take (four times the last one's wall time, between 0.5 and 5 ms; option "spin_wait_us" sets a fixed cap) --
+// then sleep as before: a drop-in library must not keep a core busy for the 10 - 20 ms of a large multiply, let alone eight
+// ranks' cores next to RCCL's proxy threads.
 int wait_stream(bhs_handle* h)
 {
     if (h->spinWait) {
+        const long long capUs = h->spinWaitUs > 0 ? h->spinWaitUs : std::max<long long>(500, std::min<long long>(5000, (long long)(4000.0 * h->lastMultiplyMs)));
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0;; ++i) {
             const hipError_t e = hipStreamQuery(h->stream);
             if (e == hipSuccess) return BHS_SUCCESS;
-            if (e != hipErrorNotReady) { (void)hipGetLastError(); return BHS_ERR_LAUNCH; }
-            if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? (int)BHS_ERR_ALLOC : (int)BHS_ERR_LAUNCH; }
+            __builtin_ia32_pause();
+            if ((i & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(capUs)) break;
         }
     }
     BHS_HIP(hipStreamSynchronize(h->stream));
@@ -229,14 +234,18 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     for (int i = 1; i < kNumSymBins; ++i) {
         const int b = kNumSymBins - i;                              // longest rows first: they have the longest tails
         if (!symCount[b]) continue;
+        // (neighbouring bins that all run the LDS-bitmap kernel go as ONE queue, taken from its end: as in the numeric stage)
+        int lo = b, rows = symCount[b];
+        if (symQueue && h->mergeBitmapBins && bin_takes_lds_bitmap<false>(h, kSymCfg[b]))
+            while (lo - 1 >= 2 && bin_takes_lds_bitmap<false>(h, kSymCfg[lo - 1])) { --lo; rows += symCount[lo]; }
         bin_stream(h, b);
         BHS_TRY(timed_begin(h, kSymNames[b], &ep));
-        int rc = dispatch_bin<false>(h, kSymCfg[b], symQueue ? symQueue + symStart[b] : nullptr, symCount[b], (int*)h->Cp.p);
+        int rc = dispatch_bin<false>(h, kSymCfg[b], symQueue ? symQueue + symStart[lo] : nullptr, rows, (int*)h->Cp.p, lo < b);
         if (rc) { h->ls = h->stream; return rc; }
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
-        h->stats[ep->stat].rows += symCount[b];
-        symStat[b] = ep->stat;
+        h->stats[ep->stat].rows += rows;
+        for (int bb = lo; bb <= b; ++bb) { if (symCount[bb]) symStat[bb] = ep->stat; symCount[bb] = 0; }
     }
     BHS_TRY(join_bins(h));
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
@@ -1152,7 +1161,9 @@ void quiesce(bhs_handle* h)
 
 int run_pipeline(bhs_handle* h)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = run_pipeline_impl(h);
+    h->lastMultiplyMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc != BHS_SUCCESS) { quiesce(h); h->ps.open = false; }
     return rc;
 }

@@ -465,17 +465,26 @@ __global__ __launch_bounds__(kLdsBitmapBlock) void k_row_bitmap_lds(
     __syncthreads();
 
     // flat product space per chunk of CH A entries; f(column, product index in B, A entry index)
+    // (round 6: the NEXT chunk's A entries and B row pointers -- two dependent loads -- are requested before this chunk's
+    // products are walked: a row of a web graph's portal pages is 4 .. 10 chunks, two passes each, and every chunk used to
+    // start with those two round trips in front of its first product)
+    auto chunk_rows = [&](int ca, int a1, int& b0, int& len) {
+        b0 = 0; len = 0;
+        const int e = ca + tid;
+        if (tid < CH && e < a1) {
+            const int c = Aj[e];
+            int2 be;
+            __builtin_memcpy(&be, Bp + c, sizeof(be));
+            b0 = be.x;
+            len = be.y - be.x;
+        }
+    };
     auto expand = [&](int a0, int a1, auto&& f) {
+        int b0n = 0, lenn = 0;
+        chunk_rows(a0, a1, b0n, lenn);
         for (int ca = a0; ca < a1; ca += CH) {
-            const int e = ca + tid;
-            int b0 = 0, len = 0;
-            if (tid < CH && e < a1) {
-                const int c = Aj[e];
-                int2 be;
-                __builtin_memcpy(&be, Bp + c, sizeof(be));
-                b0 = be.x;
-                len = be.y - be.x;
-            }
+            const int b0 = b0n, len = lenn;
+            if (ca + CH < a1) chunk_rows(ca + CH, a1, b0n, lenn);   // (wave-uniform)
             int incl = wave_incl_scan_dpp(len);
             if (lane == 63) wtot[wv] = incl;
             __syncthreads();

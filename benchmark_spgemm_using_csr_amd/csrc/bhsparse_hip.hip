@@ -165,6 +165,8 @@ struct bhs_handle {
     int classTile = 1;                   // option "class_tile": the classifier with a lane per row (bhs_class_tile.hip.h) where rows have at most 32 entries
     int specNumeric = 1;                 // option "spec_numeric": 0 never launch speculatively
     int spinWait = 1;                    // option "spin_wait": the multiply's waits for its stream poll (wait_stream)
+    int spinWaitUs = 0;                  // option "spin_wait_us": the longest a wait polls before it sleeps (0: four times the last multiply's wall time, 0.5 .. 5 ms)
+    double lastMultiplyMs = 0.5;         // wall time of this handle's last bhs_spgemm
     long long specLaunches = 0, specRefuted = 0;
     int numDirectHint = -1;              // this data set's last whole multiply ran its numeric stage without queues (1), with them (0); -1: none yet
     int earlyFill = 1;                   // general pipeline: the queues filled while the host waits for the bin counts (starts computed on the device)
@@ -178,7 +180,7 @@ struct bhs_handle {
     // workspace
     DevBuf ub, queue, blockSum, small;   // small: counters (see layout below)
     DevBuf spaRank, spaBits;             // bitmap-accumulator slots for rows beyond the LDS tables (bitmaps kept all-zero)
-    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1, ldsBitmapMinLog2 = 12;
+    int spaSlots = 0, spaCols = -1, useSpa = 1, spaMaxSlots = 0, useLdsBitmap = 1, ldsBitmapMinLog2 = 12, symBitmapMinLog2 = 13;
     bool spaDirty = false;
     // hub rows (bhs_hub.hip.h): rows with at least hubMin products are cut into items of hubItemProducts products
     // that the whole device works on; one bitmap slot (+ rank words in the numeric stage) per row of a batch
