@@ -67,7 +67,7 @@ _lib = None
 _libs = {}
 
 
-SOURCES = ("bhsparse_hip.hip", "bhs_host_launch.inc.h", "bhs_host_pipeline.inc.h", "bhs_host_setdata.inc.h", "bhs_host_cabi.inc.h", "bhs_kernels.hip.h", "bhs_row_wg.hip.h", "bhs_row_window.hip.h", "bhs_row_wave.hip.h", "bhs_row_span.hip.h", "bhs_row_quad.hip.h", "bhs_compress.hip.h", "bhs_row_lane.hip.h", "bhs_row_tiny.hip.h", "bhs_sort.hip.h", "bhs_hub.hip.h", "bhs_class.hip.h", "bhs_class_wg.hip.h", "bhs_class_ring.hip.h", "bhs_class_fused.hip.h", "bhs_class_tile.hip.h", "bhs_class_big.hip.h", "bhs_wave.hip.h", "bhs_lab.hip.h")
+SOURCES = ("bhsparse_hip.hip", "bhs_host_launch.inc.h", "bhs_host_pipeline.inc.h", "bhs_host_setdata.inc.h", "bhs_host_cabi.inc.h", "bhs_kernels.hip.h", "bhs_row_wg.hip.h", "bhs_row_window.hip.h", "bhs_row_wave.hip.h", "bhs_row_quad.hip.h", "bhs_compress.hip.h", "bhs_row_lane.hip.h", "bhs_sort.hip.h", "bhs_hub.hip.h", "bhs_class.hip.h", "bhs_class_mix.hip.h", "bhs_class_wg.hip.h", "bhs_class_ring.hip.h", "bhs_class_fused.hip.h", "bhs_class_tile.hip.h", "bhs_class_big.hip.h", "bhs_wave.hip.h", "bhs_lab.hip.h")
 
 
 def source_digest():

@@ -394,7 +394,10 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "direct_bins")) { h->directBins = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sort_b")) { h->sortB = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "lane_rows")) { h->laneRows = (int)value; return BHS_SUCCESS; }
+#if BHS_LAB               // (bhs_row_tiny.hip.h / bhs_row_span.hip.h are not in a product build: the options do not exist there)
     if (!strcmp(key, "tiny_rows")) { h->tinyRows = value ? 1 : 0; return BHS_SUCCESS; }
+    if (!strcmp(key, "span_path")) { h->spanPath = value ? 1 : 0; h->spanState = 0; return BHS_SUCCESS; }
+#endif
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
@@ -417,7 +420,6 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "class_grid_mul")) { h->classGridMul = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_per_lane")) { h->classPerLane = (int)std::max<int64_t>(1, value); return BHS_SUCCESS; }
     if (!strcmp(key, "class_path")) { h->classPath = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); h->classState = 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "span_path")) { h->spanPath = value ? 1 : 0; h->spanState = 0; return BHS_SUCCESS; }
     if (!strcmp(key, "early_fill")) { h->earlyFill = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "sorted_scan")) { h->sortedScan = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_heads")) { h->classHeadsOn = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }

@@ -450,6 +450,7 @@ int launch_row_wave(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
     }
 }
 
+#if BHS_LAB
 // one wave per row, the row's columns as a bitmap over its span (bhs_row_span.hip.h); VCAP follows the bin's table size
 template <int WPL, int VCAP, bool NUM>
 int launch_row_span_impl(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
@@ -493,6 +494,7 @@ int launch_row_span(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt, int 
         return BHS_ERR_INTERNAL;
     }
 }
+#endif
 
 template <int LOG2TS>
 int launch_row_wave_csym(bhs_handle* h, const int4* queue, int qn, int* cnt)
@@ -574,6 +576,7 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
     const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
     // every row's products in registers where the longest rows of A and B seen at hand-over keep them to 32 (checked per
     // row on the device): bhs_row_tiny.hip.h
+#if BHS_LAB
     if (h->tinyRows && h->forcePath == 0 && h->maxRowA > 0 && h->maxRowB > 0 && (long long)h->maxRowA * h->maxRowB <= 32) {
 #define BHS_TINY(KA, LB)                                                                                              \
         if (h->maxRowA <= KA && h->maxRowB <= LB) {                                                                    \
@@ -585,6 +588,7 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
         BHS_TINY(5, 5) BHS_TINY(4, 8) BHS_TINY(8, 4) BHS_TINY(2, 16) BHS_TINY(16, 2)
 #undef BHS_TINY
     }
+#endif
 #define BHS_LANE(KK)                                                                                          \
     case KK:                                                                                                  \
         if (smallB)                                                                                           \
@@ -653,11 +657,13 @@ int dispatch_bin(bhs_handle* h, const KernelCfg& c, const int4* queue, int qn, i
             }
         }
     }
+#if BHS_LAB
     // rows accumulated over their column span where the data set's scans say every row fits (checked per row on the device)
     if (h->ps.spanWPL > 0 && c.block == 64 && !win && lg <= 10 && h->forcePath == 0) return launch_row_span<NUM>(h, queue, qn, CpOrCnt, lg);
     if constexpr (!NUM) {
         if (h->ps.spanWPL > 0 && c.block == 64 && !win && h->forcePath == 0) return launch_row_span<NUM>(h, queue, qn, CpOrCnt, lg);
     }
+#endif
 #define BHS_WAVE(LG) \
     if (lg == LG && c.block == 64 && !win && h->forcePath != 2) return launch_row_wave<LG, NUM>(h, queue, qn, CpOrCnt)
     BHS_WAVE(6); BHS_WAVE(7); BHS_WAVE(8); BHS_WAVE(9); BHS_WAVE(10); BHS_WAVE(11);

@@ -108,7 +108,12 @@ int finish_set_data(bhs_handle* h)
         BHS_TRY(check_sorted());
     }
     // the scans bhs_row_span.hip.h's kernels are chosen from (rows of B strictly ascending: first / last entry = smallest / largest column)
+#if BHS_LAB
     const bool spanScan = h->spanPath && h->m > 0 && h->k > 0 && h->nnzA > 0 && h->nnzB > 0;
+#else
+    const bool spanScan = false;
+#endif
+#if BHS_LAB
     if (spanScan) {
         BHS_HIP(hipMemsetD32Async((hipDeviceptr_t)(small0 + S_SPAN), (int)0x80000000, 2, h->stream));
         BHS_HIP(hipMemsetAsync(small0 + S_SPAN + 2, 0, sizeof(int), h->stream));
@@ -118,6 +123,7 @@ int finish_set_data(bhs_handle* h)
         hipLaunchKernelGGL(k_a_width, dim3((unsigned)ga), dim3(256), 0, h->stream, h->m, h->dAp, h->dAj, small0 + S_SPAN + 2);
         BHS_HIP(hipGetLastError());
     }
+#endif
     int* hscan = (int*)h->hostSmall;                                // (pinned)
     BHS_HIP(hipMemcpyAsync(hscan, small0 + S_SCAN, sizeof(int) * 6, hipMemcpyDeviceToHost, h->stream));
     if (checkB) {

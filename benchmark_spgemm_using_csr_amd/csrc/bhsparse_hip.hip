@@ -17,18 +17,26 @@
 #include "bhs_kernels.hip.h"
 #include "bhs_row_wg.hip.h"
 #include "bhs_row_wave.hip.h"
+#if BHS_LAB               // (kernels that were built, measured slower and left out of the product: tools/lab_tests.sh builds and tests them)
 #include "bhs_row_span.hip.h"
+#endif
 #include "bhs_row_window.hip.h"
 #include "bhs_row_quad.hip.h"
 #include "bhs_compress.hip.h"
 #include "bhs_row_lane.hip.h"
+#if BHS_LAB
 #include "bhs_row_tiny.hip.h"
+#endif
 #include "bhs_sort.hip.h"
 #include "bhs_hub.hip.h"
 #include "bhs_class.hip.h"
 #include "bhs_class_mix.hip.h"
 #include "bhs_class_wg.hip.h"
+#if BHS_LAB && defined(BHS_RING_LAB)       // (the ring kernel with its ablation switches: a copy outside the product's sources)
+#include "../../tools/lab/bhs_class_ring_lab.hip.h"
+#else
 #include "bhs_class_ring.hip.h"
+#endif
 #include "bhs_class_fused.hip.h"
 #include "bhs_class_tile.hip.h"
 #include "bhs_class_big.hip.h"

@@ -986,6 +986,9 @@ def test_rows_accumulated_over_their_column_span(oracle, kind):
     plats[bhmod.BHSPARSE_HIP] = True
     bh = bhmod.bhsparse()
     assert bh.initPlatform(plats) == 0
+    if bh.set_option("span_path", 1) != 0:              # (round 6: the kernel lost and is not in the product library)
+        assert bh.freePlatform() == 0
+        pytest.skip("bhs_row_span.hip.h is compiled into lab builds only: tools/lab_tests.sh")
     for span in (1, 0):
         assert bh.set_option("span_path", span) == 0
         assert bh.set_option("class_path", 0) == 0
@@ -1005,6 +1008,14 @@ def test_rows_accumulated_over_their_column_span(oracle, kind):
 def test_rows_of_at_most_32_products_in_registers(oracle, stencil, dims):
     """bhs_row_tiny.hip.h (round 5; off by default -- slower than the lane-per-row merge, profiles/r05_experiments.md):
     option "tiny_rows" = 1 takes rows of <= 5 x 5 products through a register sorting network.  Same C as the oracle's."""
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    probe = bhmod.bhsparse()
+    assert probe.initPlatform(plats) == 0
+    lab = probe.set_option("tiny_rows", 1) == 0
+    assert probe.freePlatform() == 0
+    if not lab:                                          # (round 6: the kernel lost and is not in the product library)
+        pytest.skip("bhs_row_tiny.hip.h is compiled into lab builds only: tools/lab_tests.sh")
     m, rp, col, val = poisson_case(stencil, *dims)
     ref = oracle.spgemm(m, m, m, rp, col, val, rp, col, val)
     for tiny in (1, 0):

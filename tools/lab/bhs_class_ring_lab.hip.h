@@ -1,3 +1,6 @@
+// tools/lab/bhs_class_ring_lab.hip.h -- the LAB COPY of benchmark_spgemm_using_csr_amd/csrc/bhs_class_ring.hip.h: the same kernel with its
+// ablation switches (BHS_CLS_LAB bits; several of them produce WRONG RESULTS by design -- they take one cost out of the loop to
+// measure the rest).  Built only by tools/build_variants.sh with -DBHS_LAB=1 -DBHS_RING_LAB=1; the product library never sees it.
 // bhs_class_ring.hip.h -- numeric pass by row classes, third form (round 5): the ring kernel with its per-product
 // bookkeeping taken out of the row loop.  (Included after bhs_class_wg.hip.h; the classification and the per-class
 // tables are bhs_class.hip.h's, the ring of slabs is bhs_class_wg.hip.h's -- read that header first.)
@@ -21,8 +24,6 @@
 //                where a stretch starts and nowhere else.
 // Per row and product: fma, masked {mov, add}, add + and-or = 5 VALU; ~9.5 KB of LDS (8 KB ring, 1 KB slots, the row's
 // A values) and <= 128 VGPRs: 16 waves per CU.
-// (The ablation switches this kernel was measured with -- no slab loads, no stores, fixed operands ...: wrong results by
-// design -- live in its lab copy, tools/lab/bhs_class_ring_lab.hip.h, outside the product's sources.)
 #pragma once
 
 namespace bhs {
@@ -46,6 +47,20 @@ __device__ __forceinline__ void ring_end_step(unsigned long long mask, unsigned&
                  : [p] "+v"(slotPtr), [s] "+v"(sum), [sv] "=&s"(saved)
                  : [m] "s"(mask)
                  : "memory");
+}
+
+// s_waitcnt vmcnt(n), n <= 2 * MAXV known at run time only: the row before's stores of C (the youngest n vector-memory
+// instructions of the wave; gfx9 retires a wave's loads and stores in the order they were issued) stay in flight,
+// everything older -- the slab requested before them, the chunk of A's values -- has arrived
+template <int K>
+__device__ __forceinline__ void wait_all_but_stores(int n)
+{
+    if constexpr (K > 0) {
+        if (n >= 2 * K) { __builtin_amdgcn_s_waitcnt(kWaitVm0 | ((2 * K) & 15) | (((2 * K) >> 4) << 14)); return; }
+        wait_all_but_stores<K - 1>(n);
+    } else {
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);
+    }
 }
 
 template <int MAXU, int MAXV, int MAXJ>
@@ -125,7 +140,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
         bhs_val2 ax = bhs_val2{(value_t)0, (value_t)0};
         const int e = 2 * lane;
         if (e < nE) {
-            if ((long long)base + e + 1 < nnzA) ax = *reinterpret_cast<const bhs_val2*>(Ax + base + e);
+            // (BHS_CLS_LAB & 8192: A's values, read once by one wave, not kept in the L2)
+            if ((long long)base + e + 1 < nnzA) ax = (BHS_CLS_LAB & 8192) ? __builtin_nontemporal_load(reinterpret_cast<const bhs_val2*>(Ax + base + e)) : *reinterpret_cast<const bhs_val2*>(Ax + base + e);
             else ax.x = Ax[base + e];
         }
         return ax;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
     unsigned stepB = 0, wrapB = 0;                               // bytes per slab, bytes of this class's ring
     int slots = 1;                                               // slabs of the ring
     bool oneRow = false;                                         // the class's ring is beyond the budget: every row loads its own slabs
-    int phase = 0, loadSlot = 0, lastRow = -2;
+    int phase = 0, loadSlot = 0, lastRow = -2, storesInFlight = 0;
     acc_t bv[MAXU], av[MAXU];                                    // the operands of the row at hand's products (read from LDS a row ahead where the rows carry on)
     bool preIssued = false;                                      // ... they are the row at hand's already
     bool ringOK = false;
@@ -154,15 +170,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
 
     // one slab: this lane's 16 bytes of each of its load instructions, if they are a piece of a B row
     auto request_slab = [&]() {
+        if (!(BHS_CLS_LAB & 1)) {
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            if (j * 64 * kClassEpl < slab) {
-                const bool piece = (dma[j] & 0xFF00) != 0;
-                if (piece && (long long)src[j] + kClassEpl <= nnzB)
-                    __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, BHS_RING_LOAD_AUX);
-                else if (piece)                                      // (the last few values of valB: no 16-byte load past its end)
-                    for (int e2 = 0; e2 < kClassEpl; ++e2)
-                        if ((long long)src[j] + e2 < nnzB) ring[loadSlot * slab + (j * 64 + lane) * kClassEpl + e2] = Bx[src[j] + e2];
+            for (int j = 0; j < MAXJ; ++j) {
+                if (j * 64 * kClassEpl < slab) {
+                    const bool piece = (dma[j] & 0xFF00) != 0;
+                    if (piece && (long long)src[j] + kClassEpl <= nnzB)
+                        __builtin_amdgcn_global_load_lds((bhs_glb_void*)(Bx + src[j]), (bhs_lds_void*)(ring + loadSlot * slab + j * 64 * kClassEpl), 16, 0, BHS_RING_LOAD_AUX);
+                    else if (piece)                                  // (the last few values of valB: no 16-byte load past its end)
+                        for (int e2 = 0; e2 < kClassEpl; ++e2)
+                            if ((long long)src[j] + e2 < nnzB) ring[loadSlot * slab + (j * 64 + lane) * kClassEpl + e2] = Bx[src[j] + e2];
+                }
             }
         }
 #pragma unroll
@@ -251,8 +269,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 BHS_TICK_CLS(1);
             }
             if (!ringOK || oneRow || row != lastRow + 1) {           // a stretch begins: its first slabs, all at once, from the slot the ring is at
-                const int ajv = lane < nA ? Aj[apT + lane] : -1;
-                const int bo = ajv >= 0 ? Bp[ajv] : 0;
+                // (BHS_CLS_LAB & 16384, wrong results: what the two dependent round trips of a stretch's start cost)
+                const int ajv = (BHS_CLS_LAB & 16384) ? -1 : (lane < nA ? Aj[apT + lane] : -1);
+                const int bo = ajv >= 0 ? Bp[ajv] : ((BHS_CLS_LAB & 16384) ? (apT & 0xFFFF) * 16 : 0);
 #pragma unroll
                 for (int j = 0; j < MAXJ; ++j) src[j] = (unsigned)(__shfl(bo, (dma[j] >> 16) & 63, 64) + (dma[j] & 255));
                 loadSlot = phase;
@@ -276,13 +295,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                 typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
                 const int k0 = 2 * lane - (apRow - curBase);
                 const unsigned a0 = afixBase + (unsigned)k0 * (unsigned)sizeof(acc_t);
-                if ((unsigned)k0 < (unsigned)nA) *(lds_acc)(size_t)a0 = (acc_t)axCur.x;
-                if ((unsigned)(k0 + 1) < (unsigned)nA) *(lds_acc)(size_t)(a0 + (unsigned)sizeof(acc_t)) = (acc_t)axCur.y;
+                if (!(BHS_CLS_LAB & 16)) {
+                    if ((unsigned)k0 < (unsigned)nA) *(lds_acc)(size_t)a0 = (acc_t)axCur.x;
+                    if ((unsigned)(k0 + 1) < (unsigned)nA) *(lds_acc)(size_t)(a0 + (unsigned)sizeof(acc_t)) = (acc_t)axCur.y;
+                }
                 wave_sync();
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) bv[u] = (acc_t)*(lds_val)(size_t)at[u];
+                for (int u = 0; u < MAXU; ++u) bv[u] = (BHS_CLS_LAB & 64) ? (acc_t)*(lds_val)(size_t)(unsigned)(lane * 8 + u * 512) : (acc_t)*(lds_val)(size_t)at[u];
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) av[u] = *(lds_acc_c)(size_t)aAddr[u];
+                for (int u = 0; u < MAXU; ++u) av[u] = (BHS_CLS_LAB & 128) ? (acc_t)(u + 1) : *(lds_acc_c)(size_t)aAddr[u];
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {                     // (unsigned: below the ring's end the difference wraps to something huge)
                     const unsigned nx = at[u] + stepB;
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
 #pragma unroll
                 for (int u = 0; u < MAXU; ++u) {
                     sum = __builtin_fma(av[u], bv[u], sum);
-                    ring_end_step(endMask[u], slotPtr, sum);
+                    if (!(BHS_CLS_LAB & 32)) ring_end_step(endMask[u], slotPtr, sum);
                 }
                 if (tail >= 0) unsafeAtomicAdd(&acc[tail], sum);     // (after every plain store of the row: in order)
             }
@@ -307,12 +328,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
             BHS_TICK_CLS(4);
             // whatever is in flight was requested a row ago: the slab the next row needs first -- and the row before's stores,
             // which nobody here waits for (their acknowledgement takes longer than a row's arithmetic)
-            // (A counted wait that leaves the row before's stores in flight -- tools/lab/bhs_class_ring_lab.hip.h, bit 8 -- measured the same, and
+            // (A counted wait that leaves the row before's stores in flight -- wait_all_but_stores -- measured the same, and
             // keeps the compiler from knowing that the chunk of A's values has arrived: it then waits in front of their use.)
-            __builtin_amdgcn_s_waitcnt(kWaitVm0);
+            if (BHS_CLS_LAB & 8) wait_all_but_stores<MAXV>(storesInFlight);
+            else __builtin_amdgcn_s_waitcnt(kWaitVm0);
             BHS_TICK_CLS(6);
             // this row's sums, out of the slots before the next row's arithmetic writes there
-            const int out = __builtin_amdgcn_readlane(pc.cp, t);
+            const int out = (BHS_CLS_LAB & 512) ? (int)(blockIdx.x * 1024) : __builtin_amdgcn_readlane(pc.cp, t);   // (512: every wave writes its rows to one place)
             acc_t x0[MAXW], x1[MAXW];
             {
                 typedef __attribute__((address_space(3))) const acc_t* lds_acc_c;
@@ -360,14 +382,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
             // sums: no store below has to wait for an LDS read
             __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
             preIssued = false;
-            if (!oneRow && t + 1 < nr && __builtin_amdgcn_readlane(pc.cls, min(t + 1, 63)) == cur) {
+            if (!(BHS_CLS_LAB & 4096) && !oneRow && t + 1 < nr && __builtin_amdgcn_readlane(pc.cls, min(t + 1, 63)) == cur) {
                 issue_reads(__builtin_amdgcn_readlane(pc.ap, min(t + 1, 63)));
                 preIssued = true;
             }
             BHS_TICK_CLS(9);
             if (!oneRow) request_slab();
             BHS_TICK_CLS(11);
-            {
+            storesInFlight = (BHS_CLS_LAB & 2) ? 0 : 2 * ((nnz + 127) >> 7);   // (the store instructions below: a pair per 128 entries)
+            if (!(BHS_CLS_LAB & 2)) {
                 int* const cjRow = Cj + (long long)out;
                 value_t* const cxRow = Cx + (long long)out;
                 if (nnz >= 2) {
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAV
                         const int q = w2 * 64 + lane;
                         if (2 * q < nnz) {                           // (an odd row's last lane: its neighbour's second entry once more, and the last)
                             const int e0 = min(2 * q, nnz - 2);
-                            class_store_c2_at(cjRow, (unsigned)e0 * (unsigned)sizeof(int), relA[w2] + row + rowBase, relB[w2] + row + rowBase);
+                            if (!(BHS_CLS_LAB & 1024)) class_store_c2_at(cjRow, (unsigned)e0 * (unsigned)sizeof(int), relA[w2] + row + rowBase, relB[w2] + row + rowBase);
                             class_store_c2_at(cxRow, (unsigned)e0 * (unsigned)sizeof(value_t), (value_t)x0[w2], (value_t)x1[w2]);
                         }
                     }
