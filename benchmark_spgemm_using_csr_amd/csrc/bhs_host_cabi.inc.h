@@ -366,6 +366,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
 {
     if (!h || !key) return BHS_ERR_INVALID_ARG;
     h->classSpec.valid = false;                                     // (any option may change what a multiply decides)
+    h->laneSpec.valid = false;
     if (!strcmp(key, "spec_numeric")) { h->specNumeric = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile_piece")) { h->classTilePiece = (int)std::max<long long>(0, std::min<long long>(value, 1 << 17)); return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile")) { h->classTile = value ? 1 : 0; return BHS_SUCCESS; }

@@ -570,7 +570,7 @@ int launch_row_quad(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 
 template <bool NUM>
 int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCnt, int* ubOut = nullptr,
-                    unsigned long long* ctSlots = nullptr)
+                    unsigned long long* ctSlots = nullptr, const int* specWord = nullptr)
 {
     const unsigned grid = (unsigned)(((long long)qn + 255) / 256);
     const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
@@ -594,11 +594,11 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
-                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord);        \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
-                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR);                  \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord);        \
         break;
     switch (K) {
         BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)

@@ -72,7 +72,7 @@ int join_bins(bhs_handle* h)
 // Stages 1 and 2 of the general pipeline: upper bound, symbolic bins and queues, the symbolic kernels.  Leaves the
 // per-row counts in Cp and tells stage 3 which choices it made.
 struct SymChoices {
-    bool noUpperBound = false, symDirect = false;
+    bool noUpperBound = false, symDirect = false, laneFirst = false;
     int laneK = 0, hubRows = 0;
     BinSpec numSpec;
 };
@@ -251,6 +251,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     BHS_HIP(hipEventRecord(h->ev[2], h->stream));
 
     out.noUpperBound = noUpperBound;
+    out.laneFirst = laneFirst;
     out.symDirect = symDirect;
     out.laneK = laneK;
     out.hubRows = noUpperBound ? 0 : symCount[kHubBin];
@@ -730,6 +731,31 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
         BHS_HIP(hipEventRecord(h->ev[3], h->stream));
         return stage_rowptr_and_open(h);
     }
+    // ... and a lane-first multiply likewise (round 6): the last multiply's nnz(C) and "every row in the lane bin" stand in,
+    // k_lane_spec_check compares on the device, pipeline_finish sees the verdict
+    h->ps.laneFirst = !useClass && sc.laneFirst;
+    if (!useClass && !restart && sc.laneFirst && h->specNumeric && h->laneSpec.valid && h->laneSpec.laneK == sc.laneK && !h->lazyOut &&
+        h->directBins && h->scanOnePass && (h->laneNumeric == 1 || (h->laneNumeric == 2 && sc.laneK <= 8))) {
+        const long long need = std::max<long long>(h->laneSpec.nnzC, 1);
+        const bool room = h->extCj ? h->laneSpec.nnzC <= h->extCap
+                                   : (h->Cj.p && h->Cx.p && h->Cj.cap >= (size_t)need * sizeof(int) && h->Cx.cap >= (size_t)need * sizeof(value_t));
+        if (room) {
+            hipLaunchKernelGGL(k_lane_spec_check, dim3(1), dim3(64), 0, h->stream, h->laneSpec.nnzC, m, (const long long*)(small + S_TOTAL_C),
+                               (const int*)(small + S_ERR), (const int*)(small + S_NUM_COUNT), small + S_SPEC);
+            BHS_HIP(hipGetLastError());
+            h->ps.specLaunched = true;
+            h->ps.specLane = true;
+            h->specLaunches++;
+            h->nnzC = h->laneSpec.nnzC;
+            h->nnzCt = h->laneSpec.nnzCt;                  // (pipeline_finish puts this multiply's own count here)
+            h->ps.noUpperBound = noUpperBound;
+            h->ps.symDirect = symDirect;
+            h->ps.laneK = laneK;
+            h->ps.numSpec = numSpec;
+            BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+            return stage_rowptr_and_open(h);
+        }
+    }
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_TRY(wait_stream(h));
     if (useClass) {
@@ -866,6 +892,18 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
     const int laneK = h->ps.laneK;
     int (&numStat)[kMaxBins] = h->ps.numStat;
     h->ls = h->stream;
+    if (h->ps.specLane) {
+        // (a whole multiply: bhs_spgemm_symbolic's lazyOut keeps the two-halves API off this path)
+        h->ps.rangesRun++;
+        BHS_TRY(timed_begin(h, "numeric_lane", &ep));
+        BHS_TRY(launch_row_lane<true>(h, laneK, nullptr, h->m, (int*)h->Cp.p, nullptr, nullptr, (const int*)h->small.p + S_SPEC));
+        BHS_TRY(timed_end(h, ep));
+        h->stats[ep->stat].launches++;
+        h->stats[ep->stat].rows += h->m;
+        numStat[kLaneBin] = ep->stat;
+        h->ps.numDirectFull = true;
+        return BHS_SUCCESS;
+    }
     if (h->ps.useClass && h->ps.mixed) {
         // Mixed mode (bhs_class_mix.hip.h): the ring kernel on the rows with a class -- it skips the others -- and, beside it on
         // the side streams, the general pipeline's numeric kernels on the queue of the rows without
@@ -1028,6 +1066,9 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         h->stats[ep->stat].launches++;
     }
     if (full) { h->ps.numDirectFull = numDirect; h->numDirectHint = numDirect ? 1 : 0; }
+    // (what the next multiply of this data set may assume: every row through the lane kernels, this nnz(C))
+    h->laneSpec.valid = full && h->ps.laneFirst && numDirect && numCount[kLaneBin] == m && !h->lazyOut;
+    if (h->laneSpec.valid) { h->laneSpec.laneK = laneK; h->laneSpec.nnzC = h->nnzC; h->laneSpec.nnzCt = h->nnzCt; }
     h->ps.rangesRun++;
     const int4* numQueue = numDirect ? nullptr : (const int4*)h->queue.p;
     h->ps.midRows = h->ps.longRows = 0;
@@ -1087,7 +1128,12 @@ int pipeline_finish(bhs_handle* h)
     BHS_HIP(hipMemcpyAsync(hs, small, sizeof(int) * S_SMALL_INTS, hipMemcpyDeviceToHost, h->stream));
     BHS_HIP(hipEventRecord(h->ev[4], h->stream));
     BHS_TRY(wait_stream(h));
-    if (h->ps.specLaunched) {
+    if (h->ps.specLaunched && h->ps.specLane) {
+        if (hs[S_SPEC] != 1) return kSpecRefuted;
+        unsigned long long t = 0, v;
+        for (int i = 0; i < 64; ++i) { memcpy(&v, hs + S_CT_SLOTS + 2 * i, 8); t += v; }
+        h->nnzCt = h->laneSpec.nnzCt = (long long)t;
+    } else if (h->ps.specLaunched) {
         if (hs[S_SPEC] != 1) return kSpecRefuted;       // (the numeric kernel has written nothing: run_pipeline_impl starts over)
         unsigned long long t = 0, v;
         for (int i = 0; i < kClassSumSlots; ++i) { memcpy(&v, hs + S_CT_SLOTS + CS_SUMS + 2 * i, 8); t += v; }
@@ -1135,6 +1181,7 @@ int run_pipeline_impl(bhs_handle* h)
     if (rc != kSpecRefuted) return rc;
     // the arrays are not what they were a multiply ago: once more, every decision from this multiply's own figures
     h->classSpec.valid = false;
+    h->laneSpec.valid = false;
     h->specRefuted++;
     if (h->verbose > 1) printf("  [speculative numeric launch refuted on the device: the multiply again]\n");
     BHS_TRY(pipeline_symbolic(h, true));            // (restart: the refuted attempt's timers and kernel records stay in -- it ran inside this multiply)

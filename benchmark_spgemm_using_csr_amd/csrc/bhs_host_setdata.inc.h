@@ -68,6 +68,7 @@ int finish_set_data(bhs_handle* h)
     h->specFailed = false;
     h->numDirectHint = -1;
     h->classSpec.valid = false;
+    h->laneSpec.valid = false;
     h->classState = 0;
     const bool checkB = h->nnzB > 1 && h->k > 0;
     // rows of B beyond kSortedLongB entries are listed and checked by k_check_sorted_long, 16 workgroups per row

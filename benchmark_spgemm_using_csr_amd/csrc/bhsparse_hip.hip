@@ -169,6 +169,8 @@ struct bhs_handle {
     // the classes' figures of this data set's last whole multiply on the ring kernel: the next one launches its numeric kernel on
     // them before it has seen its own (pipeline_symbolic), checked on the device (k_class_spec_check)
     struct ClassSpec { bool valid = false; int cs[CS_INTS]; long long nnzC = 0, nnzCt = 0; } classSpec;
+    // ... the same for a lane-first multiply whose numeric stage ran k_row_lane on every row (k_lane_spec_check)
+    struct LaneSpec { bool valid = false; int laneK = 0; long long nnzC = 0, nnzCt = 0; } laneSpec;
     int classTilePiece = 0;              // option "class_tile_piece": rows per wave of that classifier (0: one piece per wave slot)
     int classTile = 1;                   // option "class_tile": the classifier with a lane per row (bhs_class_tile.hip.h) where rows have at most 32 entries
     int specNumeric = 1;                 // option "spec_numeric": 0 never launch speculatively
@@ -311,6 +313,8 @@ struct bhs_handle {
         int spanWPL = 0;                 // this multiply's wave bins run k_row_span with this many bitmap words per lane (0: hash kernels)
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
         bool specLaunched = false;       // the numeric kernel goes out on the last multiply's figures (classSpec), k_class_spec_check decides
+        bool specLane = false;           // ... a lane-first multiply's (laneSpec, k_lane_spec_check)
+        bool laneFirst = false;          // this multiply's symbolic stage was the lane kernel on every row, no upper-bound pass
         bool mixed = false;              // class path with irregular rows on the general kernels (bhs_class_mix.hip.h)
         int mixRows = 0;                 // ... how many
         bool mixNumFilled = false;       // ... their numeric queue (all rows) was filled behind the scan

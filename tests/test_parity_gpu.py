@@ -1144,6 +1144,62 @@ def test_direct_launch_bounds_are_verified_on_the_device(oracle, stencil, dims):
 
 
 @pytest.mark.gpu
+def test_speculative_lane_launch_is_verified_on_the_device(oracle):
+    """Round 6: a lane-first multiply (poisson5pt: every row through k_row_lane) launches its numeric kernel on the last
+    multiply's nnz(C) too (k_lane_spec_check).  New values: the launch stands.  A column index of A moved so that a row of C
+    gains an entry: nnz(C) differs, the launch is refuted, the multiply runs again and is right.  A row of A grown beyond the
+    lane kernel's heads: refuted by the kernel's own check, right again."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m, rp, col, val = poisson_case("poisson5pt", 64, 50, 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Bp, Bj, Bx = t(rp), t(col), t(val)
+    Ap, Aj, Ax = Bp.clone(), Bj.clone(), Bx.clone()
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.set_option("class_path", 0) == 0
+    assert bh.initData_device(m, m, m, len(col), Ax, Ap, Aj, len(col), Bx, Bp, Bj) == 0
+
+    def check(arp, acol, aval):
+        ref = oracle.spgemm(m, m, m, arp, acol, aval, rp, col, val)
+        assert bh.spgemm() == 0
+        Cp = bh.get_rowptrC()
+        nnzC = bh.get_nnzC()
+        Cj = np.empty(nnzC, np.int32); Cx = np.empty(nnzC, np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert bh.nnzCt == oracle.nnzCt(arp, acol, rp)
+        assert oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)["ok"]
+        return {s_["name"] for s_ in bh.kernel_stats() if s_["launches"]}
+
+    names = check(rp, col, val)
+    assert "numeric_lane" in names and "upper_bound" not in names and bh.get_info("spec_launches") == 0
+    check(rp, col, val); check(rp, col, val)
+    assert bh.get_info("spec_launches") == 2 and bh.get_info("spec_refuted") == 0
+    val2 = val.copy(); val2[::5] += 2.0
+    Ax.copy_(t(val2)); torch.cuda.synchronize()
+    check(rp, col, val2)
+    assert bh.get_info("spec_launches") == 3 and bh.get_info("spec_refuted") == 0
+    r = m // 2 + 3                                       # an interior row's first column (r - 64) moves one to the left: its row of C changes shape
+    col2 = col.copy(); col2[rp[r]] -= 1
+    Aj.copy_(t(col2)); torch.cuda.synchronize()
+    nnz_before = bh.get_nnzC()
+    check(rp, col2, val2)
+    assert bh.get_info("spec_launches") == 4 and bh.get_info("spec_refuted") == (1 if bh.get_nnzC() != nnz_before else 0)
+    refuted = bh.get_info("spec_refuted")
+    check(rp, col2, val2)
+    assert bh.get_info("spec_refuted") == refuted
+    # row 5 of A swallows rows 5..8 (20 entries > the lane kernel's heads): the kernels' own check refutes whatever was assumed
+    rp2 = rp.copy(); rp2[6:9] = rp[9]
+    Ap.copy_(t(rp2)); torch.cuda.synchronize()
+    names = check(rp2, col2, val2)
+    assert "upper_bound" in names
+    check(rp2, col2, val2)
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
+@pytest.mark.gpu
 def test_speculative_numeric_launch_is_verified_on_the_device(oracle):
     """From a data set's second multiply on, the class path launches its numeric kernel on the figures of the multiply before
     -- how many classes, their longest lists, the LDS they need, nnzC -- without reading this multiply's back first
