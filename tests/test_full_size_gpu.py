@@ -298,3 +298,75 @@ def test_nnz_overflow_is_an_error_code(hiplib):
         assert bh.spgemm() == facade._lib.BHS_ERR_NNZ_OVERFLOW
         assert bh.free_mem() == 0
         assert bh.freePlatform() == 0
+
+
+@pytest.mark.parametrize("case", ["perturbed_0.1pct", "long_and_hub_rows"])
+def test_poisson27pt_128_cubed_with_irregular_rows(hiplib, oracle, case):
+    """Round 6, mixed mode of the class path at BASELINE configs[2]'s size: poisson27pt 128^3 with 0.1 % of its rows given an
+    extra entry, or with a 300-entry row, a 7000-entry row (its 189 000 products: a hub row, n > 2^20 columns) and an empty
+    row.  The class kernels did run, the irregular rows are few, C has CSR's structure, C.x = A.(B.x) exactly, the whole
+    of C equals the general pipeline's bit for bit, and a block of rows around an irregular one equals the CPU oracle's."""
+    import torch
+    from benchmark_spgemm_using_csr_amd import gallery, facade
+    from benchmark_spgemm_using_csr_amd.dist import device_view
+    dev = torch.device("cuda", 0)
+    rp0, col0 = gallery.poisson_csr("poisson27pt", 128, 128, 128)
+    m = len(rp0) - 1
+    if case.startswith("perturbed"):
+        rp, col = gallery.perturb_rows_csr(rp0, col0, m, 0.001, seed=11)
+        probe = int(np.flatnonzero(np.diff(rp) != np.diff(rp0))[len(rp) // 4000])
+    else:
+        rp, col = gallery.perturb_rows_csr(rp0, col0, m, 0.0, long_row=(m // 2 + 5, 300))
+        rp, col = gallery.perturb_rows_csr(rp, col, m, 0.0, long_row=(m // 3, 7000))
+        lens = np.diff(rp).copy()
+        keep = np.ones(len(col), bool); keep[rp[12345]:rp[12346]] = False
+        lens[12345] = 0
+        col = col[keep]; rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum(lens)
+        probe = m // 3
+    del rp0, col0
+    val = gallery.fill_values(len(col))
+    Ap, Aj, Ax = (torch.from_numpy(x).to(dev) for x in (rp, col, val))
+    plats = [False] * facade.NUM_PLATFORMS
+    plats[facade.BHSPARSE_HIP] = True
+    outs = []
+    for opts in ({}, {"class_path": 0}):
+        bh = facade.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        for k_, v_ in opts.items():
+            assert bh.set_option(k_, v_) == 0
+        assert bh.initData_device(m, m, m, Aj.numel(), Ax, Ap, Aj, Aj.numel(), Ax, Ap, Aj) == 0
+        for _ in range(2):
+            assert bh.spgemm() == 0
+        names = {s["name"] for s in bh.kernel_stats() if s["launches"] > 0}
+        if not opts:
+            assert "numeric_class" in names and bh.get_info("class_state") == 2
+            assert 0 < bh.get_info("mixed_rows") < m // 20
+        else:
+            assert "numeric_class" not in names
+        nnzC = bh.get_nnzC()
+        pr, pc, pv = bh.get_C_device()
+        Cp = device_view(pr, m + 1, torch.int32, dev).clone()
+        Cj = device_view(pc, nnzC, torch.int32, dev).clone()
+        Cx = device_view(pv, nnzC, torch.float64, dev).clone()
+        outs.append((bh.nnzCt, nnzC, Cp, Cj, Cx))
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
+    (ct0, n0, Cp, Cj, Cx), (ct1, n1, Cp1, Cj1, Cx1) = outs
+    assert ct0 == ct1 and n0 == n1
+    assert torch.equal(Cp, Cp1) and torch.equal(Cj, Cj1) and torch.equal(Cx, Cx1)      # the two pipelines: bit for bit
+    cp64 = Cp.long()
+    assert int(cp64[0]) == 0 and int(cp64[-1]) == n0 and bool((cp64[1:] >= cp64[:-1]).all())
+    inc = Cj[1:] > Cj[:-1]
+    starts = cp64[1:-1]; starts = starts[(starts > 0) & (starts < n0)]
+    inc[starts - 1] = True
+    assert bool(inc.all())
+    x = (torch.arange(m, device=dev, dtype=torch.float64) % 7) + 1.0
+    lhs = _spmv(Cp, Cj, Cx, x)
+    rhs = _spmv(Ap, Aj, Ax, _spmv(Ap, Aj, Ax, x))
+    assert torch.equal(lhs, rhs)                                                           # (integer-valued: exact in fp64)
+    # a block of rows around an irregular one against the oracle
+    r0, r1 = max(0, probe - 40), min(m, probe + 40)
+    Ab = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], val[rp[r0]:rp[r1]])
+    ref = oracle.spgemm(r1 - r0, m, m, Ab[0], Ab[1], Ab[2], rp, col, val)
+    c0, c1 = int(Cp[r0]), int(Cp[r1])
+    got = ((Cp[r0:r1 + 1] - c0).cpu().numpy().astype(np.int32), Cj[c0:c1].cpu().numpy(), Cx[c0:c1].cpu().numpy())
+    assert oracle.compare(ref, got, rel_tol=0.0)["ok"]
