@@ -329,6 +329,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The per-kernel-family breakdown (hipEvent pairs around every family: 14 events a multiply, ~30 us of a 1.6 ms step) is
+    # taken over three multiplies OUTSIDE the timed region; inside it only the numeric kernels carry events (kernel_stats = 2):
+    # the roofline's launch durations are measured live over the timed steps, as the contract asks, at a fifth of the events.
+    kfam = {}
+    assert bh.set_option("kernel_stats", 1) == 0
+    for _ in range(3 if native is None else 0):
+        step()
+        for s in bh.kernel_stats():
+            if s["launches"] > 0:
+                kfam[s["name"]] = kfam.get(s["name"], 0.0) + s["ms"] / 3
+    assert bh.set_option("kernel_stats", 2) == 0
     for _ in range(args.warmup):
         step()
     barrier()
@@ -717,7 +728,10 @@ def main():
                          "bounded below by gather_link_floor_ms per step") if world > 1 else None,
         "pipeline_compulsory_bytes": int(bytes_alg_total),
         "pipeline_frac_of_hbm_peak": round(float(pipeline_frac), 5),
-        "kernels_ms_per_step": {k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items())},
+        # (numeric kernels: the timed steps' own events; the other families: three multiplies in front of the timed region)
+        "kernels_ms_per_step": dict({k2: round(v2, 4) for k2, v2 in sorted(kfam.items())},
+                                    **{k2: round(v["ms"] / max(1, v["steps"]), 4) for k2, v in sorted(kstats.items()) if v["ms"] > 0}),
+        "kernel_events_in_timed_region": "numeric kernels only (kernel_stats = 2); every family over 3 untimed multiplies",
         "roofline": roof, "cpu_baseline": cpu, "additional_configs": extra,
     }
     print(json.dumps(out))

@@ -25,6 +25,10 @@
 // Rows compared `period` apart (block-structured matrices) stay with k_class_fused.
 #pragma once
 
+#ifndef BHS_TILE_EH       // entries of a row compared at a time (for A: so many gathers of B's classes in flight per lane): poisson27pt 160^3 classify_rows 0.327 / 0.303 / 0.293 / 0.385 ms with 4 / 8 / 16 / 32
+#define BHS_TILE_EH 16
+#endif
+
 namespace bhs {
 
 constexpr int kClassTileBlock = 512;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(kClassTileBlock) __attribute__((amdgpu_waves_per_eu
         // (no short-circuit and no branch anywhere near a DPP move or a shuffle: a lane that has stopped evaluating is masked out
         // and hands its neighbour nothing)
         int diff = 0, neg = 0;
-        constexpr int EH = LMAX > 8 ? 8 : LMAX;                    // entries at a time: EH loads in flight per lane
+        constexpr int EH = LMAX > BHS_TILE_EH ? BHS_TILE_EH : LMAX;    // entries at a time: EH loads in flight per lane
 #pragma unroll
         for (int e0 = 0; e0 < LMAX; e0 += EH) {
             int cv[EH], cbv[IS_A ? EH : 1];

@@ -365,7 +365,10 @@ int bhs_get_kernel_stats(bhs_handle* h, bhs_kernel_stat* out, int cap)
 int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
 {
     if (!h || !key) return BHS_ERR_INVALID_ARG;
-    h->classSpec.valid = false;                                     // (any option may change what a multiply decides)
+    // (2: event pairs around the numeric kernels only -- what a roofline of the dominant kernel needs, at a fifth of the events;
+    // timers decide nothing: what the next multiply may assume of the last one stands)
+    if (!strcmp(key, "kernel_stats")) { h->kernelStats = (int)std::max<int64_t>(0, std::min<int64_t>(value, 2)); return BHS_SUCCESS; }
+    h->classSpec.valid = false;                                     // (any other option may change what a multiply decides)
     h->laneSpec.valid = false;
     if (!strcmp(key, "spec_numeric")) { h->specNumeric = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "class_tile_piece")) { h->classTilePiece = (int)std::max<long long>(0, std::min<long long>(value, 1 << 17)); return BHS_SUCCESS; }
@@ -401,7 +404,6 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
 #endif
     if (!strcmp(key, "lane_numeric")) { h->laneNumeric = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "compress_b")) { h->compressB = (int)value; h->cmpState = 0; return BHS_SUCCESS; }
-    if (!strcmp(key, "kernel_stats")) { h->kernelStats = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "concurrent_bins")) { h->concurrentBins = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "window_bitmap")) { h->useWindowBitmap = (int)value; return BHS_SUCCESS; }
     if (!strcmp(key, "sym_bitmap_min_log2")) { h->symBitmapMinLog2 = (int)value; return BHS_SUCCESS; }
