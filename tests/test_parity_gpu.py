@@ -1583,7 +1583,7 @@ def _mixed_run(oracle, m, k, n, A, B, options=None, multiplies=2, expect_rows=No
 
 @pytest.mark.parametrize("case", ["p27_extra_entries", "p27_one_long_row", "p27_hub_row", "p9_extra_entries", "tridiagonal_long_row",
                                   "rect_toeplitz_extra", "p27_empty_rows", "p27_f32", "p27_long_row_first_and_last",
-                                  "p27_one_percent"])
+                                  "p27_one_percent", "p27_row_block"])
 def test_row_class_path_mixed_mode(oracle, case):
     """Round 6: a structured matrix with a few irregular rows stays on the class kernels; the irregular rows -- and the rows
     of A that point at an irregular row of B -- go through the general pipeline's kernels inside the same multiply, one
@@ -1595,8 +1595,8 @@ def test_row_class_path_mixed_mode(oracle, case):
         nx, ny, nz = 24, 22, 20
         rp, col = gallery.poisson_csr("poisson27pt", nx, ny, nz)
         m = k = n = len(rp) - 1
-        if case in ("p27_extra_entries", "p27_f32"):
-            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.002, seed=5)
+        if case in ("p27_extra_entries", "p27_f32", "p27_row_block"):
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.005 if case == "p27_row_block" else 0.002, seed=5)
             expect = (20, 1200)
         elif case == "p27_one_percent":
             rp, col = gallery.perturb_rows_csr(rp, col, n, 0.01, seed=6)
@@ -1620,6 +1620,13 @@ def test_row_class_path_mixed_mode(oracle, case):
             col = col[keep]
             expect = (0, 400)                                    # (an empty row is a class like any other; the rows that point at one find room in the table)
         A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
+        if case == "p27_row_block":
+            # a rank's share of the multi-GPU job: rows [r0, r1) of the perturbed matrix against the whole of it -- only the rows of
+            # B that the block points at are classified, counted and pruned
+            r0, r1 = 3000, 6500
+            m = r1 - r0
+            A = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], B[2][rp[r0]:rp[r1]])
+            expect = (50, 1100)
     elif case == "p9_extra_entries":
         rp, col = gallery.poisson_csr("poisson9pt", 120, 90, 1)
         m = k = n = len(rp) - 1
