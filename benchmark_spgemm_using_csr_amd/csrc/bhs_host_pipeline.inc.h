@@ -947,13 +947,13 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // takes k_row_block 0.09 ms) go to ONE side stream and the ring kernel starts beside them at once: its workgroups on
         // the few CUs those hold start late, and with its super-runs handed out by the XCDs' counters (ring_dynamic) nobody
         // waits for them.
-        const bool beside = anyBin > 0 && h->ps.mixRows <= kMixBesideRows && h->ringDynamic != 0 && !h->mixFork;
+        BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0 && h->mixFork != 0));
+        const bool beside = !h->binsForked && anyBin > 0 && h->ps.mixRows <= kMixBesideRows && h->ringDynamic != 0;
         if (beside) {                                            // (their kernels FIRST: what the ring kernel has taken it keeps until it ends)
             BHS_HIP(hipEventRecord(h->evFork, h->stream));
             BHS_HIP(hipStreamWaitEvent(h->binStream[0], h->evFork, 0));
+            h->besideStream = h->binStream[0];
         }
-        BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0 && h->mixFork != 0));
-        if (beside) h->besideStream = h->binStream[0];
         if (numCount[kHubBin]) {
             bin_stream(h, kHubBin);
             BHS_TRY(timed_begin(h, "numeric_hub_rows", &ep));

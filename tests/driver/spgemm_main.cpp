@@ -8,7 +8,7 @@
 // runs unchanged on them.
 //
 //   ./spgemm -hip|-cuda|-opencl -spgemm <0|1|2|3|4|A.mtx> [B.mtx] [-seed S] [-grid NX NY [NZ]]
-//            [-keepvalues] [-nocheck] [-cpu] [-gpus N [-ranges S]]
+//            [-keepvalues] [-nocheck] [-cpu] [-devsort] [-gpus N [-ranges S]]
 // -gpus N: one child process per GPU (forked before anything touches a GPU), rows of A in N work-balanced blocks, B
 // replicated, C assembled on every rank by the library's RCCL all-gatherv (include/bhsparse_dist.h); rank 0 checks.
 // datasets (main.cu:30-53): 0 built-in 4x6*6x4 test, 1 poisson5pt 256^2, 2 poisson9pt 256^2,
@@ -39,6 +39,7 @@ struct Options {
     uint64_t seed = 20140519ull;
     int gx = 0, gy = 0, gz = 0;
     bool keepvalues = false, check = true, cpu_time = false;
+    bool devsort = false;             // -devsort: rows of a .mtx file stay in file order on the host -- the library sorts B's rows on the device (bhs_set_data), A's need no order
     int gpus = 0, ranges = 4;
     int rank = -1;                   // (-rank R -idfile F: this process IS rank R of a -gpus run; set by the parent's exec)
     string idfile;
@@ -277,17 +278,19 @@ static int benchmark_spgemm(const char *dataset_name1, const char *dataset_name2
         auto since = [](chrono::steady_clock::time_point t0) { return chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count(); };
         cout << " A: " << dataset_name1 << endl;
         auto t0 = chrono::steady_clock::now();
-        if (read_matrix_market(dataset_name1, A, &msg)) { cout << msg << endl; return -10; }
+        if (read_matrix_market(dataset_name1, A, &msg, !opt.devsort)) { cout << msg << endl; return -10; }
         cout << " Matrix Market reader: " << since(t0) << " ms." << endl;
         cout << " B: " << dataset_name2 << endl;
         t0 = chrono::steady_clock::now();
         if (strcmp(dataset_name1, dataset_name2) == 0) B = A;      // C = A^2: one parse
-        else if (read_matrix_market(dataset_name2, B, &msg)) { cout << msg << endl; return -10; }
+        else if (read_matrix_market(dataset_name2, B, &msg, !opt.devsort)) { cout << msg << endl; return -10; }
         cout << " Matrix Market reader: " << since(t0) << " ms." << endl;
         if (A.num_cols != B.num_rows) { cout << "dimension mismatch" << endl; return -11; }
         // main.cu:62-64 (the reader already sorts; kept so that the call sequence is the reference's)
-        csr_sort_indices<index_type, value_type>(A.num_rows, A.row_offsets.data(), A.column_indices.data(), A.values.data());
-        csr_sort_indices<index_type, value_type>(B.num_rows, B.row_offsets.data(), B.column_indices.data(), B.values.data());
+        if (!opt.devsort) {
+            csr_sort_indices<index_type, value_type>(A.num_rows, A.row_offsets.data(), A.column_indices.data(), A.values.data());
+            csr_sort_indices<index_type, value_type>(B.num_rows, B.row_offsets.data(), B.column_indices.data(), B.values.data());
+        } else cout << " rows left in file order: the device library sorts what it needs sorted" << endl;
     }
     if (!opt.keepvalues) {            // main.cu:79-94, with a fixed seed instead of time(NULL)
         fill_values(A.values, opt.seed, 0);
@@ -339,6 +342,7 @@ int main(int argc, char **argv)
             if (argc > argi && argv[argi][0] != '-') opt.gz = atoi(argv[argi++]);
         } else if (o == "-keepvalues") opt.keepvalues = true;
         else if (o == "-nocheck") opt.check = false;
+        else if (o == "-devsort") opt.devsort = true;
         else if (o == "-cpu") opt.cpu_time = true;
         else if (o == "-gpus" && argc > argi) opt.gpus = atoi(argv[argi++]);
         else if (o == "-ranges" && argc > argi) opt.ranges = atoi(argv[argi++]);
