@@ -307,7 +307,11 @@ __global__ __launch_bounds__(1024) void k_class_numeric_big(
         if (rg >= nRanges) break;
         const int row0 = rg * range, nr = min(range, m - row0);
         __syncthreads();                                           // (the range before is done with sCls)
-        for (int t = tid; t < range; t += NT) sCls[t] = t < nr ? classC[row0 + t] : -1;
+        // (mixed mode, bhs_class_mix.hip.h: a row without a class carries kClassDummy -- the general pipeline's kernels write it)
+        for (int t = tid; t < range; t += NT) {
+            const int c = t < nr ? classC[row0 + t] : -1;
+            sCls[t] = c == kClassDummy ? -1 : c;
+        }
         for (;;) {
             if (tid == 0) sMisc[0] = 0x7fffffff;
             __syncthreads();

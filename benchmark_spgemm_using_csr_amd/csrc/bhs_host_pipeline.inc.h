@@ -573,11 +573,11 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
             if (cs[CS_CLASSES] == 0) return to_general("no class");
             if (mixRows > 0) {
                 if ((long long)mixRows * 100 > (long long)h->mixMaxPct * m) return to_general("too many rows without a class");
-                if (cs[CS_BIGCOUNT]) return to_general("big classes");        // (k_class_numeric_big takes every row)
                 h->ps.classMaxNnz = cs[CS_MAXNNZ];
                 h->ps.classMaxNA = cs[CS_MAXNA];
                 h->ps.classMaxRing2 = std::max(cs[CS_RINGFULL], cs[CS_RINGONE]);
-                if (h->classNumeric < 2 || !class_ring2_fits(h)) return to_general("classes beyond the ring kernel");
+                // (the kernels that pass an irregular row by: the ring kernel, and k_class_numeric_big for block-structured grids)
+                if (!cs[CS_BIGCOUNT] && (h->classNumeric < 2 || !class_ring2_fits(h))) return to_general("classes beyond the ring kernel");
             }
             // (an irregular row is a head, and so is the row behind it: they are not what the verdict below is about)
             if (h->classHeadsOn && h->classPath != 2 && !cs[CS_BIGCOUNT] && ((long long)cs[CS_HEADS] - 2LL * mixRows) * 4 > (long long)m)
@@ -948,7 +948,7 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // the few CUs those hold start late, and with its super-runs handed out by the XCDs' counters (ring_dynamic) nobody
         // waits for them.
         BHS_TRY(fork_bins(h, numCount, kNumNumBins, anyBin > 0 && h->mixFork != 0));
-        const bool beside = !h->binsForked && anyBin > 0 && h->ps.mixRows <= kMixBesideRows && h->ringDynamic != 0;
+        const bool beside = !h->binsForked && anyBin > 0 && h->ps.mixRows <= kMixBesideRows && h->ringDynamic != 0 && !h->ps.classBig;
         if (beside) {                                            // (their kernels FIRST: what the ring kernel has taken it keeps until it ends)
             BHS_HIP(hipEventRecord(h->evFork, h->stream));
             BHS_HIP(hipStreamWaitEvent(h->binStream[0], h->evFork, 0));
@@ -978,7 +978,8 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         h->besideStream = nullptr;
         h->ps.ringBeside = beside;
         BHS_TRY(timed_begin(h, "numeric_class", &ep));
-        BHS_TRY(launch_class_ring(h, r0, r1));
+        if (h->ps.classBig) BHS_TRY(launch_class_numeric_big(h, r0, r1));
+        else BHS_TRY(launch_class_ring(h, r0, r1));
         BHS_TRY(timed_end(h, ep));
         h->ps.ringBeside = false;
         h->stats[ep->stat].launches++;

@@ -1583,7 +1583,7 @@ def _mixed_run(oracle, m, k, n, A, B, options=None, multiplies=2, expect_rows=No
 
 @pytest.mark.parametrize("case", ["p27_extra_entries", "p27_one_long_row", "p27_hub_row", "p9_extra_entries", "tridiagonal_long_row",
                                   "rect_toeplitz_extra", "p27_empty_rows", "p27_f32", "p27_long_row_first_and_last",
-                                  "p27_one_percent", "p27_row_block"])
+                                  "p27_one_percent", "p27_row_block", "fem3_extra_entries", "fem3_long_row"])
 def test_row_class_path_mixed_mode(oracle, case):
     """Round 6: a structured matrix with a few irregular rows stays on the class kernels; the irregular rows -- and the rows
     of A that point at an irregular row of B -- go through the general pipeline's kernels inside the same multiply, one
@@ -1627,6 +1627,18 @@ def test_row_class_path_mixed_mode(oracle, case):
             m = r1 - r0
             A = ((rp[r0:r1 + 1] - rp[r0]).astype(np.int32), col[rp[r0]:rp[r1]], B[2][rp[r0]:rp[r1]])
             expect = (50, 1100)
+    elif case.startswith("fem3"):
+        # several unknowns per node (81 entries a row, 6561 products: the big-class kernels, bhs_class_big.hip.h) with irregular rows:
+        # k_class_numeric_big passes them by as the ring kernel does
+        rp, col = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", 14, 13, 12), 3)
+        m = k = n = len(rp) - 1
+        if case == "fem3_extra_entries":
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.004, seed=21)
+            expect = (20, int(0.3 * m))
+        else:
+            rp, col = gallery.perturb_rows_csr(rp, col, n, 0.0, long_row=(m // 2 + 1, 500))
+            expect = (1, 2500)
+        A = B = (rp, col, rng.integers(1, 10, len(col)).astype(np.float64))
     elif case == "p9_extra_entries":
         rp, col = gallery.poisson_csr("poisson9pt", 120, 90, 1)
         m = k = n = len(rp) - 1

@@ -3,16 +3,21 @@
 entry, one 300-entry row -- through the facade: ms per multiply (wall clock around bhs_spgemm, inputs resident), the
 kernel-family breakdown, the number of rows that took the general pipeline's kernels, and the digest of C against the
 general pipeline's (class_path = 0) on the same input.
-usage: mixed_case.py [n=128] [cases=clean,p0.1,p1,long]   env BHS_OPTS=key=value,.."""
+usage: mixed_case.py [n=128 | fem40] [cases=clean,p0.1,p1,long]   env BHS_OPTS=key=value,.."""
 import os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from benchmark_spgemm_using_csr_amd import gallery, facade
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+arg1 = sys.argv[1] if len(sys.argv) > 1 else "128"
 cases = (sys.argv[2] if len(sys.argv) > 2 else "clean,p0.1,p1,long").split(",")
 dev = torch.device("cuda", 0)
-rp0, col0 = gallery.poisson_csr("poisson27pt", n, n, n)
+if arg1.startswith("fem"):                     # "fem40": 3 unknowns per node on poisson27pt 40^3 (the big-class kernels)
+    n = int(arg1[3:])
+    rp0, col0 = gallery.block_expand_csr(*gallery.poisson_csr("poisson27pt", n, n, n), 3)
+else:
+    n = int(arg1)
+    rp0, col0 = gallery.poisson_csr("poisson27pt", n, n, n)
 m = len(rp0) - 1
 
 
