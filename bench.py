@@ -612,6 +612,7 @@ def main():
         torch.cuda.empty_cache()
         clean_ms = ms_per_step
         for wname in ("p5_1024", "p9_1024", "p27_160", "p27_128", "p27_128_perturbed", "p27_128_perturbed_1pct", "p27_128_one_long_row", "fem3_40",
+                      "fem3_40_one_long_row",
                       "weblike_1m", "rmat_s20", "p27_256_block_1of8", "p27_256"):
             k2 = None                                   # (rows of B, where A is not the whole of it)
             if wname.startswith("p27_128_"):
@@ -641,10 +642,13 @@ def main():
                 st2, d2 = "web-like power-law (gallery.weblike_csr)", (1000005,)
                 rpw, colw = gallery.weblike_csr()
                 bp2, bj2 = torch.from_numpy(rpw).to(dev), torch.from_numpy(colw).to(dev)
-            elif wname == "fem3_40":      # 3 unknowns per node on poisson27pt 40^3, every coupling a full block
+            elif wname in ("fem3_40", "fem3_40_one_long_row"):      # 3 unknowns per node on poisson27pt 40^3, every coupling a full block
                 st2, d2 = "poisson27pt (x) ones(3,3)", (40, 40, 40)
                 rp0, col0 = gallery.poisson_csr("poisson27pt", 40, 40, 40)
                 rp3, col3 = gallery.block_expand_csr(rp0, col0, 3)
+                if wname.endswith("one_long_row"):     # (round 6: mixed mode with the big-class kernel; vs_clean against fem3_40)
+                    st2 = "poisson27pt (x) ones(3,3) + one 500-entry row"
+                    rp3, col3 = gallery.perturb_rows_csr(rp3, col3, len(rp3) - 1, 0.0, long_row=((len(rp3) - 1) // 2 + 1, 500))
                 bp2, bj2 = torch.from_numpy(rp3).to(dev), torch.from_numpy(col3).to(dev)
             else:
                 st2, d2, _ = workload_dims(wname, 1)
@@ -684,6 +688,12 @@ def main():
                     if s_["launches"] > 0:
                         kacc[s_["name"]] = kacc.get(s_["name"], 0.0) + s_["ms"] / 3
             extra[wname]["kernels_ms_per_step"] = {k_: round(v_, 4) for k_, v_ in sorted(kacc.items()) if v_ >= 0.0005}
+            if wname == "fem3_40":
+                fem_ms = msq
+            if wname == "fem3_40_one_long_row":
+                extra[wname]["vs_clean"] = round(msq / fem_ms, 4)
+                extra[wname]["irregular_rows"] = int(bh.get_info("mixed_rows"))
+                extra[wname]["class_state"] = int(bh.get_info("class_state"))
             if wname == "p27_128":
                 clean_ms = msq                                      # (the headline's matrix timed the way these short runs are: kernel_stats off)
             if wname.startswith("p27_128_"):
