@@ -106,7 +106,7 @@ int bhs_destroy(bhs_handle* h)
     release(h->classB); release(h->classC); release(h->classTab); release(h->classInfo);
     release(h->classHeads); release(h->classHeadCnt); release(h->classMap); release(h->classMapA); release(h->classRing); release(h->classRel); release(h->classLane);
     release(h->classBigIdx); release(h->classBigMap);
-    release(h->mixList); release(h->classCount);
+    release(h->mixList); release(h->classCount); release(h->laneBlockSums);
     release(h->bWin); release(h->bWinTab); release(h->bWinSpill);
     release(h->hubBits); release(h->hubRank); release(h->hubItems); release(h->hubSeg); release(h->hubCtl);
     release(h->spaBits);
@@ -411,6 +411,7 @@ int bhs_set_option(bhs_handle* h, const char* key, int64_t value)
     if (!strcmp(key, "lds_bitmap")) { h->useLdsBitmap = value != 0; return BHS_SUCCESS; }
     if (!strcmp(key, "hub_min_products")) { h->hubMin = (int)std::min<int64_t>(value, 0x7fffffff); return BHS_SUCCESS; }
     if (!strcmp(key, "hub_item_products")) { if (value < 64) return BHS_ERR_INVALID_ARG; h->hubItemProducts = (int)std::min<int64_t>(value, 1 << 30); return BHS_SUCCESS; }
+    if (!strcmp(key, "lane_from_counts")) { h->laneFromCounts = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "scan_one_pass")) { h->scanOnePass = value ? 1 : 0; return BHS_SUCCESS; }
     if (!strcmp(key, "ub_lanes")) {      // (tuning hook) lanes per row of A in k_upper_bound, a power of two; rows beyond 32 passes go to its long list
         int g = 1;

@@ -570,8 +570,10 @@ int launch_row_quad(bhs_handle* h, const int4* queue, int qn, int* CpOrCnt)
 
 template <bool NUM>
 int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCnt, int* ubOut = nullptr,
-                    unsigned long long* ctSlots = nullptr, const int* specWord = nullptr)
+                    unsigned long long* ctSlots = nullptr, const int* specWord = nullptr,
+                    int* blockSums = nullptr, long long assumedNnzC = 0, int* specOut = nullptr)   // (k_row_lane: "rowPtrC on the way")
 {
+    const int nBlocks = (int)(((long long)qn + 255) / 256);
     const unsigned grid = (unsigned)(((long long)qn + 255) / 256);
     const bool smallB = h->allowSmallB && h->nnzB < (1 << 29);
     // every row's products in registers where the longest rows of A and B seen at hand-over keep them to 32 (checked per
@@ -594,11 +596,11 @@ int launch_row_lane(bhs_handle* h, int K, const int4* queue, int qn, int* CpOrCn
         if (smallB)                                                                                           \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, true>), dim3(grid), dim3(256), 0, h->ls, queue, qn,       \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
-                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord);        \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord, blockSums, nBlocks, assumedNnzC, specOut); \
         else                                                                                                  \
             hipLaunchKernelGGL((k_row_lane<KK, NUM, false>), dim3(grid), dim3(256), 0, h->ls, queue, qn,      \
                                h->dAp, h->dAj, h->dAx, h->dBp, h->dBj, h->dBx, CpOrCnt, out_cj(h),                    \
-                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord);        \
+                               out_cx(h), ubOut, ctSlots, (int*)h->small.p + S_ERR, specWord, blockSums, nBlocks, assumedNnzC, specOut); \
         break;
     switch (K) {
         BHS_LANE(4) BHS_LANE(6) BHS_LANE(8) BHS_LANE(10) BHS_LANE(12)

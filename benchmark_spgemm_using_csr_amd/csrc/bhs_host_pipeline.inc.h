@@ -73,6 +73,7 @@ int join_bins(bhs_handle* h)
 // per-row counts in Cp and tells stage 3 which choices it made.
 struct SymChoices {
     bool noUpperBound = false, symDirect = false, laneFirst = false;
+    bool blockSums = false;           // the lane kernel left the entries of every block of 256 rows (laneBlockSums)
     int laneK = 0, hubRows = 0;
     BinSpec numSpec;
 };
@@ -213,9 +214,16 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     if (symCount[kLaneBin]) {
         bin_stream(h, kLaneBin);
         BHS_TRY(timed_begin(h, "symbolic_lane", &ep));
+        int* blockSums = nullptr;                          // (lane-first: the numeric kernel may make rowPtrC from these, pipeline_symbolic)
+        if (laneFirst && h->laneFromCounts && (long long)m <= 256LL * kLaneFromCountsBlocks) {
+            // (the blocks' sums, then -- 8-byte aligned -- their exclusive scan and the total)
+            BHS_TRY(ensure(h, h->laneBlockSums, sizeof(int) * (size_t)kLaneFromCountsBlocks + sizeof(long long) * ((size_t)kLaneFromCountsBlocks + 1)));
+            blockSums = (int*)h->laneBlockSums.p;
+        }
         BHS_TRY(launch_row_lane<false>(h, laneK, symQueue ? symQueue + symStart[kLaneBin] : nullptr, symCount[kLaneBin], (int*)h->Cp.p,
                                        laneFirst ? (int*)h->ub.p : nullptr,
-                                       laneFirst ? (unsigned long long*)(small + S_CT_SLOTS) : nullptr));
+                                       laneFirst ? (unsigned long long*)(small + S_CT_SLOTS) : nullptr, nullptr, blockSums));
+        out.blockSums = blockSums != nullptr;
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;
         h->stats[ep->stat].rows += symCount[kLaneBin];
@@ -643,6 +651,31 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     const BinSpec& numSpec = sc.numSpec;
 
     // ------------------------------------------------------------ stage 3: scan, allocate C, numeric queues
+    // Round 6, a lane-first multiply whose numeric kernel may go out on the last multiply's nnz(C) (laneSpec): no scan kernel and
+    // no check kernel either -- the numeric kernel's blocks sum the symbolic kernel's block sums, compare the total with the
+    // nnz(C) C was sized for (all of them the same verdict; nothing is written otherwise) and make rowPtrC on the way.  Not for
+    // callers that want rowPtrC on the host while the numeric kernel runs.
+    h->ps.laneFirst = !useClass && sc.laneFirst;
+    if (!useClass && !restart && sc.laneFirst && sc.blockSums && !h->wantHostRowPtr && h->specNumeric && h->laneSpec.valid &&
+        h->laneSpec.laneK == sc.laneK && !h->lazyOut && h->directBins && (h->laneNumeric == 1 || (h->laneNumeric == 2 && sc.laneK <= 8))) {
+        const long long need = std::max<long long>(h->laneSpec.nnzC, 1);
+        const bool room = h->extCj ? h->laneSpec.nnzC <= h->extCap
+                                   : (h->Cj.p && h->Cx.p && h->Cj.cap >= (size_t)need * sizeof(int) && h->Cx.cap >= (size_t)need * sizeof(value_t));
+        if (room) {
+            h->ps.specLaunched = true;
+            h->ps.specLane = true;
+            h->ps.fromCounts = true;
+            h->specLaunches++;
+            h->nnzC = h->laneSpec.nnzC;
+            h->nnzCt = h->laneSpec.nnzCt;                  // (pipeline_finish puts this multiply's own count here)
+            h->ps.noUpperBound = sc.noUpperBound;
+            h->ps.symDirect = sc.symDirect;
+            h->ps.laneK = sc.laneK;
+            h->ps.numSpec = sc.numSpec;
+            BHS_HIP(hipEventRecord(h->ev[3], h->stream));
+            return stage_rowptr_and_open(h);
+        }
+    }
     BHS_TRY(timed_begin(h, "scan_rowptr", &ep));
     if (useClass) {
         // one pass: every row's count from its class, scanned with look-back over the tiles before (k_class_scan)
@@ -896,6 +929,16 @@ int numeric_stage(bhs_handle* h, int r0, int r1)
         // (a whole multiply: bhs_spgemm_symbolic's lazyOut keeps the two-halves API off this path)
         h->ps.rangesRun++;
         BHS_TRY(timed_begin(h, "numeric_lane", &ep));
+        if (h->ps.fromCounts) {
+            const int nb = (int)(((long long)h->m + 255) / 256);
+            hipLaunchKernelGGL(k_lane_block_prefix, dim3(1), dim3(1024), 0, h->ls, nb, (const int*)h->laneBlockSums.p,
+                               reinterpret_cast<long long*>((int*)h->laneBlockSums.p + kLaneFromCountsBlocks));
+            BHS_HIP(hipGetLastError());
+        }
+        if (h->ps.fromCounts)
+            BHS_TRY(launch_row_lane<true>(h, laneK, nullptr, h->m, (int*)h->Cp.p, nullptr, nullptr, nullptr, (int*)h->laneBlockSums.p, h->laneSpec.nnzC,
+                                          (int*)h->small.p + S_SPEC));
+        else
         BHS_TRY(launch_row_lane<true>(h, laneK, nullptr, h->m, (int*)h->Cp.p, nullptr, nullptr, (const int*)h->small.p + S_SPEC));
         BHS_TRY(timed_end(h, ep));
         h->stats[ep->stat].launches++;

@@ -28,6 +28,7 @@ namespace bhs {
 // 32-bit lane offset form: no 64-bit address pair per head.
 // waves per SIMD asked of the register allocator (left alone it keeps both arms of every predicated load live:
 // 118 VGPRs for K = 6); the numeric pass is bounded by its LDS staging buffers (S = 16: 52 KB per workgroup)
+constexpr int kLaneFromCountsBlocks = 8192;       // "rowPtrC on the way": every block of the numeric kernel sums all the blocks' sums -- up to this many (2 M rows)
 constexpr int lane_waves(int K, bool NUM) { return !NUM ? (K <= 8 ? 8 : K <= 10 ? 6 : 5) : (BHS_LANE_S == 16 ? 3 : BHS_LANE_S == 8 ? (K <= 10 ? 5 : 4) : (K <= 10 ? 7 : 4)); }
 
 template <int K, bool NUM, bool SMALLB>
@@ -39,7 +40,13 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
                                                   int* __restrict__ Cj, value_t* __restrict__ Cx,
                                                   int* __restrict__ ubOut, unsigned long long* __restrict__ ctSlots,
                                                   int* __restrict__ errFlag,
-                                                  const int* __restrict__ specWord = nullptr)   // launched before the host saw this multiply's counts (k_lane_spec_check): go on only if 1
+                                                  const int* __restrict__ specWord = nullptr,   // launched before the host saw this multiply's counts (k_lane_spec_check): go on only if 1
+                                                  // round 6, "rowPtrC on the way": symbolic pass -- blockSums[block] = entries of the block's 256 rows;
+                                                  // numeric pass, direct -- cntOut holds the COUNTS: this block sums the blocks' sums before it, scans
+                                                  // its own rows and writes rowPtrC in place; nothing is written (specOut = 2) unless the sums of all
+                                                  // blocks are the nnz(C) the host assumed when it sized C
+                                                  int* __restrict__ blockSums = nullptr, int nBlocks = 0, long long assumedNnzC = 0,
+                                                  int* __restrict__ specOut = nullptr)
 {
     if (specWord != nullptr && *specWord != 1) return;
     // ubOut != nullptr (symbolic pass of a "lane-first" multiply, where no upper-bound pass ran): the row's product
@@ -62,6 +69,30 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
     // is row q (its descriptor comes from rowPtrA and, for the numeric pass, rowPtrC in cntOut)
     int4 d = make_int4(0, 0, 0, 0);
     if (more) d = desc ? desc[q] : make_int4(q, Ap[q], Ap[q + 1], NUM ? cntOut[q] : 0);
+    if constexpr (NUM) {
+        if (blockSums != nullptr) {                        // (block-uniform: cntOut holds counts, rowPtrC is made here)
+            // (blockSums[nBlocks + 1 + b]: entries in the blocks before block b, [2 nBlocks + 1]: in all -- the symbolic kernel's last block)
+            __shared__ int sCnt[4];
+            const long long* pfx = reinterpret_cast<const long long*>(blockSums + kLaneFromCountsBlocks);
+            const long long pre = pfx[blockIdx.x], total = pfx[nBlocks];
+            if (total != assumedNnzC) {                        // nothing of C is written: the host runs the multiply again the slow way
+                if (blockIdx.x == 0 && threadIdx.x == 0) *specOut = 2;
+                return;
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) *specOut = 1;
+            const int cnt = more ? d.w : 0;
+            const int incl = wave_incl_scan_dpp(cnt);
+            if (lane == 63) sCnt[w] = incl;
+            __syncthreads();
+            long long at = pre + incl - cnt;
+            for (int ww = 0; ww < w; ++ww) at += sCnt[ww];
+            if (more) {
+                cntOut[q] = (int)at;
+                if (q == qn - 1) cntOut[qn] = (int)(at + cnt);
+            }
+            d.w = (int)at;
+        }
+    }
     const int row = d.x, a0 = d.y, nA = d.z - d.y;
     // lane-first / direct launches rest on the longest row of A seen at bhs_set_data time: verified here (bit 1 of the
     // error word sends the host back through the general pipeline)
@@ -124,6 +155,13 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
         acc_t sum;
         while (more) { more = step(mn, sum); cnt += more ? 1 : 0; }
         if (q < qn) cntOut[row] = cnt;
+        if (blockSums != nullptr) {                          // (direct launches: block b holds the rows 256 b ..)
+            __shared__ int csum[4];
+            const int ws = wave_sum_dpp(q < qn ? cnt : 0);
+            if (lane == 63) csum[w] = ws;
+            __syncthreads();
+            if (threadIdx.x == 0) blockSums[blockIdx.x] = csum[0] + csum[1] + csum[2] + csum[3];
+        }
         if (ubOut) {
             __shared__ unsigned long long bsum;
             if (threadIdx.x == 0) bsum = 0;
@@ -169,6 +207,27 @@ __global__ __launch_bounds__(256, lane_waves(K, NUM)) void k_row_lane(const int4
             wave_sync();
         }
     }
+}
+
+// "rowPtrC on the way" (round 6): the exclusive scan of the symbolic lane kernel's block sums (64-bit) and their total behind it --
+// one workgroup, a few microseconds, between the symbolic and the numeric kernel.  (As the symbolic kernel's last block to finish
+// it cost 100 us: that block's device-coherent loads of the other blocks' sums come one at a time.)
+__global__ __launch_bounds__(1024) void k_lane_block_prefix(int nb, const int* __restrict__ sums, long long* __restrict__ pfx)
+{
+    __shared__ long long wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (nb + 1023) / 1024;
+    long long mine = 0;
+    for (int i = tid * per; i < min(nb, (tid + 1) * per); ++i) mine += sums[i];
+    long long x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wtot[w] = x;
+    __syncthreads();
+    long long at = x - mine, total = 0;
+    for (int ww = 0; ww < 16; ++ww) { at += ww < w ? wtot[ww] : 0; total += wtot[ww]; }
+    for (int i = tid * per; i < min(nb, (tid + 1) * per); ++i) { pfx[i] = at; at += sums[i]; }
+    if (tid == 0) pfx[nb] = total;
 }
 
 // Speculative numeric launch of a lane-first multiply (round 6; the class path has had one since round 5, bhs_class.hip.h):

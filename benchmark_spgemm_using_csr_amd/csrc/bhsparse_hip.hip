@@ -171,6 +171,10 @@ struct bhs_handle {
     struct ClassSpec { bool valid = false; int cs[CS_INTS]; long long nnzC = 0, nnzCt = 0; } classSpec;
     // ... the same for a lane-first multiply whose numeric stage ran k_row_lane on every row (k_lane_spec_check)
     struct LaneSpec { bool valid = false; int laneK = 0; long long nnzC = 0, nnzCt = 0; } laneSpec;
+    // ... and rowPtrC made by the numeric kernel itself from the symbolic kernel's counts and block sums (k_row_lane), no scan
+    // kernel, no check kernel: option "lane_from_counts" (1; up to kLaneFromCountsBlocks blocks of 256 rows)
+    int laneFromCounts = 1;
+    DevBuf laneBlockSums;
     int classTilePiece = 0;              // option "class_tile_piece": rows per wave of that classifier (0: one piece per wave slot)
     int classTile = 1;                   // option "class_tile": the classifier with a lane per row (bhs_class_tile.hip.h) where rows have at most 32 entries
     int specNumeric = 1;                 // option "spec_numeric": 0 never launch speculatively
@@ -314,6 +318,7 @@ struct bhs_handle {
         bool bWinBuilt = false;          // bWin / bWinTab belong to this multiply
         bool specLaunched = false;       // the numeric kernel goes out on the last multiply's figures (classSpec), k_class_spec_check decides
         bool specLane = false;           // ... a lane-first multiply's (laneSpec, k_lane_spec_check)
+        bool fromCounts = false;         // ... whose numeric kernel makes rowPtrC from the counts (no scan ran)
         bool laneFirst = false;          // this multiply's symbolic stage was the lane kernel on every row, no upper-bound pass
         bool mixed = false;              // class path with irregular rows on the general kernels (bhs_class_mix.hip.h)
         int mixRows = 0;                 // ... how many
@@ -345,7 +350,7 @@ enum { S_SYM_COUNT = 0, S_SYM_START = 16, S_SYM_CURSOR = 32, S_NUM_COUNT = 48, S
        S_MIX_COUNT = 104 + 195 /* rows on the mixed mode's list of irregular rows (bhs_class_mix.hip.h) */,
        S_MIX_SYM2 = 104 + 196 /* kMaxBins: their symbolic bins on the coarse ladder (S_SYM_COUNT: on the fine one) */,
        S_RING_TICKETS = 104 + 212 /* 8: the ring kernel's next super-run per XCD (bhs_class_ring.hip.h) */,
-       S_ZERO_END = 104 + 220,   /* everything below is zeroed at the start of every spgemm */
+       S_ZERO_END = 104 + 220,   /* everything below is zeroed at the start of every spgemm (324 ints: a multiple of 16 bytes -- hipMemsetAsync is ONE fill kernel then, three otherwise) */
        S_SORTED = 324, S_MAXROW = 325, S_SPEC = 326 /* k_class_spec_check's word: 1 the speculative numeric launch stands, 2 refuted */,
        S_LONG_B = 327 /* rows on k_check_sorted's long list */,
        S_TICKETS = 328 /* kMaxBins: one scheduler ticket per bin, bins run concurrently */,
