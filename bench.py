@@ -334,7 +334,7 @@ def main():
     # the roofline's launch durations are measured live over the timed steps, as the contract asks, at a fifth of the events.
     kfam = {}
     assert bh.set_option("kernel_stats", 1) == 0
-    for _ in range(3 if native is None else 0):
+    for _ in range(3):                                        # (every rank alike: the steps of an N > 1 job are collective)
         step()
         for s in bh.kernel_stats():
             if s["launches"] > 0:
