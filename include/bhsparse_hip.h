@@ -250,7 +250,22 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     the classes' figures of the multiply before (k_class_spec_check compares them with this multiply's
  *                     on the device; a refuted launch writes nothing and the multiply runs again); 0: always wait for
  *                     the read-back.  bhs_get_info: "spec_launches", "spec_refuted"
- *   "spin_wait"       1 (default): a multiply's waits for its stream poll (<= 50 ms) before they sleep; 0: sleep at once
+ *                     (round 6: a lane-first multiply -- every row through the lane kernels -- likewise, k_lane_spec_check;
+ *                     "lane_from_counts" 1 (default): its numeric kernel then makes rowPtrC from the symbolic kernel's counts
+ *                     and block sums, no scan kernel)
+ *   "class_mixed"     1 (default, round 6): a row without a class -- or of a class beyond the tables, or of a class with fewer
+ *                     than four rows -- goes through the general pipeline's kernels inside the same multiply while the other
+ *                     rows stay on the class kernels (bhs_class_mix.hip.h; the reference bins every row for itself,
+ *                     SpGEMM_cuda/bhsparse.h:483-586); 0: one such row sends the data set to the general pipeline, as until
+ *                     round 5.  "class_mixed_max_pct" (default 30): more irregular rows than this share of all rows send
+ *                     the data set to the general pipeline.  bhs_get_info: "class_state", "mixed_rows"
+ *   "kernel_stats"    0 (default) no per-kernel timers; 1 hipEvent pairs around every kernel family (bhs_get_kernel_stats);
+ *                     2 around the numeric kernels only
+ *   "ring_dynamic"    the ring kernel's super-runs handed out by a counter per XCD: 0 never, 1 always, 2 (default) where other
+ *                     kernels run beside it
+ *   "spin_wait"       1 (default): a multiply's waits for its stream poll, with a pause between polls, for at most
+ *                     "spin_wait_us" microseconds (default 0: four times the last multiply's wall time, 0.5 .. 5 ms) before
+ *                     they sleep; 0: sleep at once
  *   "hub_min_products"  rows with at least this many intermediate products are split across workgroups
  *                     (bhs_hub.hip.h: items of "hub_item_products" products handed out to the whole device, one shared
  *                     bitmap slot per row); default 131072, 0 never.  "hub_item_products" (default 8192, >= 64),
@@ -269,6 +284,9 @@ BHS_API int bhs_set_option(bhs_handle *h, const char *key, int64_t value);
  *                matrix is a whole number of such lines (a wave of the class numeric kernel then takes whole lines), else 0
  *   "compress_b_used"  1 when the symbolic pass of the general pipeline runs on B's pattern compressed to (column block,
  *                mask) pairs for this data set
+ *   "class_state"  which pipeline this data set's multiplies take: 1 row classes, 2 row classes with irregular rows on the
+ *                general pipeline's kernels (mixed mode), -1 the general pipeline (for good: until the next bhs_set_data)
+ *   "mixed_rows"   rows of the last multiply that had no class and went through the general pipeline's kernels (0: none)
  * Returns BHS_ERR_INVALID_ARG for unknown keys, BHS_ERR_NOT_READY without data.  */
 BHS_API int bhs_get_info(bhs_handle *h, const char *key, int64_t *value_out);
 
