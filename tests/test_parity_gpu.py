@@ -704,10 +704,11 @@ def test_hub_rows_in_row_ranges(oracle):
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
-@pytest.mark.parametrize("n", [2 ** 20, 2 ** 20 + 1, 3000000])
+@pytest.mark.parametrize("n", [2 ** 20, 2 ** 20 + 1, 3000000, 40000, 200000, 400000, 2 ** 19 + 5])
 def test_long_rows_bitmap_accumulators(oracle, n):
     """Rows beyond the LDS hash tables, with and without duplicate columns, either side of the 2^20-column limit
-    of the LDS-resident bitmap (wider matrices keep the bitmap in HBM).  Replaces the reference's
+    of the LDS-resident bitmap (wider matrices keep the bitmap in HBM); the narrow ones have the LDS kernel's lanes
+    own one or two eight-word groups of the bitmap, or none, instead of four.  Replaces the reference's
     EM_mergepath_global rounds (bhsparse_cuda.h:2270-2525)."""
     rng = np.random.default_rng(n % 1000)
     k = 2000
