@@ -988,7 +988,10 @@ __global__ __launch_bounds__(256) void k_class_patterns(const unsigned long long
         for (int q = tid; q < kClassMaxLoads * 64; q += 256) {
             const int un = colour ? (int)sUnitOwner[q] : q;
             unsigned word = 0;
-            if (un != 255 && un * kClassEpl < slab0) {
+            // (255: a coloured position without a unit.  Uncoloured, position 255 IS unit 255 -- the last 16 bytes of a slab of
+            // exactly 512 values, 32 B rows of 15 or 16 entries, say: until round 6's soak found it, that unit was never loaded
+            // and the products that read it were products with whatever the ring held there)
+            if (!(colour && un == 255) && un * kClassEpl < slab0) {
                 const int x = un * kClassEpl;
                 int c = 0;
                 for (int cc = 1; cc < nChains; ++cc) c += x >= (sChain[cc] >> 16) ? 1 : 0;
@@ -1250,7 +1253,11 @@ __device__ __forceinline__ void class_store_c2_at(double* base, unsigned off, do
 {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2 v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, %2" BHS_CLS_STORE_POLICY ::"v"(off), "v"(v), "s"(base) : "memory");
+    // (s_nop 1: a VMEM store of more than 64 bits reads its data over the next two wait states on gfx940+, and the compiler's
+    // hazard recogniser does not see a store inside an asm statement: without it k_class_ring<16, 8, 4> had `v_or_b32 v22, 0x80, v26`
+    // -- the next pair's entry number -- one s_or_b64 behind `global_store_dwordx4 v28, v[22:25]`, and lanes 12 .. 15 of every 16
+    // stored that in the low word of their first value now and then.  Found by the mixed-mode soak, round 6.)
+    asm volatile("global_store_dwordx4 %0, %1, %2" BHS_CLS_STORE_POLICY "\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void class_store_c2_at(float* base, unsigned off, float a, float b)
 {

@@ -310,7 +310,8 @@ def spgemm_csr(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx, device=0, warmups=0, options=Non
         if err:
             raise BhsparseError("get_C", err)
         info = {"nnzCt": bh.nnzCt, "nnzC": nnzC, "stage_ms": bh.stage_ms, "time_ms": bh.time_ms,
-                "kernels": bh.kernel_stats()}
+                "kernels": bh.kernel_stats(), "mixed_rows": bh.get_info("mixed_rows"),
+                "class_state": bh.get_info("class_state")}
         err = bh.free_mem()
         if err:
             raise BhsparseError("free_mem", err)

@@ -1341,7 +1341,7 @@ def test_row_classes_with_a_column_twice_in_rows_of_b(oracle):
 
 @pytest.mark.parametrize("case", ["p27", "p5", "p7", "p9", "rect_toeplitz", "holes", "float_values", "f32_build",
                                   "unsorted_b", "row_block", "fem_3dof", "fem_4dof", "fem_3dof_f32", "long_b_rows",
-                                  "fem_3dof_row_block"])
+                                  "fem_3dof_row_block", "slab_of_512_values", "five_steps_five_pairs"])
 def test_row_class_path(oracle, case):
     """Row classes (bhs_class.hip.h): inputs whose rows repeat one another's relative pattern take the class kernels --
     classify_rows / class_patterns / numeric_class instead of upper bound, symbolic and numeric bins -- and give the
@@ -1386,6 +1386,23 @@ def test_row_class_path(oracle, case):
         m, k, n = 2000, 2500, 4000          # 3 entries per row of A, 100 per row of B: few products, but a B entry's number needs 7 bits
         A = _toeplitz(m, k, (-7, 0, 300), rng)
         B = _toeplitz(k, n, tuple(range(-50, 50)), rng)
+    elif case == "slab_of_512_values":
+        # 32 B rows of 15 entries: a slab of exactly 4 x 64 16-byte units -- the last one, number 255, was taken for "no unit"
+        # and never loaded (the mixed-mode soak's seed 361, round 6); 480 products, 358 entries: k_class_ring<16, 8>
+        m, k, n = 9000, 9200, 9100
+        # (offsets in fours: every cut-off pattern along the borders has >= 4 rows, no class is too small to keep)
+        offa = np.unique(rng.integers(-375, 376, 60) * 4)[:32]; offb = np.unique(rng.integers(-375, 376, 30) * 4)[:15]
+        assert len(offa) == 32 and len(offb) == 15 and len(np.unique(offa[:, None] + offb[None, :])) > 256
+        A = _toeplitz(m, k, tuple(int(o) for o in offa), rng)
+        B = _toeplitz(k, n, tuple(int(o) for o in offb), rng)
+    elif case == "five_steps_five_pairs":
+        # 9 x 31 entries: 279 products, 263 entries a row -- k_class_ring<16, 8>, whose 16-byte stores of two values had the
+        # next pair's entry number written over their first word two wait states too early (the soak's seed 327)
+        m, k, n = 20000, 20500, 21000
+        offa = np.unique(rng.integers(-625, 626, 12) * 4)[:9]; offb = np.unique(rng.integers(-625, 626, 50) * 4)[:31]
+        assert len(offa) == 9 and len(offb) == 31 and len(np.unique(offa[:, None] + offb[None, :])) > 256
+        A = _toeplitz(m, k, tuple(int(o) for o in offa), rng)
+        B = _toeplitz(k, n, tuple(int(o) for o in offb), rng)
     elif case == "rect_toeplitz":
         m, k, n = 3000, 3500, 5000          # relative columns far from 0, rows cut off at every border
         A = _toeplitz(m, k, (-40, -3, 0, 1, 2, 500, 501, 3400), rng)
@@ -1450,6 +1467,154 @@ if os.environ.get("BHS_SOAK") == "1":             # (BHS_SOAK=1 python -m pytest
         """The same draw with up to 40 000 rows of at most 32 entries: many steps and pieces of the lane-per-row classifier
         (bhs_class_tile.hip.h), heads in every lane, last steps of every length.  Round 5: 120 of 120 bit-exact."""
         _randomized_class_case(oracle, seed, big=True)
+
+
+    @pytest.mark.parametrize("seed", list(range(300 + int(os.environ.get("BHS_SOAK_BASE", "0")), 396 + int(os.environ.get("BHS_SOAK_BASE", "0")))))
+    def test_row_class_path_mixed_soak(oracle, seed):
+        """Mixed mode (bhs_class_mix.hip.h) on random structured products of 8 000 - 60 000 rows: a share of the rows of A
+        and of B with an entry more or less, a few rows of 130 - 700 entries (longer than the ring kernel's chunk of A's
+        values), a run of neighbouring irregular rows, empty rows; two multiplies of one handle (the second one launched on
+        what the first one found), both against the oracle bit for bit."""
+        _randomized_mixed_case(oracle, seed)
+
+
+    @pytest.mark.parametrize("seed", list(range(500 + int(os.environ.get("BHS_SOAK_BASE", "0")), 596 + int(os.environ.get("BHS_SOAK_BASE", "0")))))
+    def test_general_pipeline_soak(oracle, seed):
+        """The general pipeline (upper bound, bins, symbolic and numeric kernels of every size, bitmaps in LDS and in HBM,
+        column windows, hub rows) on random inputs of every shape the draw below knows -- row lengths constant, uniform,
+        power-law or with a few very long rows; columns uniform, banded or from a small pool; 500 to 60 000 rows, up to
+        3 M columns -- against the oracle bit for bit, with the defaults and with one switch thrown."""
+        (m, k, n, how), A, B = _general_soak_inputs(seed)
+        ref = oracle.spgemm(m, k, n, *A, *B)
+        rng = np.random.default_rng(seed)
+        alt = [{"concurrent_bins": 0}, {"lds_bitmap": 0}, {"spa": 0}, {"window_bitmap": 2}, {"spec_numeric": 0}, {"lane_from_counts": 0},
+               {"max_table_log2": 8}, {"no_pack32": 1}, {"hub_min_products": 200000}][int(rng.integers(0, 9))]
+        for opts in ({}, alt):
+            Cp, Cj, Cx, info = spgemm_csr(m, k, n, *A, *B, options=opts)
+            assert info["nnzCt"] == oracle.nnzCt(A[0], A[1], B[0]) and info["nnzC"] == ref[0][-1], (seed, how, opts)
+            res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+            assert res["ok"], (seed, how, opts, res, sorted(_kernel_names(info)))
+        print("general soak, seed %d: %d x %d x %d, %s, %d products -> %d entries; %s" % (
+            seed, m, k, n, how, info["nnzCt"], info["nnzC"], " ".join(sorted(_kernel_names(info)))))
+
+
+def _general_soak_inputs(seed):
+    rng = np.random.default_rng(9000 + seed)
+
+    def lengths(rows, cols, kind, mean):
+        if kind == "const": L = np.full(rows, mean)
+        elif kind == "uniform": L = rng.integers(0, 2 * mean + 1, rows)
+        elif kind == "powerlaw": L = np.minimum((rng.pareto(1.3, rows) * mean / 3).astype(np.int64), 6000)
+        else:                                                        # short rows and a few very long ones
+            L = rng.integers(0, mean + 1, rows)
+            idx = rng.integers(0, rows, int(rng.integers(1, 12)))
+            L[idx] = rng.integers(300, 8000, len(idx))
+        L = np.minimum(L, cols)
+        L[rng.random(rows) < 0.01] = 0
+        return L.astype(np.int64)
+
+    def matrix(rows, cols, kindL, mean, kindC):
+        L = lengths(rows, cols, kindL, mean)
+        r = np.repeat(np.arange(rows, dtype=np.int64), L)
+        if kindC == "uniform": c = rng.integers(0, cols, len(r))
+        elif kindC == "banded":
+            w = int(rng.choice([50, 2000, 40000]))
+            c = np.clip(r * cols // rows + (rng.standard_normal(len(r)) * w).astype(np.int64), 0, cols - 1)
+        else:
+            pool = rng.integers(0, cols, max(8, min(cols, int(rng.choice([64, 3000, 50000])))))
+            c = pool[rng.integers(0, len(pool), len(r))]
+        key = np.unique(r * cols + c)                                # (sorted rows without duplicates; a row may come out shorter)
+        r, c = key // cols, key % cols
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum(np.bincount(r, minlength=rows))
+        return rp, c.astype(np.int32), rng.integers(-9, 10, len(c)).astype(np.float64)
+
+    m = int(np.exp(rng.uniform(np.log(500), np.log(60000)))); k = int(np.exp(rng.uniform(np.log(500), np.log(60000))))
+    n = int(np.exp(rng.uniform(np.log(500), np.log(3.0e6))))
+    kA, kB = (str(rng.choice(["const", "uniform", "powerlaw", "long"])) for _ in range(2))
+    cA, cB = (str(rng.choice(["uniform", "banded", "pool"])) for _ in range(2))
+    meanA, meanB = int(rng.choice([1, 3, 8, 20, 60])), int(rng.choice([1, 3, 8, 20, 60, 200]))
+    A = matrix(m, k, kA, meanA, cA)
+    B = matrix(k, n, kB, meanB, cB)
+    prod = np.add.reduceat(np.append(np.diff(B[0])[A[1]].astype(np.int64), 0), np.minimum(A[0][:-1], len(A[1]))) if len(A[1]) else np.zeros(m, np.int64)
+    prod[np.diff(A[0]) == 0] = 0
+    total = int(prod.sum())
+    if total > 30000000:                                            # (the oracle in a second or two: the first rows that hold 3e7 products)
+        m = max(1, int(np.searchsorted(np.cumsum(prod), 30000000)))
+        A = (A[0][:m + 1].copy(), A[1][:A[0][m]].copy(), A[2][:A[0][m]].copy())
+    if seed % 4 == 1:                                                # rows of B in random stored order (sorted at set_data time by default)
+        Bp, Bj, Bx = B
+        key = np.repeat(np.arange(k), np.diff(Bp)) + rng.random(len(Bj))
+        o = np.argsort(key, kind="stable")
+        B = (Bp, Bj[o], Bx[o])
+    how = "A %s/%s %d, B %s/%s %d" % (kA, cA, meanA, kB, cB, meanB)
+    return (m, k, n, how), A, B
+
+
+def _mixed_soak_inputs(seed):
+    rng = np.random.default_rng(7000 + seed)
+    # (row i of A has its entries at i * sa + offsets, row j of B at j * sb + offsets: the rows of C repeat a handful of patterns)
+    # (a step other than 1: no two rows with the same columns relative to the row -- the class path gives way)
+    sa, sb = ([(1, 1)] * 6 + [(1, 2), (2, 1)])[int(rng.integers(0, 8))]
+    m = int(rng.integers(8000, 60000)); k = m * sa + int(rng.integers(-3000, 3000)); n = k * sb + int(rng.integers(-3000, 3000))
+    na = int(rng.choice([5, 9, 17, 27, 32])); nb = int(rng.choice([7, 9, 15, 27, 32]))
+    if seed >= 3300:                                             # (BHS_SOAK_BASE=3000: rows of up to 64 entries, up to 1024 products a row)
+        na = int(rng.choice([3, 12, 31, 33, 48, 64])); nb = int(rng.choice([2, 8, 16, 31, 48, 64, 100]))
+        while na * nb > 1024: nb = max(2, nb // 2)
+        m = min(m, 24000000 // (na * nb)); k = m * sa + int(rng.integers(-3000, 3000)); n = k * sb + int(rng.integers(-3000, 3000))
+    noise = float(rng.choice([0.0, 0.0005, 0.005, 0.03]))
+
+    def structured(rows, cols, step, cnt, longs):
+        offs = np.unique(rng.integers(-min(cols // 3, 3000), min(cols // 3, 3000) + 1, cnt))
+        base = (np.arange(rows, dtype=np.int64) * step)[:, None] + offs[None, :]
+        ok = (base >= 0) & (base < cols)
+        out = [base[i][ok[i]] for i in range(rows)]
+        odd = np.flatnonzero(rng.random(rows) < noise)
+        if rng.random() < 0.3:                                   # a run of neighbouring irregular rows
+            r0 = int(rng.integers(0, rows - 200)); odd = np.union1d(odd, np.arange(r0, r0 + int(rng.integers(2, 200))))
+        for i in odd:
+            u = rng.random()
+            c = out[i]
+            if u < 0.4 and len(c) > 1: c = np.delete(c, rng.integers(0, len(c)))
+            elif u < 0.9: c = np.unique(np.append(c, rng.integers(0, cols, int(rng.integers(1, 4)))))
+            else: c = c[:0]
+            out[i] = c
+        for _ in range(longs):
+            i = int(rng.choice([0, rows - 1, rng.integers(0, rows)]))
+            out[i] = np.unique(rng.integers(0, cols, int(rng.integers(130, 700))))
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum([len(r) for r in out])
+        return rp, np.concatenate(out).astype(np.int32)
+
+    Ap, Aj = structured(m, k, sa, na, int(rng.integers(0, 4)))
+    Bp, Bj = structured(k, n, sb, nb, int(rng.integers(0, 2)) if rng.random() < 0.3 else 0)
+    Ax = rng.integers(-9, 10, len(Aj)).astype(np.float64)
+    Bx = rng.integers(-9, 10, len(Bj)).astype(np.float64)
+    return (m, k, n, sa, sb, na, nb, noise), (Ap, Aj, Ax), (Bp, Bj, Bx)
+
+
+def _randomized_mixed_case(oracle, seed):
+    (m, k, n, sa, sb, na, nb, noise), (Ap, Aj, Ax), (Bp, Bj, Bx) = _mixed_soak_inputs(seed)
+    ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, Bp, Bj, Bx)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0
+    assert bh.set_option("class_path", 2) == 0
+    Cp = np.zeros(m + 1, np.int32)
+    assert bh.initData(m, k, n, len(Aj), Ax, Ap, Aj, len(Bj), Bx, Bp, Bj, Cp) == 0
+    for it in range(2):
+        assert bh.spgemm() == 0
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        assert bh.nnzCt == oracle.nnzCt(Ap, Aj, Bp)
+        res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+        names = sorted(s_["name"] for s_ in bh.kernel_stats() if s_["launches"])
+        assert res["ok"], (seed, it, res, names)
+    print("mixed soak, seed %d: %d x %d x %d (steps %d, %d), %d / %d entries per row, noise %.4f -> class_state %d, %d irregular rows, %s" % (
+        seed, m, k, n, sa, sb, na, nb, noise, bh.get_info("class_state"), bh.get_info("mixed_rows"),
+        "numeric_class" if "numeric_class" in names else "general pipeline"))
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
 
 
 def _randomized_class_case(oracle, seed, big):
