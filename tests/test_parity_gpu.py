@@ -1494,8 +1494,33 @@ if os.environ.get("BHS_SOAK") == "1":             # (BHS_SOAK=1 python -m pytest
             assert info["nnzCt"] == oracle.nnzCt(A[0], A[1], B[0]) and info["nnzC"] == ref[0][-1], (seed, how, opts)
             res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
             assert res["ok"], (seed, how, opts, res, sorted(_kernel_names(info)))
+        # ... and on one handle: a multiply, then one in row ranges
+        plats = [False] * bhmod.NUM_PLATFORMS
+        plats[bhmod.BHSPARSE_HIP] = True
+        bh = bhmod.bhsparse()
+        assert bh.initPlatform(plats) == 0
+        Cp = np.zeros(m + 1, np.int32)
+        assert bh.initData(m, k, n, len(A[1]), A[2], A[0], A[1], len(B[1]), B[2], B[0], B[1], Cp) == 0
+        assert bh.spgemm() == 0
+        cuts = _multiply_in_row_ranges(bh, m, rng)
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+        assert res["ok"], (seed, how, "row ranges", cuts, res)
+        assert bh.free_mem() == 0 and bh.freePlatform() == 0
         print("general soak, seed %d: %d x %d x %d, %s, %d products -> %d entries; %s" % (
             seed, m, k, n, how, info["nnzCt"], info["nnzC"], " ".join(sorted(_kernel_names(info)))))
+
+
+def _multiply_in_row_ranges(bh, m, rng):
+    """bhs_spgemm_symbolic, bhs_spgemm_numeric on 1 .. 5 random row ranges (some empty), bhs_spgemm_finish: what the multi-GPU
+    layer runs on one handle."""
+    assert bh.spgemm_symbolic() == 0
+    cuts = np.concatenate(([0], np.sort(rng.integers(0, m + 1, int(rng.integers(0, 5)))), [m]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert bh.spgemm_numeric(int(a), int(b)) == 0
+    assert bh.spgemm_finish() == 0
+    return [int(c) for c in cuts]
 
 
 def _general_soak_inputs(seed):
@@ -1605,14 +1630,17 @@ def _randomized_mixed_case(oracle, seed):
     assert bh.set_option("class_path", 2) == 0
     Cp = np.zeros(m + 1, np.int32)
     assert bh.initData(m, k, n, len(Aj), Ax, Ap, Aj, len(Bj), Bx, Bp, Bj, Cp) == 0
-    for it in range(2):
-        assert bh.spgemm() == 0
+    rng = np.random.default_rng(seed)
+    for it in range(3):                                          # (the third one in row ranges)
+        cuts = None
+        if it < 2: assert bh.spgemm() == 0
+        else: cuts = _multiply_in_row_ranges(bh, m, rng)
         Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), vd)
         assert bh.get_C(Cj, Cx) == 0
         assert bh.nnzCt == oracle.nnzCt(Ap, Aj, Bp)
         res = oracle.compare(ref, (Cp, Cj, Cx.astype(np.float64)), rel_tol=0.0)
         names = sorted(s_["name"] for s_ in bh.kernel_stats() if s_["launches"])
-        assert res["ok"], (seed, it, res, names)
+        assert res["ok"], (seed, it, cuts, res, names)
     print("mixed soak%s, seed %d: %d x %d x %d (steps %d, %d), %d / %d entries per row, noise %.4f -> class_state %d, %d irregular rows, %s" % (
         " (float)" if vd == np.float32 else "", seed, m, k, n, sa, sb, na, nb, noise, bh.get_info("class_state"), bh.get_info("mixed_rows"),
         "numeric_class" if "numeric_class" in names else "general pipeline"))
