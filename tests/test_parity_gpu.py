@@ -1588,12 +1588,23 @@ def _mixed_soak_inputs(seed):
         while na * nb > 1024: nb = max(2, nb // 2)
         m = min(m, 24000000 // (na * nb)); k = m * sa + int(rng.integers(-3000, 3000)); n = k * sb + int(rng.integers(-3000, 3000))
     noise = float(rng.choice([0.0, 0.0005, 0.005, 0.03]))
+    d = 1
+    if 6300 <= seed < 6600:                                      # (BHS_SOAK_BASE=6000 .. 6200: d unknowns per node, every coupling a full d x d block -- the big-class kernel)
+        d = int(rng.choice([2, 3, 4])); sa = sb = 1
+        na = int(rng.choice([3, 5, 7, 9])); nb = int(rng.choice([3, 5, 7, 9]))
+        m = int(rng.integers(3000, 16000)) * d; k = m + d * int(rng.integers(-500, 500)); n = k + d * int(rng.integers(-500, 500))
 
     def structured(rows, cols, step, cnt, longs):
-        offs = np.unique(rng.integers(-min(cols // 3, 3000), min(cols // 3, 3000) + 1, cnt))
-        base = (np.arange(rows, dtype=np.int64) * step)[:, None] + offs[None, :]
-        ok = (base >= 0) & (base < cols)
-        out = [base[i][ok[i]] for i in range(rows)]
+        offs = np.unique(rng.integers(-min(cols // d // 3, 3000), min(cols // d // 3, 3000) + 1, cnt))
+        base = (np.arange(rows // d, dtype=np.int64) * step)[:, None] + offs[None, :]
+        ok = (base >= 0) & (base < cols // d)
+        if d == 1:
+            out = [base[i][ok[i]] for i in range(rows)]
+        else:                                                    # (node i's columns, d scalar columns each, for each of its d rows)
+            out = []
+            for i in range(rows // d):
+                c = (base[i][ok[i]][:, None] * d + np.arange(d)[None, :]).ravel()
+                out.extend([c] * d)
         odd = np.flatnonzero(rng.random(rows) < noise)
         if rng.random() < 0.3:                                   # a run of neighbouring irregular rows
             r0 = int(rng.integers(0, rows - 200)); odd = np.union1d(odd, np.arange(r0, r0 + int(rng.integers(2, 200))))
@@ -1641,7 +1652,7 @@ def _randomized_mixed_case(oracle, seed):
         res = oracle.compare(ref, (Cp, Cj, Cx.astype(np.float64)), rel_tol=0.0)
         names = sorted(s_["name"] for s_ in bh.kernel_stats() if s_["launches"])
         assert res["ok"], (seed, it, cuts, res, names)
-    print("mixed soak%s, seed %d: %d x %d x %d (steps %d, %d), %d / %d entries per row, noise %.4f -> class_state %d, %d irregular rows, %s" % (
+    print("mixed soak%s, seed %d: %d x %d x %d (steps %d, %d), %d / %d entries per row or node, noise %.4f -> class_state %d, %d irregular rows, %s" % (
         " (float)" if vd == np.float32 else "", seed, m, k, n, sa, sb, na, nb, noise, bh.get_info("class_state"), bh.get_info("mixed_rows"),
         "numeric_class" if "numeric_class" in names else "general pipeline"))
     assert bh.free_mem() == 0 and bh.freePlatform() == 0
@@ -1660,7 +1671,10 @@ def _randomized_class_case(oracle, seed, big):
         offs = np.unique(rng.integers(-cols // 3, cols // 3 + 1, cnt))
         out = []
         for i in range(rows):
-            c = i * cols // rows + offs
+            # (row i around column i: the rows repeat one another's columns relative to the row, classes form.  Every fourth
+            # seed keeps the draw of round 5 -- row i around column i * cols / rows: no two rows alike unless the matrix is
+            # square, the class path gives way -- which is all that round's "120 of 120" had run)
+            c = (i * cols // rows if seed % 4 == 3 else i) + offs
             c = c[(c >= 0) & (c < cols)]
             u = rng.random()
             if u < noise / 2 and len(c) > 1:
@@ -1694,6 +1708,8 @@ def _randomized_class_case(oracle, seed, big):
     res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
     assert res["ok"], (seed, res, sorted(_kernel_names(info)))
     check_csr_invariants(m, n, Cp, Cj)
+    print("class draw, seed %d: %d x %d x %d, %d / %d entries per row -> class_state %d, %d irregular rows, %s" % (
+        seed, m, k, n, na, nb, info["class_state"], info["mixed_rows"], "numeric_class" if "numeric_class" in _kernel_names(info) else "general pipeline"))
 
 
 @pytest.mark.parametrize("seed", list(range(20)))
