@@ -1461,6 +1461,21 @@ def test_row_class_path_randomized(oracle, seed):
     _randomized_class_case(oracle, seed, big=False)
 
 
+@pytest.mark.parametrize("seed", [327, 361, 304, 352, 392, 1305, 3366, 4332, 6302, 6342, 6355])
+def test_mixed_mode_draws_of_the_soak(oracle, seed):
+    """A handful of the soak's draws in the default suite (the full soaks: BHS_SOAK=1): the two that found round 6's faults
+    (327: k_class_ring<16, 8> clean; 361: a slab of 512 values, 4932 irregular rows), clean and mixed ones, rows of up to 64
+    entries, the float build, block-structured ones -- three multiplies of one handle each, the last in row ranges."""
+    _randomized_mixed_case(oracle, seed)
+
+
+@pytest.mark.parametrize("seed", [504, 508, 515, 524, 543, 1506, 5564])
+def test_general_pipeline_draws_of_the_soak(oracle, seed):
+    """... and of the general pipeline's: long rows through the bitmaps in LDS and in HBM, hub rows, column windows, every
+    size of hash kernel; with the defaults, with one switch thrown, and in row ranges."""
+    _general_soak_case(oracle, seed)
+
+
 if os.environ.get("BHS_SOAK") == "1":             # (BHS_SOAK=1 python -m pytest tests -m gpu -k soak -n 4: 1.5 minutes)
     @pytest.mark.parametrize("seed", list(range(100, 220)))
     def test_row_class_path_soak(oracle, seed):
@@ -1484,6 +1499,11 @@ if os.environ.get("BHS_SOAK") == "1":             # (BHS_SOAK=1 python -m pytest
         column windows, hub rows) on random inputs of every shape the draw below knows -- row lengths constant, uniform,
         power-law or with a few very long rows; columns uniform, banded or from a small pool; 500 to 60 000 rows, up to
         3 M columns -- against the oracle bit for bit, with the defaults and with one switch thrown."""
+        _general_soak_case(oracle, seed)
+
+
+def _general_soak_case(oracle, seed):
+    if True:
         (m, k, n, how), A, B = _general_soak_inputs(seed)
         ref = oracle.spgemm(m, k, n, *A, *B)
         rng = np.random.default_rng(seed)
