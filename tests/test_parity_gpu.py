@@ -1532,6 +1532,55 @@ def _general_soak_case(oracle, seed):
             seed, m, k, n, how, info["nnzCt"], info["nnzC"], " ".join(sorted(_kernel_names(info)))))
 
 
+def _class_boundary_cases():
+    cases = []
+    for na in (1, 2, 3, 16, 31, 32, 33, 63, 64):
+        for nb in (1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 100, 128, 256):
+            if na * nb > 1024: continue
+            for kind in ("band", "random", "two_bands", "band_x_random"):
+                cases.append((na, nb, kind))
+    return cases
+
+
+@pytest.mark.parametrize("na,nb,kind", [(1, 1, "band"), (64, 16, "band"), (2, 256, "band"), (32, 32, "band"), (33, 31, "two_bands"),
+                                        (16, 64, "two_bands"), (63, 16, "two_bands"), (3, 100, "random"), (32, 16, "random")])
+def test_row_class_path_at_its_limits(oracle, na, nb, kind):
+    """Nine of the sweep below in the default suite."""
+    _class_boundary_case(oracle, na, nb, kind)
+
+
+if os.environ.get("BHS_SOAK") == "1":
+    @pytest.mark.parametrize("na,nb,kind", _class_boundary_cases())
+    def test_row_class_path_at_its_limits_soak(oracle, na, nb, kind):
+        """Row lengths at the edges of the class tables (1, 2, 16 +- 1, 32 +- 1, 64 entries of A; up to 256 of B; up to 1024
+        products), as dense bands (one chain of consecutive columns: the longest rings), random offsets (chains of one: the
+        widest slabs), two bands, and a band times random offsets."""
+        _class_boundary_case(oracle, na, nb, kind)
+
+
+def _class_boundary_case(oracle, na, nb, kind):
+    rng = np.random.default_rng(na * 1000 + nb)
+
+    def offsets(cnt, how):
+        if how == "band": return np.arange(cnt) - cnt // 2
+        if how == "two_bands": return np.concatenate((np.arange(cnt // 2) - 900, np.arange(cnt - cnt // 2) + 400))
+        o = np.unique(rng.integers(-300, 301, 4 * cnt) * 4)
+        return np.sort(rng.choice(o, cnt, replace=False))
+    offa = offsets(na, "band" if kind == "band_x_random" else kind)
+    offb = offsets(nb, "random" if kind == "band_x_random" else kind)
+    m, k, n = 7000, 7100, 7200
+    A = _toeplitz(m, k, tuple(int(o) for o in offa), rng)
+    B = _toeplitz(k, n, tuple(int(o) for o in offb), rng)
+    ref = oracle.spgemm(m, k, n, *A, *B)
+    Cp, Cj, Cx, info = spgemm_csr(m, k, n, *A, *B, options={"class_path": 2})
+    assert info["nnzCt"] == oracle.nnzCt(A[0], A[1], B[0]) and info["nnzC"] == ref[0][-1]
+    res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+    assert res["ok"], (na, nb, kind, res, sorted(_kernel_names(info)))
+    print("class limits: %d x %d entries, %s -> %d entries of C a row at most; class_state %d, %d irregular rows, %s" % (
+        na, nb, kind, int(np.diff(ref[0]).max()), info["class_state"], info["mixed_rows"],
+        "numeric_class" if "numeric_class" in _kernel_names(info) else "general pipeline"))
+
+
 def _multiply_in_row_ranges(bh, m, rng):
     """bhs_spgemm_symbolic, bhs_spgemm_numeric on 1 .. 5 random row ranges (some empty), bhs_spgemm_finish: what the multi-GPU
     layer runs on one handle."""
