@@ -1509,10 +1509,13 @@ def _general_soak_case(oracle, seed):
         rng = np.random.default_rng(seed)
         alt = [{"concurrent_bins": 0}, {"lds_bitmap": 0}, {"spa": 0}, {"window_bitmap": 2}, {"spec_numeric": 0}, {"lane_from_counts": 0},
                {"max_table_log2": 8}, {"no_pack32": 1}, {"hub_min_products": 200000}][int(rng.integers(0, 9))]
+        # (every fifth draw on the float build: sums of small integers below 2^24 are exact there too)
+        vd = np.float32 if seed % 5 == 2 and float(np.abs(ref[2]).max(initial=0.0)) < 2.0 ** 22 else np.float64
+        how += ", float" if vd == np.float32 else ""
         for opts in ({}, alt):
-            Cp, Cj, Cx, info = spgemm_csr(m, k, n, *A, *B, options=opts)
+            Cp, Cj, Cx, info = spgemm_csr(m, k, n, A[0], A[1], A[2].astype(vd), B[0], B[1], B[2].astype(vd), options=opts, value_dtype=vd)
             assert info["nnzCt"] == oracle.nnzCt(A[0], A[1], B[0]) and info["nnzC"] == ref[0][-1], (seed, how, opts)
-            res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+            res = oracle.compare(ref, (Cp, Cj, Cx.astype(np.float64)), rel_tol=0.0)
             assert res["ok"], (seed, how, opts, res, sorted(_kernel_names(info)))
         # ... and on one handle: a multiply, then one in row ranges
         plats = [False] * bhmod.NUM_PLATFORMS
