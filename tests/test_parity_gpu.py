@@ -1535,6 +1535,41 @@ def _general_soak_case(oracle, seed):
             seed, m, k, n, how, info["nnzCt"], info["nnzC"], " ".join(sorted(_kernel_names(info)))))
 
 
+@pytest.mark.parametrize("m,L", [(4000, 4), (16000, 4), (32000, 8), (34000, 8), (70000, 8), (33000, 3), (66000, 16)])
+def test_row_class_path_with_about_as_many_classes_as_table_slots(oracle, m, L):
+    """Runs of L rows with a pattern of their own (two of A's offsets change from run to run): 1000 to 8750 classes of L rows
+    each against a table of 4096 slots -- below it the class kernels with as many pattern workgroups, at and beyond it
+    whatever the library decides (the rows that find no slot are irregular rows, or the class path gives way), and runs of 3
+    rows are too short to keep a class.  Whatever runs, C is the oracle's."""
+    rng = np.random.default_rng(m + L)
+    k = n = m + 500
+    blk = np.arange(m) // L
+    offs = np.stack([np.full(m, -40), np.full(m, -1), np.zeros(m, np.int64), blk % 97 + 2, 100 + blk // 97], axis=1)
+    cols = np.arange(m)[:, None] + offs
+    ok = (cols >= 0) & (cols < k)
+    Ap = np.zeros(m + 1, np.int32); Ap[1:] = np.cumsum(ok.sum(axis=1))
+    Aj = cols[ok].astype(np.int32)
+    Ax = rng.integers(-9, 10, len(Aj)).astype(np.float64)
+    B = _toeplitz(k, n, (-3, -1, 0, 2, 40), rng)
+    ref = oracle.spgemm(m, k, n, Ap, Aj, Ax, *B)
+    plats = [False] * bhmod.NUM_PLATFORMS
+    plats[bhmod.BHSPARSE_HIP] = True
+    bh = bhmod.bhsparse()
+    assert bh.initPlatform(plats) == 0 and bh.set_option("class_path", 2) == 0
+    Cp = np.zeros(m + 1, np.int32)
+    assert bh.initData(m, k, n, len(Aj), Ax, Ap, Aj, len(B[1]), B[2], B[0], B[1], Cp) == 0
+    for it in range(2):
+        assert bh.spgemm() == 0
+        Cj = np.empty(bh.get_nnzC(), np.int32); Cx = np.empty(bh.get_nnzC(), np.float64)
+        assert bh.get_C(Cj, Cx) == 0
+        res = oracle.compare(ref, (Cp, Cj, Cx), rel_tol=0.0)
+        names = sorted(s_["name"] for s_ in bh.kernel_stats() if s_["launches"])
+        assert res["ok"], (m, L, it, res, names)
+    print("many classes: %d rows in runs of %d -> class_state %d, %d irregular rows, %s" % (
+        m, L, bh.get_info("class_state"), bh.get_info("mixed_rows"), "numeric_class" if "numeric_class" in names else "general pipeline"))
+    assert bh.free_mem() == 0 and bh.freePlatform() == 0
+
+
 def _class_boundary_cases():
     cases = []
     for na in (1, 2, 3, 16, 31, 32, 33, 63, 64):
