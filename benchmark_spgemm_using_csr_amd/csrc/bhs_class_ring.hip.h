@@ -33,6 +33,13 @@ namespace bhs {
 #ifndef BHS_RING_WAVES
 #define BHS_RING_WAVES 4
 #endif
+// ... of the instance for up to 1024 products and 512 entries a row (MAXU 16, MAXV 8): it wants 175 VGPRs.  At 4 waves (128
+// VGPRs, as until round 6) it kept 62 of them in scratch, reloaded row by row behind an s_waitcnt vmcnt(0) each: rows of 32 x 15
+// entries (400 k rows) numeric_class 1.42 ms, 9 x 31 entries 0.93; at 2 waves 0.49 - 0.58 / 0.37; at 3 (168 VGPRs, 7 spilled;
+// 13 KB of LDS a wave give 12 waves a CU anyway) 0.48 - 0.58 / 0.35.
+#ifndef BHS_RING_WAVES_WIDE
+#define BHS_RING_WAVES_WIDE 3
+#endif
 
 // {store the running sum to the lane's slot pointer, move the pointer on, restart the sum} in the lanes of `mask`
 __device__ __forceinline__ void ring_end_step(unsigned long long mask, unsigned& slotPtr, acc_t& sum)
@@ -49,7 +56,7 @@ __device__ __forceinline__ void ring_end_step(unsigned long long mask, unsigned&
 }
 
 template <int MAXU, int MAXV, int MAXJ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BHS_RING_WAVES, 8))) void k_class_ring(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXU >= 16 ? BHS_RING_WAVES_WIDE : BHS_RING_WAVES, 8))) void k_class_ring(
     int m, const int* __restrict__ Ap, const int* __restrict__ Aj, const value_t* __restrict__ Ax, long long nnzA,
     const int* __restrict__ Bp, const value_t* __restrict__ Bx, long long nnzB, const int* __restrict__ classC,
     const int4* __restrict__ classInfo, const unsigned* __restrict__ classRing, const int* __restrict__ classRel,
