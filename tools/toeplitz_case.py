@@ -18,7 +18,8 @@ for na, nb in pairs:
     offa = np.sort(rng.choice(np.arange(-750, 751) * 4, na, replace=False)); offb = np.sort(rng.choice(np.arange(-750, 751) * 4, nb, replace=False))
     Ap, Aj = toeplitz(m, m, offa); Bp, Bj = toeplitz(m, m, offb)
     t = [torch.from_numpy(x).to(dev) for x in (Ap, Aj, gallery.fill_values(len(Aj)), Bp, Bj, gallery.fill_values(len(Bj)))]
-    for opts in ({}, {"class_path": 0}):
+    sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in o.split(",") if kv) for o in os.environ["TOEP_OPTS"].split(";")] if "TOEP_OPTS" in os.environ else [{}, {"class_path": 0}]
+    for opts in sets:
         plats = [False] * 9; plats[3] = True
         bh = facade.bhsparse(); assert bh.initPlatform(plats) == 0
         for k_, v_ in opts.items(): assert bh.set_option(k_, v_) == 0
