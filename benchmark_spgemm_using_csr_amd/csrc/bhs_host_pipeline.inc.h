@@ -101,9 +101,13 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     // hub bin: rows with hubMin products or more are split across workgroups (bhs_hub.hip.h) in both stages
     const int hubMin = (h->hubMin > 0 && h->useSpa && h->forcePath == 0 && h->maxTableLog2 >= 15 && h->n <= (1 << 25))
                            ? h->hubMin : 0;
-    const BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK, hubMin);
+    BinSpec symSpec = make_spec(kSymCfg, kNumSymBins, h->maxTableLog2, h->symLoadPct, h->forcePath == 0, laneK, hubMin);
     BinSpec numSpec = make_spec(kNumCfg, kNumNumBins, std::min(h->maxTableLog2, 13), h->numLoadPct, h->forcePath == 0,
                                 (h->laneNumeric == 1 || (h->laneNumeric == 2 && laneK <= 8)) ? laneK : 0, hubMin);
+    if (h->laneRows != 2) {                                      // (lane_rows = 2: the lane kernels wherever they can run, for the tests)
+        symSpec.laneCost = kLaneCost;
+        numSpec.laneMax = std::min(numSpec.laneMax, kLaneNumMax);
+    }
     BHS_HIP(hipMemsetAsync(small, 0, sizeof(int) * S_ZERO_END, h->stream));
     EventPair* ep;
     h->cmpActive = false;
@@ -128,7 +132,7 @@ int symbolic_general(bhs_handle* h, SymChoices& out)
     // upper-bound pass, its host round trip and the symbolic queue all disappear; the lane kernel writes ub[] and
     // the product total on the side.
     const bool laneFirst = laneK > 0 && h->maxRowA <= laneK && h->laneFirst && h->directBins && !cmpRun && h->maxRowB <= 64 &&
-                           !h->specFailed;
+                           (h->laneRows == 2 || (long long)h->maxRowA * h->maxRowB * h->maxRowB <= kLaneCost) && !h->specFailed;
     // "Wave-first": maxRow(A) x maxRow(B) bounds every row's product count; when that bound fits a wave-per-row
     // table and is not far above the average row (stencils, FEM meshes: poisson27pt 27 x 27 = 729 for every interior
     // row), every row can run the symbolic wave kernel of that one table size -- again without upper-bound pass,

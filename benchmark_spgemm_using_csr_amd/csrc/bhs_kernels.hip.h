@@ -48,6 +48,7 @@ struct BinSpec {                    // bin b >= 2 holds rows with upper[b-1] < v
     int nbins;                      // bin 1 ("quad" bin): 0 < v <= quadMax and at most kQuadMaxA entries in the A row
     int quadMax;                    // 0 disables the quad bin
     int laneMax, laneMaxA;          // lane bin (kLaneBin, k_row_lane): 0 < v <= laneMax and at most laneMaxA entries in the A row
+    int laneCost;                   // ... and v^2 <= laneCost x (entries in the A row); 0: no such limit (see kLaneCost)
     int hubMin;                     // hub bin (kHubBin, bhs_hub.hip.h): rows with at least hubMin products; 0 disables
     int upper[kMaxBins];            // upper[1] is 0: the size ladder starts at bin 2
 };
@@ -61,7 +62,7 @@ constexpr int kQuadMaxA = 16;       // a 16-lane quarter wave holds one A entry 
 __device__ __forceinline__ int bin_of(const BinSpec& s, int v, int nA, int qv, int prod)
 {
     if (s.hubMin > 0 && v > 0 && prod >= s.hubMin) return kHubBin;
-    if (qv > 0 && qv <= s.laneMax && nA <= s.laneMaxA) return kLaneBin;
+    if (qv > 0 && qv <= s.laneMax && nA <= s.laneMaxA && (s.laneCost == 0 || (long long)qv * qv <= (long long)s.laneCost * nA)) return kLaneBin;
     if (qv > 0 && qv <= s.quadMax && nA <= kQuadMaxA) return 1;
     int b = 0;
 #pragma unroll

@@ -101,6 +101,14 @@ constexpr int kQuadMax = 48;        // products (symbolic) / entries (numeric) a
 
 constexpr int kLaneMaxK = 12;       // heads a lane keeps in registers (k_row_lane<K>: K = 4, 6, .., 12)
 constexpr int kLaneMax = kLaneMaxK * kLaneMaxK;   // products (symbolic) / entries (numeric) of a lane-bin row
+// What a lane's walk over its row costs grows with the LENGTH of the B rows, not with the products alone (round 6,
+// tools/toeplitz_case.py, 400 k rows of nA x nB entries, symbolic lane kernel against the wave kernels: 8 x 16 0.23 / 0.32 ms,
+// 4 x 20 0.20 / 0.29, but 6 x 20 0.37 / 0.28, 4 x 30 0.82 / 0.27, 9 x 31 1.98 / 0.52; ~ nA nB^2): the lane kernels take rows with
+// nA nB^2 <= kLaneCost -- a row's products p stand in for nA nB: p^2 <= kLaneCost nA.  The numeric lane kernel stages a row's
+// entries through LDS 16 at a time: beyond ~50 entries a row the wave kernels' tables win (7 x 7: 0.19 / 0.17 ms even,
+// 8 x 8 0.31 / 0.25, 8 x 16 0.92 / 0.43, 4 x 30 1.42 / 0.38).
+constexpr int kLaneCost = 2048;
+constexpr int kLaneNumMax = 56;
 
 BinSpec make_spec(const KernelCfg* cfg, int nbins, int maxLog2, int loadPct, bool quad, int laneK, int hubMin)
 {
