@@ -553,10 +553,13 @@ int pipeline_symbolic(bhs_handle* h, bool restart = false)
     const bool useClass = h->classPath && h->classState >= 0 && h->forcePath == 0 && h->maxTableLog2 >= 15 &&
                           cls_row_a(h) <= kClassMaxRowBig && cls_row_b(h) <= kClassMaxRowBig &&
                           (h->classPath == 2 || (h->avgRowA * h->avgRowB >= (double)h->classMinProducts &&
-                                                 // ... and enough of them: every block of the classifier meets every class once
-                                                 // (poisson27pt 51^3, 90 M products: 0.44 ms general, 0.41 ms by classes;
-                                                 // poisson9pt 512^2, 21 M: 0.20 against 0.25)
-                                                 (double)h->m * h->avgRowA * h->avgRowB >= 6e7));
+                                                 // ... and enough of them: every block of the classifier meets every class once.
+                                                 // (Round 6, class kernels against general pipeline: 16 x 16 entries a row, 25 k
+                                                 // rows -- 5.8 M products -- 0.182 / 0.179 ms, 50 k rows 0.192 / 0.266, 100 k rows
+                                                 // 0.209 / 0.435; 27 x 8 entries, 50 k rows 0.192 / 0.240; poisson27pt 40^3, 43 M
+                                                 // products, 0.219 / 0.249; poisson9pt 512^2, 21 M, 0.192 / 0.194.  Round 3's
+                                                 // kernels had put the line at 6e7.)
+                                                 (double)h->m * h->avgRowA * h->avgRowB >= 1e7));
     // Mixed mode (bhs_class_mix.hip.h): this data set's last multiply met rows without a class -- they go through the general
     // pipeline's kernels, everything else stays on the class kernels.  mixRows: how many this multiply found.
     const bool mixedFlow = useClass && h->mixOn && h->classMixed;

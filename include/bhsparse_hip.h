@@ -229,7 +229,7 @@ BHS_API int bhs_get_kernel_stats(bhs_handle *h, bhs_kernel_stat *out, int cap);
  *                     assembled on a regular grid -- get their structure (sorted columns, entry count, product ->
  *                     position map) worked out once per class instead of once per row.  1 (default): tried on data
  *                     sets whose rows of A and B have at most 256 entries and, on average, at least
- *                     "class_min_products" (default 64) products per row of C and 6e7 products in all; every row is classified and verified
+ *                     "class_min_products" (default 64) products per row of C and 1e7 products in all; every row is classified and verified
  *                     on the device, and a data set with rows that find no class (or a class of more than 8192
  *                     products / 512 entries per row of C) goes back to the general pipeline for good.
  *                     2: tried whatever the average; 0: never.

@@ -1447,7 +1447,7 @@ def test_row_class_path(oracle, case):
     assert numc["rows"] == m and numc["products"] == info["nnzCt"] and numc["nnz_out"] == info["nnzC"]
     if case in ("p27", "p5", "p9"):
         # left to itself (class_path = 1) the library takes the class kernels where they pay: rows with a few hundred
-        # products (poisson27pt: 729; from 64 on) and at least 6e7 products in all -- not the small stencils, whose whole general
+        # products (poisson27pt: 729; from 64 on) and at least 1e7 products in all -- not the small stencils, whose whole general
         # pipeline is cheaper than classifying, and not small matrices
         _, _, _, info1 = spgemm_csr(m, k, n, A[0], A[1], Ax, B[0], B[1], Bx)
         assert "numeric_class" not in _kernel_names(info1)
